@@ -1,0 +1,142 @@
+"""Deterministic, order-independent test inputs shared by make_golden.py and tests/ (TEST INFRASTRUCTURE).
+
+Every tensor is drawn from its own NumPy stream seeded by crc32(tag), so the
+golden files only need to hold the reference's OUTPUTS: tests rebuild the exact
+inputs and parameters from the tags.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+from . import mcedm_oracle as orc
+
+
+def _rng(tag: str):
+    return np.random.default_rng(zlib.crc32(tag.encode()))
+
+
+def randn(tag: str, *shape, dtype=np.float32) -> torch.Tensor:
+    return torch.from_numpy(_rng(tag).standard_normal(shape).astype(dtype))
+
+
+def uniform(tag: str, *shape) -> np.ndarray:
+    return _rng(tag).random(size=shape, dtype=np.float64) * 2.0 - 1.0
+
+
+def param(tag: str, name: str, shape) -> torch.Tensor:
+    """A test parameter called ``name`` (fill rule of mcedm_oracle.fill_param)."""
+    return torch.from_numpy(orc.fill_param(name, shape, uniform(f"{tag}/P/{name}", *shape)).astype(np.float32))
+
+
+# block shape classes of SURVEY.md §3.4 (+ a 2-head block for ch=128)
+BLOCK_CASES = {
+    "plain": dict(cin=64, cout=64),
+    "down": dict(cin=64, cout=64, down=True),
+    "up": dict(cin=64, cout=64, up=True),
+    "attn": dict(cin=64, cout=64, attn=True),
+    "cat": dict(cin=128, cout=64),
+    "catattn": dict(cin=128, cout=64, attn=True),
+    "attn2h": dict(cin=128, cout=128, attn=True),
+}
+
+
+def block_spec(tag: str) -> orc.BlockSpec:
+    c = BLOCK_CASES[tag]
+    cin, cout = c["cin"], c["cout"]
+    up, down, attn = c.get("up", False), c.get("down", False), c.get("attn", False)
+    skip = (1 if cin != cout else 0) if (cin != cout or up or down) else -1
+    return orc.BlockSpec("blk", cin, cout, up, down, attn, cout // 64 if attn else 0, skip)
+
+
+def block_params(tag: str, emb: int = 64):
+    b = block_spec(tag)
+    return {n: param(f"blocks/{tag}", n, s) for n, s in orc.block_param_shapes(b, emb)}
+
+
+def block_inputs(tag: str, n_emb: int, B: int = 2, H: int = 8, W: int = 8, emb: int = 64):
+    b = block_spec(tag)
+    return randn(f"blocks/{tag}/n{n_emb}/x", B, b.cin, H, W), randn(f"blocks/{tag}/n{n_emb}/emb", n_emb, emb)
+
+
+# ---- per-op cases ----------------------------------------------------------
+CONV_CASES = {"k3": dict(kernel=3), "k3up": dict(kernel=3, up=True), "k3down": dict(kernel=3, down=True),
+              "k1": dict(kernel=1), "k0up": dict(kernel=0, up=True), "k0down": dict(kernel=0, down=True)}
+
+
+def conv_channels(tag):
+    return (8, 8) if CONV_CASES[tag]["kernel"] == 0 else (8, 16)
+
+
+ATTN_CASES = {64: (2, (8, 8)), 256: (1, (16, 16))}        # tokens -> (batch, spatial), 2 heads x 64 ch
+PE_LABELS = torch.tensor([-1.5536, -0.1733, 1.0955, 0.25], dtype=torch.float32)
+
+# ---- whole-network cases -----------------------------------------------------
+CFG_P = orc.UNetConfig()                                                     # adm_edm_mcedm_res32.yaml, ch=64
+CFG_W = orc.UNetConfig(ch=128, ch_mult=(1, 1, 1, 1), attn_resolutions=(16,))  # BASELINE config 3 shape
+UNET_LABELS = {"n1": torch.tensor([0.3]), "nB": torch.tensor([-1.2, -0.1, 0.6, 1.1])}
+UNET_W_LABELS = torch.tensor([0.1, -0.7])
+PRECOND_SIGMAS = (0.002, 0.5, 80.0)
+PRECOND_SIGMA_B = torch.tensor([0.05, 0.4, 2.0, 30.0])
+
+# ---- sampler cases: tag -> (S_churn, mask kind) --------------------------------
+SAMPLER_CASES = {"det_u": (0.0, "u"), "churn_u": (15.0, "u"), "det_h": (0.0, "h_time")}
+
+
+def task_mask(kind: str, B: int, H: int, W: int) -> torch.Tensor:
+    """NCHW masks, 1 = missing.  'u': h observed, u missing (h5_dataset.py:245-247);
+    'h': the converse; 'h_time': h missing everywhere, u missing for t >= H/2 (h5_dataset.py:370-373)."""
+    m = torch.zeros(B, 2, H, W)
+    if kind == "u":
+        m[:, 1] = 1.0
+    elif kind == "h":
+        m[:, 0] = 1.0
+    elif kind == "h_time":
+        m[:, 0] = 1.0
+        m[:, 1, H // 2:] = 1.0
+    else:
+        raise ValueError(kind)
+    return m
+
+
+def sampler_inputs(tag: str, B: int = 4, H: int = 32, W: int = 32, n_steps: int = 18):
+    churn, kind = SAMPLER_CASES[tag]
+    m = task_mask(kind, B, H, W)
+    state = randn(f"sampler/{tag}/state", B, 2, H, W)
+    cond = state * (1 - m) + randn(f"sampler/{tag}/cond_noise", B, 2, H, W) * m
+    init = randn(f"sampler/{tag}/init", B, 2, H, W)
+    # per-step noise is fp32-representable so an fp32 transport of it loses nothing
+    steps = [randn(f"sampler/{tag}/step{i}", B, 2, H, W).double() for i in range(n_steps)]
+    return cond, m, init, steps
+
+
+# ---- training case -------------------------------------------------------------
+TRAIN_NORM_STATS = (1.4, 0.2, 0.0, 0.5)        # input mean/std, target mean/std
+TRAIN_GRAD_NAMES = ["enc.128x128_conv.weight", "out_conv.weight", "enc.64x64_down.norm1.weight",
+                    "dec.32x32_block0.affine.weight", "dec.32x32_in0.qkv.weight", "dec.128x128_block1.skip.weight",
+                    "map_layer0.weight", "dec.32x32_in0.proj.bias", "enc.32x32_block0.conv0.weight",
+                    "dec.64x64_up.conv1.bias"]
+
+
+def training_inputs(B: int = 4, T: int = 32, X: int = 32):
+    """The reference's 5-tuple batch pieces (NHWC, h5_dataset.py:257-261) + injected noises."""
+    h = randn("train/h", B, T, X, 1) * 0.2 + 1.4
+    u = randn("train/u", B, T, X, 1) * 0.5
+    mask = torch.zeros(B, T, X, 2)
+    mask[0, ..., 1] = 1
+    mask[1, ..., 0] = 1
+    mask[2, ..., 1] = 1
+    mask[3, : T // 2, :, 0] = 1
+    mask[3, ..., 1] = 1
+    cond_noise = randn("train/cond_noise", B, T, X, 2)
+    noise = randn("train/noise", B, 2, T, X)
+    rnd_normal = randn("train/rnd_normal", B, 1, 1, 1)
+    return h, u, mask, cond_noise, noise, rnd_normal
+
+
+def training_nchw(h, u, mask, cond_noise):
+    """data_transform + get_cond_in + rearranges of training_step (mcedm.py:259-265,274)."""
+    st = TRAIN_NORM_STATS
+    x = torch.cat([(h - st[0]) / st[1], (u - st[2]) / st[3]], dim=-1)
+    cond_in = orc.cond_input(x, mask, cond_noise).permute(0, 3, 1, 2).contiguous()
+    return x.permute(0, 3, 1, 2).contiguous(), cond_in, mask.permute(0, 3, 1, 2).contiguous()

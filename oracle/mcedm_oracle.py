@@ -1,0 +1,438 @@
+"""CPU oracle for the m-cedm EDM hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32/fp64) restatement of the reference's
+algorithm for the one hot path this repository accelerates.  It is NOT part of
+the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it, and only as the checker.
+The product path (``m-cedm_amd/``) never imports it and fails loudly when the
+HIP library is missing.
+
+Parity pinning: every function below is checked against the reference itself
+(imported from /root/reference in the build container by
+``oracle/make_golden.py``) and against the golden vectors that script commits
+under ``tests/golden/`` (see ``tests/test_oracle_golden.py``).
+
+Functions cite the reference lines they restate (paths relative to the
+reference checkout).  Parameters are passed as a flat ``dict[str, Tensor]``
+keyed exactly like ``DhariwalUNet.state_dict()`` so that reference checkpoints
+and the HIP path share one naming scheme.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- #
+# architecture description (restates DhariwalUNet.__init__, adm_blocks.py:203-317)
+# --------------------------------------------------------------------------- #
+@dataclass
+class UNetConfig:
+    """Subset of ``hparams.model`` the hot path reads (adm_edm_mcedm_res32.yaml:4-28)."""
+    in_channels: int = 2
+    cond_channels: int = 2
+    out_ch: int = 2
+    ch: int = 64
+    ch_mult: Tuple[int, ...] = (1, 1, 1)
+    num_res_blocks: int = 1
+    attn_resolutions: Tuple[int, ...] = (32,)
+    resolution: int = 128
+    channels_per_head: int = 64
+    eps: float = 1e-5
+
+
+@dataclass
+class BlockSpec:
+    key: str            # e.g. "enc.64x64_down"
+    cin: int
+    cout: int
+    up: bool = False
+    down: bool = False
+    attn: bool = False
+    heads: int = 0
+    skip_kernel: int = -1   # -1 no skip module, 0 resample-only, 1 1x1 conv
+
+
+@dataclass
+class UNetSpec:
+    cfg: UNetConfig
+    conv_in_key: str
+    enc: List[BlockSpec] = field(default_factory=list)
+    dec: List[BlockSpec] = field(default_factory=list)
+    # channel count pushed on the skip stack by conv_in and each encoder block
+    skip_channels: List[int] = field(default_factory=list)
+
+
+def build_spec(cfg: UNetConfig) -> UNetSpec:
+    """Block list of the network, in execution order (adm_blocks.py:282-317)."""
+    ch = cfg.ch
+    in_total = cfg.in_channels + cfg.cond_channels      # cat_cond=True (adm_blocks.py:236-238)
+    res0 = cfg.resolution
+    spec = UNetSpec(cfg=cfg, conv_in_key=f"enc.{res0}x{res0}_conv")
+
+    def mk(key, cin, cout, up=False, down=False, attn=False):
+        heads = cout // cfg.channels_per_head if attn else 0        # adm_blocks.py:135
+        skip_kernel = -1
+        if cout != cin or up or down:                               # adm_blocks.py:148-151
+            skip_kernel = 1 if cout != cin else 0
+        return BlockSpec(key, cin, cout, up, down, bool(heads), heads, skip_kernel)
+
+    cout = in_total
+    for level, mult in enumerate(cfg.ch_mult):
+        res = cfg.resolution >> level
+        if level == 0:
+            cout = ch * mult
+            spec.skip_channels.append(cout)          # conv_in output is skips[0] (adm_blocks.py:392)
+        else:
+            spec.enc.append(mk(f"enc.{res}x{res}_down", cout, cout, down=True))
+            spec.skip_channels.append(cout)
+        for idx in range(cfg.num_res_blocks):
+            cin = cout
+            cout = ch * mult
+            spec.enc.append(mk(f"enc.{res}x{res}_block{idx}", cin, cout, attn=(res in cfg.attn_resolutions)))
+            spec.skip_channels.append(cout)
+    skips = list(spec.skip_channels)
+    for level, mult in reversed(list(enumerate(cfg.ch_mult))):
+        res = cfg.resolution >> level
+        if level == len(cfg.ch_mult) - 1:
+            spec.dec.append(mk(f"dec.{res}x{res}_in0", cout, cout, attn=True))
+            spec.dec.append(mk(f"dec.{res}x{res}_in1", cout, cout))
+        else:
+            spec.dec.append(mk(f"dec.{res}x{res}_up", cout, cout, up=True))
+        for idx in range(cfg.num_res_blocks + 1):
+            cin = cout + skips.pop()
+            cout = ch * mult
+            spec.dec.append(mk(f"dec.{res}x{res}_block{idx}", cin, cout, attn=(res in cfg.attn_resolutions)))
+    return spec
+
+
+def block_param_shapes(b: BlockSpec, emb: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Parameters of one UNetBlock in registration order (adm_blocks.py:140-157)."""
+    k = b.key
+    o = [(f"{k}.norm0.weight", (b.cin,)), (f"{k}.norm0.bias", (b.cin,)),
+         (f"{k}.conv0.weight", (b.cout, b.cin, 3, 3)), (f"{k}.conv0.bias", (b.cout,)),
+         (f"{k}.affine.weight", (2 * b.cout, emb)), (f"{k}.affine.bias", (2 * b.cout,)),
+         (f"{k}.norm1.weight", (b.cout,)), (f"{k}.norm1.bias", (b.cout,)),
+         (f"{k}.conv1.weight", (b.cout, b.cout, 3, 3)), (f"{k}.conv1.bias", (b.cout,))]
+    if b.skip_kernel == 1:
+        o += [(f"{k}.skip.weight", (b.cout, b.cin, 1, 1)), (f"{k}.skip.bias", (b.cout,))]
+    if b.attn:
+        o += [(f"{k}.norm2.weight", (b.cout,)), (f"{k}.norm2.bias", (b.cout,)),
+              (f"{k}.qkv.weight", (3 * b.cout, b.cout, 1, 1)), (f"{k}.qkv.bias", (3 * b.cout,)),
+              (f"{k}.proj.weight", (b.cout, b.cout, 1, 1)), (f"{k}.proj.bias", (b.cout,))]
+    return o
+
+
+def param_shapes(cfg: UNetConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    """(name, shape) of every *parameter* in ``DhariwalUNet.state_dict()`` order
+    (buffers ``*.resample_filter`` are not parameters and are omitted)."""
+    spec = build_spec(cfg)
+    ch = cfg.ch
+    emb = ch
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    out += [("map_layer0.weight", (emb, ch)), ("map_layer0.bias", (emb,)),
+            ("map_layer1.weight", (emb, emb)), ("map_layer1.bias", (emb,))]
+    in_total = cfg.in_channels + cfg.cond_channels
+    c0 = ch * cfg.ch_mult[0]
+    # ModuleDict order: conv_in first, then encoder blocks in creation order
+    out += [(f"{spec.conv_in_key}.weight", (c0, in_total, 3, 3)), (f"{spec.conv_in_key}.bias", (c0,))]
+    for b in spec.enc:
+        out += block_param_shapes(b, emb)
+    for b in spec.dec:
+        out += block_param_shapes(b, emb)
+    clast = spec.dec[-1].cout
+    out += [("out_norm.weight", (clast,)), ("out_norm.bias", (clast,)),
+            ("out_conv.weight", (cfg.out_ch, clast, 3, 3)), ("out_conv.bias", (cfg.out_ch,))]
+    return out
+
+
+def fill_param(name: str, shape: Sequence[int], u: np.ndarray) -> np.ndarray:
+    """Map a U(-1,1) draw to a test parameter: weights /sqrt(fan_in), GroupNorm gains 1+0.2u, rest 0.1u."""
+    if name.endswith(".weight") and len(shape) >= 2:
+        return u / math.sqrt(int(np.prod(shape[1:])))
+    if ".norm" in name or name.startswith("out_norm"):
+        return (1.0 + 0.2 * u) if name.endswith(".weight") else 0.1 * u
+    return 0.1 * u
+
+
+def make_params(cfg: UNetConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, Tensor]:
+    """Deterministic non-trivial parameter fill (SURVEY.md §8c fixture recipe).
+
+    The reference zero-initialises conv1/proj/out_conv (adm_blocks.py:145,157,317)
+    so default-init outputs are identically zero; tests instead draw every
+    parameter from one NumPy stream in ``param_shapes`` order:
+    weights ~ U(-1,1)/sqrt(fan_in), biases ~ 0.1*U(-1,1), GroupNorm gains ~ 1+0.2*U(-1,1).
+    """
+    rng = np.random.default_rng(seed)
+    P: Dict[str, Tensor] = {}
+    for name, shape in param_shapes(cfg):
+        u = rng.random(size=shape, dtype=np.float64) * 2.0 - 1.0
+        P[name] = torch.from_numpy(fill_param(name, shape, u).astype(np.float32)).to(dtype)
+    return P
+
+
+# --------------------------------------------------------------------------- #
+# primitive ops
+# --------------------------------------------------------------------------- #
+def positional_embedding(x: Tensor, num_channels: int, max_positions: int = 10000) -> Tensor:
+    """adm_blocks.py:192-199 (endpoint=False)."""
+    half = num_channels // 2
+    freqs = torch.arange(0, half).to(x.dtype) / half
+    freqs = (1.0 / max_positions) ** freqs
+    x = torch.outer(x, freqs)
+    return torch.cat([x.cos(), x.sin()], dim=1)
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """adm_blocks.py:28-32."""
+    y = x @ w.t()
+    return y + b if b is not None else y
+
+
+def group_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    """adm_blocks.py:86-97: groups = min(32, C // 4)."""
+    groups = min(32, x.shape[1] // 4)
+    return F.group_norm(x, groups, w, b, eps)
+
+
+def resample_down(x: Tensor) -> Tensor:
+    """adm_blocks.py:75-77 with resample_filter [1,1]: depthwise 2x2 box, stride 2 == 2x2 mean."""
+    return F.avg_pool2d(x, 2)
+
+
+def resample_up(x: Tensor) -> Tensor:
+    """adm_blocks.py:72-74: transposed depthwise conv with f*4 == ones(2,2), stride 2 == nearest 2x."""
+    return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+
+def conv2d(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], up=False, down=False) -> Tensor:
+    """adm_blocks.py:57-82, fused_resample=False branch; w None == kernel 0."""
+    if up:
+        x = resample_up(x)
+    if down:
+        x = resample_down(x)
+    if w is not None:
+        x = F.conv2d(x, w, padding=w.shape[-1] // 2)
+    if b is not None:
+        x = x + b.reshape(1, -1, 1, 1)
+    return x
+
+
+def attention(qkv: Tensor, heads: int) -> Tensor:
+    """adm_blocks.py:103-109,175-178.  qkv [B, 3C, H, W] -> a [B, C, H, W]."""
+    B, C3, H, W = qkv.shape
+    C = C3 // 3
+    q, k, v = qkv.reshape(B * heads, C // heads, 3, H * W).unbind(2)
+    w = torch.einsum("ncq,nck->nqk", q, k / math.sqrt(k.shape[1])).softmax(dim=2)
+    a = torch.einsum("nqk,nck->ncq", w, v)
+    return a.reshape(B, C, H, W)
+
+
+def unet_block(P: Dict[str, Tensor], b: BlockSpec, x: Tensor, emb: Tensor, eps: float = 1e-5) -> Tensor:
+    """adm_blocks.py:159-181 (adaptive_scale=True, dropout=0, skip_scale=1)."""
+    k = b.key
+    orig = x
+    x = conv2d(F.silu(group_norm(x, P[f"{k}.norm0.weight"], P[f"{k}.norm0.bias"], eps)),
+               P[f"{k}.conv0.weight"], P[f"{k}.conv0.bias"], up=b.up, down=b.down)
+    params = linear(emb, P[f"{k}.affine.weight"], P[f"{k}.affine.bias"])[:, :, None, None]
+    scale, shift = params.chunk(2, dim=1)
+    x = F.silu(torch.addcmul(shift, group_norm(x, P[f"{k}.norm1.weight"], P[f"{k}.norm1.bias"], eps), scale + 1))
+    x = conv2d(x, P[f"{k}.conv1.weight"], P[f"{k}.conv1.bias"])
+    if b.skip_kernel >= 0:
+        sk = conv2d(orig, P.get(f"{k}.skip.weight"), P.get(f"{k}.skip.bias"), up=b.up, down=b.down)
+    else:
+        sk = orig
+    x = x + sk
+    if b.attn:
+        qkv = conv2d(group_norm(x, P[f"{k}.norm2.weight"], P[f"{k}.norm2.bias"], eps),
+                     P[f"{k}.qkv.weight"], P[f"{k}.qkv.bias"])
+        a = attention(qkv, b.heads)
+        x = conv2d(a, P[f"{k}.proj.weight"], P[f"{k}.proj.bias"]) + x
+    return x
+
+
+def noise_embedding(P: Dict[str, Tensor], cfg: UNetConfig, noise_labels: Tensor) -> Tensor:
+    """adm_blocks.py:367-379 with map_augment/map_label absent (augment_dim=label_dim=0)."""
+    emb = positional_embedding(noise_labels, cfg.ch)
+    emb = F.silu(linear(emb, P["map_layer0.weight"], P["map_layer0.bias"]))
+    emb = linear(emb, P["map_layer1.weight"], P["map_layer1.bias"])
+    return F.silu(emb)
+
+
+def unet_forward(P: Dict[str, Tensor], cfg: UNetConfig, x: Tensor, noise_labels: Tensor,
+                 cond: Optional[Tensor] = None, spec: Optional[UNetSpec] = None) -> Tensor:
+    """DhariwalUNet.forward, adm_blocks.py:364-404 (cat_cond=True; cond_enc/dx_enc/self_cond off)."""
+    spec = spec or build_spec(cfg)
+    emb = noise_embedding(P, cfg, noise_labels)
+    if cfg.cond_channels > 0:
+        if cond is None:                                 # adm_blocks.py:328-331
+            cond = torch.zeros((x.shape[0], cfg.cond_channels) + tuple(x.shape[2:]), dtype=x.dtype)
+        x = torch.cat((cond, x), dim=1)                  # cond FIRST (adm_blocks.py:332)
+    x = conv2d(x, P[f"{spec.conv_in_key}.weight"], P[f"{spec.conv_in_key}.bias"])
+    skips = [x]
+    for b in spec.enc:
+        x = unet_block(P, b, x, emb, cfg.eps)
+        skips.append(x)
+    for b in spec.dec:
+        if x.shape[1] != b.cin:
+            x = torch.cat([x, skips.pop()], dim=1)
+        x = unet_block(P, b, x, emb, cfg.eps)
+    x = conv2d(F.silu(group_norm(x, P["out_norm.weight"], P["out_norm.bias"])),   # out_norm uses default eps
+               P["out_conv.weight"], P["out_conv.bias"])
+    return x
+
+
+# --------------------------------------------------------------------------- #
+# EDM preconditioning, loss, sampler (models/mcedm.py)
+# --------------------------------------------------------------------------- #
+SIGMA_DATA = 1.0      # mcedm.py:47
+P_MEAN, P_STD = -1.2, 1.2   # mcedm.py:45-46
+SIGMA_MIN, SIGMA_MAX = 0.002, 80   # mcedm.py:49-50
+
+
+def precond_coeffs(sigma: Tensor, sigma_data: float = SIGMA_DATA):
+    """mcedm.py:203-206 / :448-451 (fp32)."""
+    c_skip = sigma_data ** 2 / (sigma ** 2 + sigma_data ** 2)
+    c_out = sigma * sigma_data / (sigma ** 2 + sigma_data ** 2).sqrt()
+    c_in = 1 / (sigma_data ** 2 + sigma ** 2).sqrt()
+    c_noise = sigma.log() / 4
+    return c_skip, c_out, c_in, c_noise
+
+
+def model_precond(P, cfg, x_noise: Tensor, sigma: Tensor, cond: Optional[Tensor] = None,
+                  return_F: bool = False):
+    """PlMcedm.model_precond, mcedm.py:199-211 (== get_denoised, :443-461, with w=0)."""
+    sigma = sigma.to(torch.float32).reshape(-1, 1, 1, 1)
+    c_skip, c_out, c_in, c_noise = precond_coeffs(sigma)
+    F_x = unet_forward(P, cfg, c_in * x_noise, c_noise.flatten(), cond)
+    D_x = c_skip * x_noise + c_out * F_x
+    return (D_x, F_x) if return_F else D_x
+
+
+def get_denoised(P, cfg, xt: Tensor, t: Tensor, cond: Optional[Tensor] = None, w: Optional[float] = None):
+    """PlMcedm.get_denoised, mcedm.py:443-461 including the classifier-free branch."""
+    xt = xt.to(torch.float32)
+    sigma = t.to(torch.float32).reshape(-1, 1, 1, 1)
+    c_skip, c_out, c_in, c_noise = precond_coeffs(sigma)
+    if w is None or abs(w) < 0.001 or cond is None:
+        F_x = unet_forward(P, cfg, c_in * xt, c_noise.flatten(), cond)
+    else:
+        F_x = (w + 1) * unet_forward(P, cfg, c_in * xt, c_noise.flatten(), cond) \
+            - w * unet_forward(P, cfg, c_in * xt, c_noise.flatten(), None)
+    D_x = c_skip * xt + c_out * F_x
+    return D_x, F_x
+
+
+def loss_weight(sigma: Tensor, sigma_data: float = SIGMA_DATA) -> Tensor:
+    """mcedm.py:237-239."""
+    return (sigma ** 2 + sigma_data ** 2) / (sigma * sigma_data) ** 2
+
+
+def training_loss(P, cfg, x: Tensor, cond_in: Tensor, mask_c: Tensor, noise: Tensor, rnd_normal: Tensor) -> Tensor:
+    """training_step after data_transform/get_cond_in, mcedm.py:266-278 + forward :213-235
+    + NoiseEstimationLoss losses.py:48-59.  All tensors NCHW; rnd_normal [B,1,1,1]."""
+    sigma = (rnd_normal * P_STD + P_MEAN).exp()
+    weight = loss_weight(sigma)
+    x_noise = x + mask_c * noise * sigma
+    D_x = model_precond(P, cfg, x_noise, sigma.float(), cond_in)
+    loss_matrix = weight * (D_x * mask_c - x * mask_c) ** 2
+    return loss_matrix.sum(dim=(1, 2, 3)).mean()
+
+
+def cond_input(x: Tensor, mask: Tensor, cond_noise: Tensor) -> Tensor:
+    """get_cond_in, mcedm.py:247 (add_cond_mask False, add_xt False); any layout."""
+    return x * (1 - mask) + cond_noise * mask
+
+
+def edm_t_steps(num_steps: int, sigma_min: float, sigma_max: float, rho: float) -> Tensor:
+    """mcedm.py:579-588, float64, with t_N = 0 appended."""
+    sigma_min = max(sigma_min, SIGMA_MIN)
+    sigma_max = min(sigma_max, SIGMA_MAX)
+    idx = torch.arange(num_steps, dtype=torch.float64)
+    t = (sigma_max ** (1 / rho) + idx / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    return torch.cat([t, torch.zeros_like(t[:1])])
+
+
+@dataclass
+class SamplerParams:
+    """configs/diff_sampler/edm_sampler.yaml:1-20 (fields sample_edm reads)."""
+    timesteps: int = 18
+    sigma_min: float = 0.002
+    sigma_max: float = 80.0
+    rho: float = 7.0
+    S_churn: float = 0.0
+    S_min: float = 0.0
+    S_max: float = float("inf")
+    S_noise: float = 1.0
+    w: float = 0.0
+
+
+def sample_edm(P, cfg, cond: Tensor, hu_mask: Tensor, sp: SamplerParams, init_noise: Tensor,
+               step_noise: Optional[Sequence[Tensor]] = None, n_state: int = 2,
+               return_last: bool = True) -> Tensor:
+    """PlMcedm.sample_edm, mcedm.py:570-638 with guide_dx False / dx_cond False.
+
+    ``init_noise`` replaces ``randn_like(hu)`` (:576) and ``step_noise[i]`` the
+    per-step ``randn_like(x_cur)`` (:608); when ``step_noise`` is None the churn
+    term is taken as zero noise (only valid for S_churn == 0 where its factor is 0).
+    Returns [B, T, H, W, C] float64 like the reference."""
+    N = sp.timesteps
+    t_steps = edm_t_steps(N, sp.sigma_min, sp.sigma_max, sp.rho)
+    hu_known = cond[:, 0:n_state]
+    x_next = init_noise.to(torch.float64) * t_steps[0]
+    x_next = hu_known * (1 - hu_mask) + x_next * hu_mask
+    xs = [x_next]
+    for i in range(N):
+        t_cur, t_next = t_steps[i], t_steps[i + 1]
+        x_cur = x_next
+        gamma = min(sp.S_churn / N, math.sqrt(2) - 1) if sp.S_min <= float(t_cur) <= float(sp.S_max) else 0
+        t_hat = t_cur + gamma * t_cur
+        eps_i = step_noise[i] if step_noise is not None else torch.zeros_like(x_cur)
+        x_hat = x_cur + (t_hat ** 2 - t_cur ** 2).sqrt() * sp.S_noise * eps_i * hu_mask
+        denoised, _ = get_denoised(P, cfg, x_hat, t_hat, cond=cond, w=sp.w)
+        denoised = denoised.to(torch.float64)
+        d_cur = (x_hat - denoised) / t_hat
+        x_next = x_hat + (t_next - t_hat) * d_cur * hu_mask
+        if i < N - 1:
+            denoised, _ = get_denoised(P, cfg, x_next, t_next, cond=cond, w=sp.w)
+            denoised = denoised.to(torch.float64)
+            d_prime = (x_next - denoised) / t_next
+            x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime) * hu_mask
+        if return_last:
+            xs = [x_next]
+        else:
+            xs.append(x_next)
+    xs = torch.stack(xs, dim=0)
+    return xs.permute(1, 0, 3, 4, 2).contiguous()      # 't b c h w -> b t h w c'
+
+
+# --------------------------------------------------------------------------- #
+# optimizer + EMA (mcedm.py:139-168, ddim_blocks.py:44-54, trainer_ddim.yaml:8-9)
+# --------------------------------------------------------------------------- #
+def clip_scale(grads: Sequence[Tensor], max_norm: float = 1.0) -> Tuple[float, float]:
+    """torch.nn.utils.clip_grad_norm_ semantics (Lightning gradient_clip_val=1.0, algorithm=norm):
+    coef = min(1, max_norm / (total_norm + 1e-6))."""
+    total = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads))
+    return min(1.0, max_norm / (total + 1e-6)), total
+
+
+def adam_ema_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, ema: Tensor, step: int,
+                  lr=2e-4, b1=0.9, b2=0.999, eps=1e-8, clip=1.0, ema_beta=0.999):
+    """One torch.optim.Adam step (wd=0, amsgrad False) on clipped grads followed by
+    EmaModel.update (ddim_blocks.py:44-54).  ``step`` counts from 1.  Returns new (p, m, v, ema)."""
+    g = g * clip
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    p = p - (lr / bc1) * m / denom
+    ema = ema * ema_beta + (1 - ema_beta) * p
+    return p, m, v, ema

@@ -1,0 +1,144 @@
+"""CPU: the oracle (oracle/mcedm_oracle.py) reproduces every committed golden vector.
+
+The golden vectors are outputs of the reference itself (oracle/make_golden.py); inputs and
+parameters are rebuilt from the tags in oracle/fixtures.py.  Tolerances: the oracle restates the
+reference with the same torch CPU primitives, so agreement is expected at rounding level
+(rtol 1e-5); the HIP-vs-oracle bar (rtol 1e-4 / atol 1e-5, north_star) lives in the -m gpu tests.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import mcedm_oracle as orc
+
+torch.set_num_threads(4)
+
+
+def close(got, ref, rtol=1e-5, atol=1e-6):
+    ref = torch.as_tensor(ref)
+    assert got.shape == ref.shape and got.dtype == ref.dtype
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_group_norm(golden, C):
+    g = golden("ops.npz")
+    x = fx.randn(f"ops/gn{C}/x", 2, C, 8, 8) * 1.5 + 0.3
+    y = orc.group_norm(x, fx.param(f"ops/gn{C}", "norm.weight", (C,)), fx.param(f"ops/gn{C}", "norm.bias", (C,)))
+    close(y, g[f"gn{C}_y"])
+
+
+@pytest.mark.parametrize("tag", list(fx.CONV_CASES))
+def test_conv2d(golden, tag):
+    g = golden("ops.npz")
+    kw = fx.CONV_CASES[tag]
+    cin, cout = fx.conv_channels(tag)
+    w = b = None
+    if kw["kernel"]:
+        w = fx.param(f"ops/conv_{tag}", "conv.weight", (cout, cin, kw["kernel"], kw["kernel"]))
+        b = fx.param(f"ops/conv_{tag}", "conv.bias", (cout,))
+    x = fx.randn(f"ops/conv_{tag}/x", 2, cin, 8, 12)
+    close(orc.conv2d(x, w, b, up=kw.get("up", False), down=kw.get("down", False)), g[f"conv_{tag}_y"])
+
+
+@pytest.mark.parametrize("T", list(fx.ATTN_CASES))
+def test_attention_fwd_bwd(golden, T):
+    g = golden("ops.npz")
+    B, hw = fx.ATTN_CASES[T]
+    qkv = fx.randn(f"ops/attn{T}/qkv", B, 384, *hw).requires_grad_(True)
+    a = orc.attention(qkv, 2)
+    close(a.detach(), g[f"attn{T}_a"])
+    (dqkv,) = torch.autograd.grad(a, qkv, fx.randn(f"ops/attn{T}/da", *a.shape))
+    close(dqkv, g[f"attn{T}_dqkv"], rtol=1e-4, atol=2e-6)
+
+
+def test_positional_embedding(golden):
+    close(orc.positional_embedding(fx.PE_LABELS, 64), golden("ops.npz")["pe_y"])
+
+
+@pytest.mark.parametrize("tag", list(fx.BLOCK_CASES))
+@pytest.mark.parametrize("n_emb", [1, 2])
+def test_unet_block(golden, tag, n_emb):
+    x, emb = fx.block_inputs(tag, n_emb)
+    y = orc.unet_block(fx.block_params(tag), fx.block_spec(tag), x, emb)
+    close(y, golden("blocks.npz")[f"{tag}_n{n_emb}_y"], rtol=1e-4, atol=1e-5)
+
+
+def test_param_layout_matches_reference_counts():
+    # 1,587,010 parameters (ch=64); 6,120,834 (ch=128, 3 levels, attn_resolutions=[16] so
+    # only dec.32x32_in0 attends -- SURVEY.md §8d)
+    assert sum(int(np.prod(s)) for _, s in orc.param_shapes(fx.CFG_P)) == 1_587_010
+    cfg128 = orc.UNetConfig(ch=128, attn_resolutions=(16,))
+    assert sum(int(np.prod(s)) for _, s in orc.param_shapes(cfg128)) == 6_120_834
+    spec = orc.build_spec(fx.CFG_P)
+    assert len(spec.enc) + len(spec.dec) == 15
+    assert sum(b.attn for b in spec.enc + spec.dec) == 4
+
+
+def test_unet_forward_and_precond(golden):
+    g = golden("unet_P.npz")
+    P = orc.make_params(fx.CFG_P, int(g["seed"]))
+    x = fx.randn("unet_P/x", 4, 2, 32, 32)
+    cond = fx.randn("unet_P/cond", 4, 2, 32, 32)
+    with torch.no_grad():
+        for tag, labels in fx.UNET_LABELS.items():
+            close(orc.unet_forward(P, fx.CFG_P, x, labels, cond), g[f"F_{tag}"], rtol=1e-4, atol=1e-5)
+        close(orc.unet_forward(P, fx.CFG_P, x, torch.tensor([0.3]), None), g["F_nocond"], rtol=1e-4, atol=1e-5)
+        for i, s in enumerate(fx.PRECOND_SIGMAS):
+            close(orc.model_precond(P, fx.CFG_P, x * (1 + s), torch.tensor(s), cond), g[f"D_sigma{i}"],
+                  rtol=1e-4, atol=1e-5)
+        close(orc.model_precond(P, fx.CFG_P, x, fx.PRECOND_SIGMA_B, cond), g["D_sigmaB"], rtol=1e-4, atol=1e-5)
+        D, _ = orc.get_denoised(P, fx.CFG_P, x.double(), torch.tensor(0.7).double(), cond, w=0.5)
+        close(D, g["D_cfg_w05"], rtol=1e-4, atol=1e-5)
+
+
+def test_unet_forward_wide(golden):
+    g = golden("unet_W.npz")
+    P = orc.make_params(fx.CFG_W, int(g["seed"]))
+    with torch.no_grad():
+        y = orc.unet_forward(P, fx.CFG_W, fx.randn("unet_W/x", 2, 2, 16, 16), fx.UNET_W_LABELS,
+                             fx.randn("unet_W/cond", 2, 2, 16, 16))
+    close(y, g["F"], rtol=1e-4, atol=1e-5)
+
+
+def test_t_steps(golden):
+    t = orc.edm_t_steps(18, 0.002, 80, 7)
+    assert t.dtype == torch.float64 and t.shape == (19,) and t[0] == 80.0 and t[-1] == 0.0
+    np.testing.assert_array_equal(t.numpy(), golden("sampler_P.npz")["t_steps"])
+
+
+@pytest.mark.parametrize("tag", ["det_u", "churn_u"])
+def test_sample_edm(golden, tag):
+    g = golden("sampler_P.npz")
+    P = orc.make_params(fx.CFG_P, int(g["seed"]))
+    cond, m, init, steps = fx.sampler_inputs(tag)
+    sp = orc.SamplerParams(S_churn=fx.SAMPLER_CASES[tag][0])
+    with torch.no_grad():
+        xs = orc.sample_edm(P, fx.CFG_P, cond, m, sp, init, steps, return_last=False)
+    assert xs.dtype == torch.float64 and xs.shape == (4, 19, 32, 32, 2)
+    close(xs[:, -1:], g[f"{tag}_xs_last"], rtol=1e-3, atol=1e-4)
+    close(xs[:, ::6], g[f"{tag}_xs_traj"], rtol=1e-3, atol=1e-4)
+    # observed entries stay exactly the conditioning values (mcedm.py:597,618,628)
+    obs = (m == 0).permute(0, 2, 3, 1)
+    assert torch.equal(xs[:, -1][obs], cond.permute(0, 2, 3, 1).double()[obs])
+
+
+def test_training_loss_grads_adam(golden):
+    g = golden("training_P.npz")
+    P = orc.make_params(fx.CFG_P, int(g["seed"]))
+    h, u, mask, cond_noise, noise, rnd_normal = fx.training_inputs()
+    xc, cond_in, mc = fx.training_nchw(h, u, mask, cond_noise)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss = orc.training_loss(Pg, fx.CFG_P, xc, cond_in, mc, noise, rnd_normal)
+    loss.backward()
+    close(loss.detach(), g["loss"], rtol=1e-5)
+    grads = [Pg[n].grad for n, _ in orc.param_shapes(fx.CFG_P)]
+    coef, total = orc.clip_scale(grads, 1.0)
+    assert abs(total - float(g["clip_total_norm"])) <= 1e-5 * total
+    for n in fx.TRAIN_GRAD_NAMES:
+        ref = torch.as_tensor(g[f"grad::{n}"])
+        close(Pg[n].grad, ref, rtol=1e-3, atol=2e-6 * float(ref.abs().max()))
+        p1, _, _, e1 = orc.adam_ema_step(P[n], ref, torch.zeros_like(ref), torch.zeros_like(ref), P[n], 1, clip=coef)
+        close(p1, g[f"adam::{n}"], rtol=1e-5, atol=1e-7)
+        close(e1, g[f"ema::{n}"], rtol=1e-5, atol=1e-7)
