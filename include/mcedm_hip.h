@@ -1,0 +1,198 @@
+/* mcedm_hip.h -- C ABI of libmcedm_hip.so, the MI355X (gfx950) implementation of the
+ * m-cedm EDM hot path: ADM/EDM U-Net forward (+backward), EDM preconditioning, the
+ * deterministic/stochastic Heun sampler, the masked EDM loss and the Adam+EMA step.
+ *
+ * The reference (katehai/m-cedm) is pure Python and has no FFI of its own; the seam it
+ * exposes is Python-level.  Each entry point below names the
+ * reference function whose device work it replaces (paths relative to the reference
+ * checkout).  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no torch / C++ types.
+ *  - Every entry point returns 0 on success and a negative mcedm_status on failure;
+ *    mcedm_last_error() returns a thread-local message for the last failure.
+ *  - All device buffers are owned by the caller (parameters, packed weights, workspace,
+ *    inputs, outputs).  The library allocates only the host-side plan object.
+ *  - Kernels are enqueued on the caller's HIP stream (passed as void* = hipStream_t);
+ *    nothing synchronises the device, so calls are graph-capturable.
+ *  - Tensors are dense NCHW fp32 unless stated; the sampler state is fp64 like the reference.
+ */
+#ifndef MCEDM_HIP_H_
+#define MCEDM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCEDM_ABI_VERSION 1
+#define MCEDM_MAX_LEVELS 8
+
+typedef enum {
+  MCEDM_OK = 0,
+  MCEDM_ERR_INVALID = -1,      /* bad argument / unsupported shape (rejected before any launch) */
+  MCEDM_ERR_UNSUPPORTED = -2,  /* configuration outside the hot path (e.g. cond_enc, self_cond) */
+  MCEDM_ERR_WORKSPACE = -3,    /* workspace / packed buffer too small */
+  MCEDM_ERR_HIP = -4           /* a HIP runtime call or launch failed */
+} mcedm_status;
+
+/* Architecture of DhariwalUNet as read from hparams.model (models/adm_blocks.py:203-317,
+ * configs/model/adm_edm_mcedm_res32.yaml:4-28).  Only the cat_cond=True, dx_cond=False,
+ * self_cond=False, label_dim=augment_dim=0, dropout=0 configuration is on the hot path. */
+typedef struct {
+  int32_t in_channels;       /* state channels (h_ch + u_ch), 2 */
+  int32_t cond_channels;     /* concatenated conditioning channels, 2 (0 = none) */
+  int32_t out_channels;      /* out_ch */
+  int32_t ch;                /* base width; emb_channels == ch */
+  int32_t n_levels;          /* len(ch_mult) */
+  int32_t ch_mult[MCEDM_MAX_LEVELS];
+  int32_t num_res_blocks;
+  int32_t resolution;        /* label only: level names are resolution >> level */
+  int32_t n_attn_resolutions;
+  int32_t attn_resolutions[MCEDM_MAX_LEVELS];
+  int32_t channels_per_head; /* 64 */
+  float eps;                 /* GroupNorm eps, 1e-5 */
+} mcedm_unet_desc;
+
+/* Sampler parameters (configs/diff_sampler/edm_sampler.yaml:1-20; fields read by
+ * PlMcedm.sample_edm, models/mcedm.py:570-638). */
+typedef struct {
+  int32_t timesteps;
+  double sigma_min, sigma_max, rho;
+  double S_churn, S_min, S_max, S_noise;
+  double w;                  /* classifier-free guidance weight; |w| < 1e-3 == off (mcedm.py:453) */
+  double sigma_data;         /* 1.0 (mcedm.py:47) */
+  double net_sigma_min, net_sigma_max; /* 0.002 / 80 (mcedm.py:49-50) */
+} mcedm_sampler_desc;
+
+typedef struct mcedm_plan mcedm_plan;
+
+int mcedm_version(void);
+const char* mcedm_last_error(void);
+
+/* ---- plan: the static block list of the network ------------------------------------ */
+int mcedm_unet_plan_create(const mcedm_unet_desc* desc, mcedm_plan** out);
+void mcedm_unet_plan_destroy(mcedm_plan* plan);
+
+/* Parameter table in DhariwalUNet.state_dict() order (parameters only, no buffers).
+ * name is owned by the plan. */
+int mcedm_unet_param_count(const mcedm_plan* plan);
+int mcedm_unet_param_info(const mcedm_plan* plan, int index, const char** name, int64_t* numel,
+                          int32_t* ndim, int64_t shape[4]);
+
+/* Derived ("packed") weights: MFMA-friendly copies of the conv / linear weights.  Must be
+ * re-run whenever a parameter changes.  params[i] is the device pointer of parameter i. */
+int mcedm_unet_packed_bytes(const mcedm_plan* plan, size_t* bytes);
+int mcedm_unet_pack_weights(const mcedm_plan* plan, const float* const* params, void* packed, void* stream);
+
+/* Workspace needed by one forward at batch B and spatial size HxW (H, W multiples of
+ * 2^(n_levels-1)).  training != 0 keeps every activation the backward needs. */
+int mcedm_unet_workspace_bytes(const mcedm_plan* plan, int B, int H, int W, int training, size_t* bytes);
+
+/* DhariwalUNet.forward (models/adm_blocks.py:364-404): out = F(cat(cond, x_scale * x), noise_labels).
+ *  x            [B, in_channels, H, W]
+ *  cond         [B, cond_channels, H, W] or NULL (treated as zeros, adm_blocks.py:328-331)
+ *  x_scale      [n_noise] per-sample factor applied to x while it is read (EDM c_in), or NULL (= 1)
+ *  noise_labels [n_noise], n_noise == 1 (broadcast, sampling) or == B (training)
+ *  out          [B, out_channels, H, W] */
+int mcedm_unet_forward(const mcedm_plan* plan, const void* packed, const float* x, const float* cond,
+                       const float* x_scale, const float* noise_labels, int n_noise, float* out,
+                       void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
+                       void* stream);
+
+/* PlMcedm.model_precond / get_denoised with w == 0 (models/mcedm.py:199-211, 443-461):
+ * D = c_skip*x + c_out*F(c_in*x, ln(sigma)/4, cond).  sigma is a device array of n_sigma (1 or B)
+ * fp32 values.  F_out may be NULL. */
+int mcedm_edm_denoise(const mcedm_plan* plan, const void* packed, const float* x, const float* sigma,
+                      int n_sigma, const float* cond, float* D_out, float* F_out, void* workspace,
+                      size_t workspace_bytes, int B, int H, int W, int training, double sigma_data,
+                      void* stream);
+
+/* PlMcedm.sample_edm (models/mcedm.py:570-638), guide_dx False / dx_cond False.
+ *  cond       [B, cond_channels, H, W] fp32; its first in_channels channels are hu_known
+ *  mask       [B, in_channels, H, W] fp32, 1 = missing
+ *  init_noise [B, in_channels, H, W] fp32  (the reference's randn_like(hu), mcedm.py:576)
+ *  step_noise [timesteps, B, in_channels, H, W] fp64 or NULL (the per-step randn_like(x_cur) of
+ *             mcedm.py:608, fp64 like x_cur; NULL is only legal when no step has gamma > 0)
+ *  out        fp64, [B, 1, H, W, C] if return_last else [B, timesteps+1, H, W, C]
+ *  workspace must hold mcedm_sampler_workspace_bytes(). */
+int mcedm_sampler_workspace_bytes(const mcedm_plan* plan, int B, int H, int W, size_t* bytes);
+int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                      const float* cond, const float* mask, const float* init_noise,
+                      const double* step_noise, double* out, int return_last, void* workspace,
+                      size_t workspace_bytes, int B, int H, int W, void* stream);
+/* Host helper: the float64 sigma schedule of mcedm.py:584-588 (timesteps+1 values, last = 0). */
+int mcedm_edm_t_steps(const mcedm_sampler_desc* sp, double* t_steps);
+
+/* ---- training --------------------------------------------------------------------- */
+/* Masked, weighted EDM loss of training_step (models/mcedm.py:266-278, models/losses.py:48-59)
+ * and its gradient w.r.t. D:  loss = mean_b sum_chw w_b (D*m - x*m)^2,  w_b = (s^2+sd^2)/(s*sd)^2.
+ *  loss_out: 1 fp32 (device), accumulated from zero by this call;  dD_out [B,C,H,W] or NULL. */
+int mcedm_edm_loss(const float* D, const float* x, const float* mask, const float* sigma, int B, int C,
+                   int H, int W, double sigma_data, float* loss_out, float* dD_out, void* stream);
+
+/* x_noise = x + mask*noise*sigma (mcedm.py:216), sigma = exp(rnd_normal*P_std + P_mean) (mcedm.py:271). */
+int mcedm_edm_noise_inputs(const float* x, const float* mask, const float* noise, const float* rnd_normal,
+                           int B, int C, int H, int W, double P_mean, double P_std, float* x_noise,
+                           float* sigma_out, void* stream);
+
+/* Backward of mcedm_edm_denoise through the U-Net: consumes the activations kept in
+ * `workspace` by the matching forward (training != 0).  grads[i] receives dLoss/dparam_i
+ * (overwritten).  dD is the gradient w.r.t. D_out. */
+int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* packed, const float* const* params,
+                               const float* x, const float* sigma, int n_sigma, const float* cond,
+                               const float* dD, float* const* grads, void* workspace,
+                               size_t workspace_bytes, int B, int H, int W, double sigma_data, void* stream);
+
+/* Squared L2 norm of a flat fp32 buffer, accumulated in fp64 into *sqnorm_out (device, overwritten). */
+int mcedm_sqnorm(const float* g, size_t n, double* sqnorm_out, void* stream);
+
+/* Fused grad-clip + Adam + EMA on flat fp32 buffers (models/mcedm.py:139-168,
+ * models/ddim_blocks.py:44-54, configs/trainer/trainer_ddim.yaml:8-9).
+ *  clip = min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) is computed on device from sqnorm (NULL = no clip);
+ *  grad_scale multiplies grads first (1/world_size after a sum all-reduce). `step` counts from 1. */
+int mcedm_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                        size_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        const double* sqnorm, double max_norm, double grad_scale, double ema_beta,
+                        int64_t step, void* stream);
+
+/* ---- kernel-level entry points ----------------------------------------------------------
+ * The building blocks the schedules above are made of, exported so that each kernel can be
+ * parity-tested against the oracle and timed on its own (bench.py roofline leg). */
+
+/* Per-(sample, channel) input transform a conv applies while staging: v' = act((v-mean)*scale+offset). */
+typedef struct { float mean, scale, offset, pad; } mcedm_coef;
+
+/* Packed-weight size (floats) of a [Cout, Cin, k, k] conv, k in {1, 3}; bias_pk needs ceil32(Cout) floats. */
+size_t mcedm_op_conv_packed_floats(int Cout, int Cin, int k);
+/* Conv2d weights -> MFMA slab order.  qkv_heads > 0 re-orders output rows from the reference's
+ * (head, c, {q,k,v}) interleave (adm_blocks.py:175) to (head, {q,k,v}, c).  dgrad != 0 packs the
+ * transposed, tap-mirrored weights of the data gradient instead (then wpk has Cin output rows). */
+int mcedm_op_pack_conv(const float* w, const float* b, int Cout, int Cin, int k, int qkv_heads, int dgrad,
+                       float* wpk, float* bias_pk, void* stream);
+/* GroupNorm statistics of cat(xa, xb) [B, Ca+Cb, HW] -> coef table [B][C] (models/adm_blocks.py:86-97
+ * fused with the FiLM of :163-166 when film != NULL: row n = film[n*film_stride + (scale[0..C) | shift[C..2C))]).
+ * groups = min(32, C/4).  stats_out [B][groups][2] (mean, rstd) may be NULL. */
+int mcedm_op_gn_coef(const float* xa, const float* xb, int Ca, int Cb, int B, int HW, const float* gamma,
+                     const float* beta, const float* film, int film_batch, int film_stride, float eps,
+                     mcedm_coef* coef_out, float* stats_out, void* stream);
+/* out = conv_k(resample(act(coef(cat(xa, xb))))) + bias + resample(res)   (models/adm_blocks.py:57-82 with the
+ * pointwise ops of :161,166,171,179 fused).  resample / res_mode: 0 none, 1 nearest-2x up, 2 2x2-mean down.
+ * (Hs, Ws) is the source size, (H, W) the conv size. */
+int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch, int act,
+                  int resample, int Hs, int Ws, int H, int W, const float* wpk, const float* bias_pk,
+                  const float* res, int res_mode, float* out, int Cout, int B, int k, void* stream);
+/* a = softmax(q^T k / sqrt(64)) v per (sample, head) (models/adm_blocks.py:103-109,174-178);
+ * qkv is [B][heads][3][64][T] (the packed qkv conv's output), out [B][heads*64][T]. */
+int mcedm_op_attention(const float* qkv, float* out, int B, int heads, int T, void* stream);
+/* Test hook: force the conv tile (channel tile mt in {32,64,128}, pixel tile ph x pw in {8x32,16x16,8x8});
+ * (0,0,0) restores the size heuristic.  Process-global, not thread-safe. */
+int mcedm_op_set_conv_tile(int mt, int ph, int pw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCEDM_HIP_H_ */

@@ -1,0 +1,118 @@
+// common.hpp -- shared declarations for libmcedm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "mcedm_hip.h"
+
+namespace mcedm {
+
+void set_error(const char* fmt, ...);
+
+#define MCEDM_HIP_TRY(expr)                                                                   \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      ::mcedm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return MCEDM_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+#define MCEDM_LAUNCH_CHECK(what)                                                               \
+  do {                                                                                        \
+    hipError_t e__ = hipGetLastError();                                                       \
+    if (e__ != hipSuccess) {                                                                  \
+      ::mcedm::set_error("launch of %s failed: %s", what, hipGetErrorString(e__));            \
+      return MCEDM_ERR_HIP;                                                                   \
+    }                                                                                         \
+  } while (0)
+
+#define MCEDM_REQUIRE(cond, ...)                                                              \
+  do {                                                                                        \
+    if (!(cond)) {                                                                            \
+      ::mcedm::set_error(__VA_ARGS__);                                                        \
+      return MCEDM_ERR_INVALID;                                                               \
+    }                                                                                         \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------
+// Per-(sample, channel) input transform applied while a conv / GEMM stages its input:
+//   v' = act((v - mean) * scale + offset)
+// GroupNorm, the FiLM modulation addcmul(shift, norm(x), scale+1) and the EDM c_in factor
+// are all instances of it (adm_blocks.py:94-97,166; mcedm.py:208).
+struct __attribute__((aligned(16))) Coef {
+  float mean, scale, offset, pad;
+};
+
+enum Resample { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
+
+// Arguments of the implicit-GEMM convolution (3x3 pad 1, or 1x1).
+struct ConvArgs {
+  const float* xa;   // first source of the virtual channel concat [B, Ca, Hs, Ws] (may be null => zeros)
+  const float* xb;   // second source [B, Cb, Hs, Ws] (null iff Cb == 0)
+  int Ca, Cb;
+  const Coef* coef;  // [coef_batch ? B : 1][Ca + Cb], or null (identity, no activation)
+  int coef_batch;    // 1: per-sample rows, 0: one row broadcast over the batch
+  int act;           // 1: SiLU after the affine
+  int resample;      // Resample applied to the (activated) source before the conv
+  int Hs, Ws;        // source spatial size
+  int H, W;          // conv input == output spatial size
+  const float* wpk;  // packed weights (see pack_conv_weights)
+  const float* bias; // [Cout] (packed order) or null
+  const float* res;  // residual [B, Cout, Hr, Wr] or null
+  int res_mode;      // Resample applied to the residual source
+  float* out;        // [B, Cout, H, W]
+  int Cout;
+  int B;
+};
+
+int launch_conv(const ConvArgs& a, int taps, hipStream_t stream);
+void set_conv_tile_override(int mt, int ph, int pw);   // test hook; (0,0,0) restores the heuristic
+// geometry the packer must use for a given (Cout, taps): tile height over Cout and K-chunk
+int conv_mt_for(int Cout);
+int conv_kc_for(int taps);
+size_t conv_packed_floats(int Cout, int Cin, int taps);
+// src [Cout][Cin][taps]; perm_qkv_heads > 0 permutes output rows from the reference's interleaved
+// (head, c, {q,k,v}) order to (head, {q,k,v}, c).  transpose_flip: build the dgrad weights.
+int launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int taps, int qkv_heads, int transpose_flip,
+                     hipStream_t stream);
+int launch_pack_bias(const float* b, float* dst, int Cout, int qkv_heads, hipStream_t stream);
+
+// GroupNorm statistics + coefficient table (K1).  x = virtual concat of xa[B,Ca,HW], xb[B,Cb,HW].
+struct GnArgs {
+  const float* xa; const float* xb; int Ca, Cb;
+  int HW, B, groups;
+  const float* gamma; const float* beta;     // [C]
+  const float* film;  // row n: film[n*film_stride + (0..C) = scale | (C..2C) = shift], or null
+  int film_batch;     // 1: one row per sample, 0: row 0 broadcast over the batch
+  int film_stride;
+  float eps;
+  Coef* coef;        // out [B][C]
+  float* stats;      // out [B][groups][2] (mean, rstd) or null (kept for backward)
+};
+int launch_gn_coef(const GnArgs& a, hipStream_t stream);
+
+// sigma-embedding MLP + all FiLM affine rows (K6)
+struct EmbArgs {
+  const float* labels; int n;      // noise labels [n]
+  int ch;                          // embedding width
+  const float* freqs;              // [ch/2]
+  const float* w0; const float* b0; const float* w1; const float* b1;  // map_layer0/1, [ch][ch] row-major (out,in)
+  const float* waff; const float* baff; int rows;  // concatenated affine weights [rows][ch], bias [rows]
+  float* emb;                      // out [n][ch]
+  float* film;                     // out [n][rows]
+};
+int launch_embedding(const EmbArgs& a, hipStream_t stream);
+
+// attention (K5): qkv [B][heads][3][64][T] -> a [B][heads*64][T]
+int launch_attention(const float* qkv, float* out, int B, int heads, int T, hipStream_t stream);
+
+}  // namespace mcedm

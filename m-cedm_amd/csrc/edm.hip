@@ -1,0 +1,308 @@
+// edm.hip -- K7 (EDM preconditioning), K8 (Heun sampler state updates, fp64), K9 (masked EDM
+// loss + its gradient), K11 (grad-clip + Adam + EMA).  All HBM-bound elementwise / reduction
+// kernels: one pass over the tensors, coalesced, grid-stride.
+//
+// The fp64 sampler arithmetic mirrors the evaluation order of models/mcedm.py:594-628 term by
+// term, so this file is compiled with -ffp-contract=off (see build.py).
+#include "common.hpp"
+#include "edm.hpp"
+
+namespace mcedm {
+
+static inline int grid_for(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (int)(b < 2048 ? (b ? b : 1) : 2048);
+}
+
+// ---- K7a: per-sample EDM coefficients (mcedm.py:203-206 / 448-451), fp32 like the reference.
+// Writes c_skip/c_out/c_in/c_noise rows and the conv_in transform table: cond channels pass
+// through, state channels are scaled by c_in (mcedm.py:208: only x is scaled, not cond).
+__global__ void precond_prepare_kernel(const float* __restrict__ sigma_dev, float sigma_host, int use_host, int n,
+                                       float sigma_data, int cond_ch, int in_ch, float* __restrict__ coefs4,
+                                       float* __restrict__ c_noise, Coef* __restrict__ conv_in_coef) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = use_host ? sigma_host : sigma_dev[i];
+  const float sd2 = sigma_data * sigma_data;
+  const float s2 = s * s;
+  const float c_skip = sd2 / (s2 + sd2);
+  const float c_out = s * sigma_data / sqrtf(s2 + sd2);
+  const float c_in = 1.0f / sqrtf(sd2 + s2);
+  const float cn = logf(s) / 4.0f;
+  coefs4[4 * i + 0] = c_skip;
+  coefs4[4 * i + 1] = c_out;
+  coefs4[4 * i + 2] = c_in;
+  coefs4[4 * i + 3] = cn;
+  c_noise[i] = cn;
+  const int Ct = cond_ch + in_ch;
+  for (int c = 0; c < Ct; ++c) conv_in_coef[(size_t)i * Ct + c] = Coef{0.f, c < cond_ch ? 1.0f : c_in, 0.f, 0.f};
+}
+
+int launch_precond_prepare(const float* sigma_dev, float sigma_host, int use_host, int n, float sigma_data,
+                           int cond_ch, int in_ch, float* coefs4, float* c_noise, Coef* conv_in_coef,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(precond_prepare_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, stream, sigma_dev, sigma_host,
+                     use_host, n, sigma_data, cond_ch, in_ch, coefs4, c_noise, conv_in_coef);
+  MCEDM_LAUNCH_CHECK("precond_prepare_kernel");
+  return MCEDM_OK;
+}
+
+// ---- K7b: D = c_skip*x + c_out*F  (mcedm.py:210 / 460); optional classifier-free blend
+// F = (w+1)*F - w*F_uncond first (mcedm.py:457-458).
+__global__ void precond_finish_kernel(const float* __restrict__ x, const float* __restrict__ F,
+                                      const float* __restrict__ Fu, float w, const float* __restrict__ coefs4,
+                                      int n_sigma, size_t per_sample, size_t total, float* __restrict__ D,
+                                      float* __restrict__ F_out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = n_sigma == 1 ? 0 : i / per_sample;
+    float f = F[i];
+    if (Fu) f = (w + 1.0f) * f - w * Fu[i];
+    if (F_out) F_out[i] = f;
+    D[i] = coefs4[4 * b] * x[i] + coefs4[4 * b + 1] * f;
+  }
+}
+
+int launch_precond_finish(const float* x, const float* F, const float* Fu, float w, const float* coefs4, int n_sigma,
+                          size_t per_sample, size_t total, float* D, float* F_out, hipStream_t stream) {
+  hipLaunchKernelGGL(precond_finish_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, F, Fu, w, coefs4, n_sigma,
+                     per_sample, total, D, F_out);
+  MCEDM_LAUNCH_CHECK("precond_finish_kernel");
+  return MCEDM_OK;
+}
+
+// ---- K8: sampler state (fp64) ---------------------------------------------------------------
+// x0 = hu_known*(1-mask) + (noise*t0)*mask                      (mcedm.py:594-597)
+__global__ void heun_init_kernel(const float* __restrict__ cond, int cond_ch, int in_ch, size_t hw,
+                                 const float* __restrict__ mask, const float* __restrict__ noise, double t0,
+                                 size_t total, double* __restrict__ x, float* __restrict__ x32) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / (in_ch * hw), r = i % (in_ch * hw);
+    const float known = cond[b * cond_ch * hw + r];          // cond[:, 0:in_ch]
+    const float m = mask[i];
+    const float keep = known * (1.0f - m);                   // fp32 product like the reference
+    const double v = (double)keep + ((double)noise[i] * t0) * (double)m;
+    x[i] = v;
+    x32[i] = (float)v;
+  }
+}
+
+// x_hat = x_cur + (c*eps)*mask, c = sqrt(t_hat^2 - t_cur^2)*S_noise   (mcedm.py:608)
+__global__ void heun_churn_kernel(double* __restrict__ x, const double* __restrict__ eps, const float* __restrict__ mask,
+                                  double c, size_t total, float* __restrict__ x32) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const double v = x[i] + (c * eps[i]) * (double)mask[i];
+    x[i] = v;
+    x32[i] = (float)v;
+  }
+}
+
+// d = (x_hat - D)/t_hat ; x_next = x_hat + ((t_next - t_hat)*d)*mask    (mcedm.py:617-618)
+__global__ void heun_euler_kernel(const double* __restrict__ x_hat, const float* __restrict__ D,
+                                  const float* __restrict__ mask, double t_hat, double dt, size_t total,
+                                  double* __restrict__ d_cur, double* __restrict__ x_next, float* __restrict__ x32) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const double xh = x_hat[i];
+    const double d = (xh - (double)D[i]) / t_hat;
+    const double v = xh + (dt * d) * (double)mask[i];
+    d_cur[i] = d;
+    x_next[i] = v;
+    x32[i] = (float)v;
+  }
+}
+
+// d' = (x_next - D')/t_next ; x_next = x_hat + (dt*(0.5 d + 0.5 d'))*mask   (mcedm.py:627-628)
+__global__ void heun_correct_kernel(const double* __restrict__ x_hat, const double* __restrict__ d_cur,
+                                    const float* __restrict__ D, const float* __restrict__ mask, double t_next, double dt,
+                                    size_t total, double* __restrict__ x_next, float* __restrict__ x32) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const double dp = (x_next[i] - (double)D[i]) / t_next;
+    const double v = x_hat[i] + (dt * (0.5 * d_cur[i] + 0.5 * dp)) * (double)mask[i];
+    x_next[i] = v;
+    x32[i] = (float)v;
+  }
+}
+
+// 'b c h w -> b t h w c' for one time slot (mcedm.py:636-638)
+__global__ void heun_store_kernel(const double* __restrict__ x, int C, size_t hw, int t, int T, size_t total,
+                                  double* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // i enumerates the OUTPUT (b, p, c) so stores are contiguous
+    const size_t c = i % C;
+    const size_t p = (i / C) % hw;
+    const size_t b = i / (C * hw);
+    out[((b * T + t) * hw + p) * C + c] = x[(b * C + c) * hw + p];
+  }
+}
+
+int launch_heun_init(const float* cond, int cond_ch, int in_ch, size_t hw, const float* mask, const float* noise,
+                     double t0, size_t total, double* x, float* x32, hipStream_t s) {
+  hipLaunchKernelGGL(heun_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, cond, cond_ch, in_ch, hw, mask, noise, t0,
+                     total, x, x32);
+  MCEDM_LAUNCH_CHECK("heun_init_kernel");
+  return MCEDM_OK;
+}
+int launch_heun_churn(double* x, const double* eps, const float* mask, double c, size_t total, float* x32, hipStream_t s) {
+  hipLaunchKernelGGL(heun_churn_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, eps, mask, c, total, x32);
+  MCEDM_LAUNCH_CHECK("heun_churn_kernel");
+  return MCEDM_OK;
+}
+int launch_heun_euler(const double* x_hat, const float* D, const float* mask, double t_hat, double dt, size_t total,
+                      double* d_cur, double* x_next, float* x32, hipStream_t s) {
+  hipLaunchKernelGGL(heun_euler_kernel, dim3(grid_for(total)), dim3(256), 0, s, x_hat, D, mask, t_hat, dt, total, d_cur,
+                     x_next, x32);
+  MCEDM_LAUNCH_CHECK("heun_euler_kernel");
+  return MCEDM_OK;
+}
+int launch_heun_correct(const double* x_hat, const double* d_cur, const float* D, const float* mask, double t_next,
+                        double dt, size_t total, double* x_next, float* x32, hipStream_t s) {
+  hipLaunchKernelGGL(heun_correct_kernel, dim3(grid_for(total)), dim3(256), 0, s, x_hat, d_cur, D, mask, t_next, dt,
+                     total, x_next, x32);
+  MCEDM_LAUNCH_CHECK("heun_correct_kernel");
+  return MCEDM_OK;
+}
+int launch_heun_store(const double* x, int C, size_t hw, int t, int T, size_t total, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(heun_store_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, C, hw, t, T, total, out);
+  MCEDM_LAUNCH_CHECK("heun_store_kernel");
+  return MCEDM_OK;
+}
+
+// ---- training-side elementwise ----------------------------------------------------------------
+// sigma = exp(rnd*P_std + P_mean) (mcedm.py:271); x_noise = x + mask*noise*sigma (mcedm.py:216)
+__global__ void noise_inputs_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                    const float* __restrict__ noise, const float* __restrict__ rnd, float P_mean,
+                                    float P_std, size_t per_sample, size_t total, float* __restrict__ x_noise,
+                                    float* __restrict__ sigma_out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / per_sample;
+    const float sigma = expf(rnd[b] * P_std + P_mean);
+    if (i % per_sample == 0) sigma_out[b] = sigma;
+    x_noise[i] = x[i] + mask[i] * noise[i] * sigma;
+  }
+}
+
+// loss = mean_b sum_chw w_b*(D*m - x*m)^2 ; dD = (2 w_b / B) * (D*m - x*m) * m   (mcedm.py:278, losses.py:48-53)
+__global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__ D, const float* __restrict__ x,
+                                                       const float* __restrict__ mask, const float* __restrict__ sigma,
+                                                       float sigma_data, int B, size_t per_sample,
+                                                       float* __restrict__ loss, float* __restrict__ dD) {
+  const int b = blockIdx.y;
+  const float s = sigma[b];
+  const float wgt = (s * s + sigma_data * sigma_data) / ((s * sigma_data) * (s * sigma_data));
+  const size_t base = (size_t)b * per_sample;
+  float acc = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_sample; i += (size_t)gridDim.x * blockDim.x) {
+    const float m = mask[base + i];
+    const float diff = D[base + i] * m - x[base + i] * m;
+    acc += wgt * (diff * diff);
+    if (dD) dD[base + i] = (2.0f * wgt / (float)B) * diff * m;
+  }
+  double t = acc;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)B));
+}
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, double* __restrict__ out) {
+  float a0 = 0.f, a1 = 0.f;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i + stride < n; i += 2 * stride) {
+    const float u = g[i], v = g[i + stride];
+    a0 += u * u; a1 += v * v;
+  }
+  if (i < n) { const float u = g[i]; a0 += u * u; }
+  double t = (double)a0 + (double)a1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// torch.optim.Adam (no amsgrad) on clipped grads, then EmaModel.update (ddim_blocks.py:44-54).
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, float* __restrict__ ema, size_t n, float step_size, float w1,
+                                float b2, float w2, float eps, float wd, const double* __restrict__ sqnorm,
+                                double max_norm, float gscale, float ema_beta, float ema_w, float bc2_sqrt) {
+  float clip = 1.f;
+  if (sqnorm) {
+    // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1; norm of the (scaled) grads
+    const double total = sqrt(*sqnorm) * (double)gscale;
+    const double c = max_norm / (total + 1e-6);
+    clip = (float)(c < 1.0 ? c : 1.0);
+  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale * clip;
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    // exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1-b2); addcdiv_(m, denom, -step_size)
+    const float m0 = m[i];
+    const float mi = m0 + w1 * (gi - m0);
+    const float vi = v[i] * b2 + w2 * (gi * gi);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float pn = pi - step_size * (mi / denom);
+    m[i] = mi; v[i] = vi; p[i] = pn;
+    if (ema) ema[i] = ema[i] * ema_beta + ema_w * pn;
+  }
+}
+
+}  // namespace mcedm
+
+using namespace mcedm;
+
+extern "C" int mcedm_edm_noise_inputs(const float* x, const float* mask, const float* noise, const float* rnd_normal,
+                                      int B, int C, int H, int W, double P_mean, double P_std, float* x_noise,
+                                      float* sigma_out, void* stream) {
+  MCEDM_REQUIRE(x && mask && noise && rnd_normal && x_noise && sigma_out, "noise_inputs: null pointer");
+  MCEDM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "noise_inputs: empty shape");
+  const size_t per = (size_t)C * H * W, total = per * B;
+  hipLaunchKernelGGL(noise_inputs_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, mask, noise,
+                     rnd_normal, (float)P_mean, (float)P_std, per, total, x_noise, sigma_out);
+  MCEDM_LAUNCH_CHECK("noise_inputs_kernel");
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_edm_loss(const float* D, const float* x, const float* mask, const float* sigma, int B, int C, int H,
+                              int W, double sigma_data, float* loss_out, float* dD_out, void* stream) {
+  MCEDM_REQUIRE(D && x && mask && sigma && loss_out, "edm_loss: null pointer");
+  MCEDM_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0, "edm_loss: bad shape");
+  const size_t per = (size_t)C * H * W;
+  MCEDM_HIP_TRY(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
+  int gx = (int)((per + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(edm_loss_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, D, x, mask, sigma,
+                     (float)sigma_data, B, per, loss_out, dD_out);
+  MCEDM_LAUNCH_CHECK("edm_loss_kernel");
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_sqnorm(const float* g, size_t n, double* sqnorm_out, void* stream) {
+  MCEDM_REQUIRE(g && sqnorm_out, "sqnorm: null pointer");
+  MCEDM_HIP_TRY(hipMemsetAsync(sqnorm_out, 0, sizeof(double), (hipStream_t)stream));
+  if (n == 0) return MCEDM_OK;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm_out);
+  MCEDM_LAUNCH_CHECK("sqnorm_kernel");
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                                   size_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                   const double* sqnorm, double max_norm, double grad_scale, double ema_beta,
+                                   int64_t step, void* stream) {
+  MCEDM_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adam: null pointer");
+  MCEDM_REQUIRE(step >= 1, "adam: step counts from 1 (got %lld)", (long long)step);
+  if (n == 0) return MCEDM_OK;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  // scalar factors are formed in double on the host exactly as torch.optim.Adam / EmaModel form them in Python
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, ema, n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                     (float)eps, (float)weight_decay, sqnorm, max_norm, (float)grad_scale, (float)ema_beta,
+                     (float)(1.0 - ema_beta), (float)sqrt(bc2));
+  MCEDM_LAUNCH_CHECK("adam_ema_kernel");
+  return MCEDM_OK;
+}

@@ -1,0 +1,250 @@
+// norm_emb_attn.hip -- K1 (GroupNorm statistics -> per-channel transform table), K6 (sigma
+// embedding MLP + every FiLM affine row) and K5 (fused softmax attention on fp32 MFMA).
+#include "common.hpp"
+
+namespace mcedm {
+
+// =========================================================================================
+// K1: GroupNorm statistics.  One workgroup per (sample, group); the group's cpg*HW floats are
+// contiguous in NCHW.  Sums are taken relative to the group's first element (shifted-data
+// variance), per-thread in fp32 and across threads in fp64.  HBM-bound: reads the tensor once.
+// Emits, per channel, the transform the consuming conv applies while staging its input:
+//   norm(x)*(film_scale+1) + film_shift  ==  (x - mean) * [g*rstd*(1+s)] + [b*(1+s) + t]
+// (adm_blocks.py:94-97 and :163-166).
+// =========================================================================================
+__global__ __launch_bounds__(256) void gn_coef_kernel(GnArgs a) {
+  const int C = a.Ca + a.Cb;
+  const int cpg = C / a.groups;
+  const int n = blockIdx.x / a.groups;
+  const int g = blockIdx.x % a.groups;
+  const int c0 = g * cpg;
+  const float* src = (c0 < a.Ca) ? a.xa + ((size_t)n * a.Ca + c0) * a.HW
+                                 : a.xb + ((size_t)n * a.Cb + (c0 - a.Ca)) * a.HW;
+  const int N = cpg * a.HW;
+  const float shift = src[0];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tid = threadIdx.x;
+  if ((N & 3) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    const int N4 = N >> 2;
+    for (int i = tid; i < N4; i += 256) {
+      const float4 v = s4[i];
+      const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+      s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+      s2[0] += d0 * d0; s2[1] += d1 * d1; s2[2] += d2 * d2; s2[3] += d3 * d3;
+    }
+  } else {
+    for (int i = tid; i < N; i += 256) {
+      const float d = src[i] - shift;
+      s1[0] += d; s2[0] += d * d;
+    }
+  }
+  double t1 = ((double)s1[0] + (double)s1[1]) + ((double)s1[2] + (double)s1[3]);
+  double t2 = ((double)s2[0] + (double)s2[1]) + ((double)s2[2] + (double)s2[3]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    t1 += __shfl_xor(t1, off);
+    t2 += __shfl_xor(t2, off);
+  }
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  if ((tid & 63) == 0) { red[0][tid >> 6] = t1; red[1][tid >> 6] = t2; }
+  __syncthreads();
+  if (tid == 0) {
+    const double S1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double S2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double m = S1 / N;
+    double var = S2 / N - m * m;
+    if (var < 0) var = 0;
+    const float mean = (float)((double)shift + m);
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    stat[0] = mean; stat[1] = rstd;
+    if (a.stats) { a.stats[((size_t)n * a.groups + g) * 2] = mean; a.stats[((size_t)n * a.groups + g) * 2 + 1] = rstd; }
+  }
+  __syncthreads();
+  if (tid < cpg) {
+    const int c = c0 + tid;
+    const float mean = stat[0], rstd = stat[1];
+    float sc = 1.f, sh = 0.f;
+    if (a.film) {
+      const float* f = a.film + (size_t)(a.film_batch ? n : 0) * a.film_stride;
+      sc = f[c] + 1.f;
+      sh = f[C + c];
+    }
+    Coef o;
+    o.mean = mean;
+    o.scale = a.gamma[c] * rstd * sc;
+    o.offset = a.beta[c] * sc + sh;
+    o.pad = 0.f;
+    a.coef[(size_t)n * C + c] = o;
+  }
+}
+
+int launch_gn_coef(const GnArgs& a, hipStream_t stream) {
+  const int C = a.Ca + a.Cb;
+  MCEDM_REQUIRE(a.groups > 0 && C % a.groups == 0, "group_norm: C=%d not divisible by groups=%d", C, a.groups);
+  const int cpg = C / a.groups;
+  MCEDM_REQUIRE(a.Cb == 0 || a.Ca % cpg == 0, "group_norm: a group straddles the concat boundary (Ca=%d cpg=%d)", a.Ca, cpg);
+  MCEDM_REQUIRE(cpg <= 256, "group_norm: too many channels per group (%d)", cpg);
+  MCEDM_REQUIRE(a.xa != nullptr && (a.Cb == 0 || a.xb != nullptr), "group_norm: null input");
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(a.B * a.groups), dim3(256), 0, stream, a);
+  MCEDM_LAUNCH_CHECK("gn_coef_kernel");
+  return MCEDM_OK;
+}
+
+// =========================================================================================
+// K6: PositionalEmbedding -> map_layer0 -> SiLU -> map_layer1 -> SiLU (adm_blocks.py:192-199,
+// 367-379) and all per-block `affine` rows (adm_blocks.py:163) in one launch.
+// One workgroup per noise label (n = 1 while sampling, n = B while training).
+// =========================================================================================
+__device__ __forceinline__ float silu_e(float v) { return v / (1.0f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void embedding_kernel(EmbArgs a) {
+  extern __shared__ float sm[];
+  float* e0 = sm;            // [ch]
+  float* e1 = sm + a.ch;     // [ch]
+  const int n = blockIdx.x, tid = threadIdx.x, ch = a.ch, half = a.ch / 2;
+  const float x = a.labels[n];
+  for (int k = tid; k < ch; k += 256) {
+    const float arg = x * a.freqs[k < half ? k : k - half];
+    e0[k] = (k < half) ? cosf(arg) : sinf(arg);
+  }
+  __syncthreads();
+  for (int j = tid; j < ch; j += 256) {
+    float s = 0.f;
+    for (int k = 0; k < ch; ++k) s = fmaf(e0[k], a.w0[(size_t)j * ch + k], s);
+    e1[j] = silu_e(s + a.b0[j]);
+  }
+  __syncthreads();
+  for (int j = tid; j < ch; j += 256) {
+    float s = 0.f;
+    for (int k = 0; k < ch; ++k) s = fmaf(e1[k], a.w1[(size_t)j * ch + k], s);
+    const float v = silu_e(s + a.b1[j]);
+    e0[j] = v;   // e0 is free after the first barrier pair
+    if (a.emb) a.emb[(size_t)n * ch + j] = v;
+  }
+  __syncthreads();
+  for (int r = tid; r < a.rows; r += 256) {
+    float s = 0.f;
+    for (int k = 0; k < ch; ++k) s = fmaf(e0[k], a.waff[(size_t)r * ch + k], s);
+    a.film[(size_t)n * a.rows + r] = s + a.baff[r];
+  }
+}
+
+int launch_embedding(const EmbArgs& a, hipStream_t stream) {
+  MCEDM_REQUIRE(a.n > 0 && a.ch > 0 && a.ch % 2 == 0, "embedding: bad shape n=%d ch=%d", a.n, a.ch);
+  hipLaunchKernelGGL(embedding_kernel, dim3(a.n), dim3(256), 2 * a.ch * sizeof(float), stream, a);
+  MCEDM_LAUNCH_CHECK("embedding_kernel");
+  return MCEDM_OK;
+}
+
+// =========================================================================================
+// K5: attention  a[c][q] = sum_k softmax_k(q.k/8)[q][k] * v[c][k]   (adm_blocks.py:103-109,174-178)
+// One wave per 32 queries of one (sample, head); keys in tiles of 32; head_dim = 64; fp32 MFMA.
+// The score tile is computed TRANSPOSED (rows = keys, column = this lane's query) so the softmax
+// row reduction is 15 in-register ops + one cross-half shuffle, and the probabilities are already
+// in B-operand position for the P.V product (no LDS, no transposes).  The reference materialises
+// the [T x T] weight matrix; this kernel never does.
+// qkv layout (written by the packed qkv 1x1 conv): [B][heads][3][64][T].
+// =========================================================================================
+__global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                       int T) {
+  const int lane = threadIdx.x;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32;
+  const size_t bh = blockIdx.y;
+  const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
+  const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
+  const int q = q0 + l31;
+  const int qc = q < T ? q : T - 1;
+
+  float qreg[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) qreg[s] = Q[(size_t)(2 * s + h) * T + qc] * 0.125f;   // 1/sqrt(64), exact
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    const bool full = (k0 + 32 <= T);
+    const int kk = k0 + l31;
+    const int kc = kk < T ? kk : T - 1;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+      const float a = K[(size_t)(2 * st + h) * T + kc];
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[st], s, 0, 0, 0);
+    }
+    // s[r] = score(query l31, key k0 + (r&3) + 8*(r>>2) + 4*h)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (!full && key >= T) s[r] = -INFINITY;
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = expf(m - m_new);
+    float p[16];
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = expf(s[r] - m_new);
+      rs += p[r];
+    }
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // O[c][q] += sum_key V[c][key] * P[key][q]; MFMA step r contracts the key pair held by the two lane halves
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* vrow = V + (size_t)(32 * i + l31) * T;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v4[4];
+        const int kb = k0 + 8 * g + 4 * h;
+        if (full && (T & 3) == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(vrow + kb);
+          v4[0] = t.x; v4[1] = t.y; v4[2] = t.z; v4[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = vrow[(kb + e) < T ? (kb + e) : T - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[e], p[4 * g + e], o[i], 0, 0, 0);
+      }
+    }
+  }
+  if (q < T) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[(bh * 64 + c) * (size_t)T + q] = o[i][r] * inv;
+      }
+  }
+}
+
+int launch_attention(const float* qkv, float* out, int B, int heads, int T, hipStream_t stream) {
+  MCEDM_REQUIRE(B > 0 && heads > 0 && T > 0, "attention: empty shape");
+  MCEDM_REQUIRE((long long)B * heads <= 65535, "attention: B*heads too large for grid.y");
+  hipLaunchKernelGGL(attention_kernel, dim3(ceil_div(T, 32), B * heads), dim3(64), 0, stream, qkv, out, T);
+  MCEDM_LAUNCH_CHECK("attention_kernel");
+  return MCEDM_OK;
+}
+
+}  // namespace mcedm

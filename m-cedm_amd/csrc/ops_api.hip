@@ -1,0 +1,60 @@
+// ops_api.hip -- kernel-level C entry points (tests, per-kernel timing).
+#include "common.hpp"
+
+using namespace mcedm;
+
+static_assert(sizeof(mcedm_coef) == sizeof(Coef), "mcedm_coef must mirror Coef");
+
+extern "C" size_t mcedm_op_conv_packed_floats(int Cout, int Cin, int k) {
+  if (Cout <= 0 || Cin <= 0 || (k != 1 && k != 3)) return 0;
+  return conv_packed_floats(Cout, Cin, k * k);
+}
+
+extern "C" int mcedm_op_pack_conv(const float* w, const float* b, int Cout, int Cin, int k, int qkv_heads, int dgrad,
+                                  float* wpk, float* bias_pk, void* stream) {
+  MCEDM_REQUIRE(w && wpk, "op_pack_conv: null pointer");
+  MCEDM_REQUIRE(Cout > 0 && Cin > 0 && (k == 1 || k == 3), "op_pack_conv: bad shape");
+  MCEDM_REQUIRE(qkv_heads == 0 || (Cout % (3 * qkv_heads) == 0 && !dgrad), "op_pack_conv: bad qkv_heads");
+  int rc = dgrad ? launch_pack_conv(w, wpk, Cin, Cout, k * k, 0, 1, (hipStream_t)stream)
+                 : launch_pack_conv(w, wpk, Cout, Cin, k * k, qkv_heads, 0, (hipStream_t)stream);
+  if (rc) return rc;
+  if (b && bias_pk) rc = launch_pack_bias(b, bias_pk, Cout, qkv_heads, (hipStream_t)stream);
+  return rc;
+}
+
+extern "C" int mcedm_op_gn_coef(const float* xa, const float* xb, int Ca, int Cb, int B, int HW, const float* gamma,
+                                const float* beta, const float* film, int film_batch, int film_stride, float eps,
+                                mcedm_coef* coef_out, float* stats_out, void* stream) {
+  MCEDM_REQUIRE(xa && gamma && beta && coef_out, "op_gn_coef: null pointer");
+  MCEDM_REQUIRE(B > 0 && HW > 0 && Ca > 0 && Cb >= 0, "op_gn_coef: bad shape");
+  const int C = Ca + Cb;
+  MCEDM_REQUIRE(C >= 4, "op_gn_coef: C=%d < 4 gives zero groups (adm_blocks.py:89)", C);
+  GnArgs a{xa, xb, Ca, Cb, HW, B, C / 4 < 32 ? C / 4 : 32, gamma, beta, film, film_batch, film_stride, eps,
+           reinterpret_cast<Coef*>(coef_out), stats_out};
+  return launch_gn_coef(a, (hipStream_t)stream);
+}
+
+extern "C" int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch,
+                             int act, int resample, int Hs, int Ws, int H, int W, const float* wpk,
+                             const float* bias_pk, const float* res, int res_mode, float* out, int Cout, int B, int k,
+                             void* stream) {
+  MCEDM_REQUIRE(k == 1 || k == 3, "op_conv: k must be 1 or 3");
+  MCEDM_REQUIRE(resample >= 0 && resample <= 2 && res_mode >= 0 && res_mode <= 2, "op_conv: bad resample mode");
+  ConvArgs a{};
+  a.xa = xa; a.xb = xb; a.Ca = Ca; a.Cb = Cb;
+  a.coef = reinterpret_cast<const Coef*>(coef); a.coef_batch = coef_batch; a.act = act;
+  a.resample = resample; a.Hs = Hs; a.Ws = Ws; a.H = H; a.W = W;
+  a.wpk = wpk; a.bias = bias_pk; a.res = res; a.res_mode = res_mode;
+  a.out = out; a.Cout = Cout; a.B = B;
+  return launch_conv(a, k * k, (hipStream_t)stream);
+}
+
+extern "C" int mcedm_op_attention(const float* qkv, float* out, int B, int heads, int T, void* stream) {
+  MCEDM_REQUIRE(qkv && out, "op_attention: null pointer");
+  return launch_attention(qkv, out, B, heads, T, (hipStream_t)stream);
+}
+
+extern "C" int mcedm_op_set_conv_tile(int mt, int ph, int pw) {
+  set_conv_tile_override(mt, ph, pw);
+  return MCEDM_OK;
+}

@@ -1,0 +1,774 @@
+// plan.hip -- the C ABI: plan construction, weight packing, workspace layout, the U-Net forward
+// schedule, EDM denoise and the Heun sampler loop.  Host code only launches the kernels of
+// conv_mfma.hip / norm_emb_attn.hip / edm.hip on the caller's stream; it never allocates device
+// memory and never synchronises.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "edm.hpp"
+#include "plan.hpp"
+
+namespace mcedm {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// plan construction: restates DhariwalUNet.__init__ (models/adm_blocks.py:203-317)
+// ------------------------------------------------------------------------------------------
+static int add_param(mcedm_plan& P, const std::string& name, std::initializer_list<int64_t> shape) {
+  ParamInfo pi;
+  pi.name = name;
+  pi.ndim = (int)shape.size();
+  pi.numel = 1;
+  int i = 0;
+  for (int64_t s : shape) { pi.shape[i++] = s; pi.numel *= s; }
+  P.params.push_back(pi);
+  return (int)P.params.size() - 1;
+}
+
+static NormP make_norm(mcedm_plan& P, const std::string& key, int C) {
+  NormP n;
+  n.C = C;
+  n.groups = std::min(32, C / 4);          // adm_blocks.py:89
+  n.w = add_param(P, key + ".weight", {C});
+  n.b = add_param(P, key + ".bias", {C});
+  return n;
+}
+
+static ConvP make_conv(mcedm_plan& P, const std::string& key, int cin, int cout, int k, int qkv_heads = 0) {
+  ConvP c;
+  c.cin = cin; c.cout = cout; c.taps = k * k; c.qkv_heads = qkv_heads;
+  c.w = add_param(P, key + ".weight", {cout, cin, k, k});
+  c.b = add_param(P, key + ".bias", {cout});
+  return c;
+}
+
+static BlockP make_block(mcedm_plan& P, const std::string& key, int cin, int cout, bool up, bool down, bool attn) {
+  const int emb = P.desc.ch;
+  BlockP b;
+  b.key = key; b.cin = cin; b.cout = cout; b.up = up; b.down = down;
+  b.heads = attn ? cout / P.desc.channels_per_head : 0;      // adm_blocks.py:135
+  b.attn = b.heads > 0;
+  b.norm0 = make_norm(P, key + ".norm0", cin);
+  b.conv0 = make_conv(P, key + ".conv0", cin, cout, 3);
+  b.aff_w = add_param(P, key + ".affine.weight", {2 * cout, emb});
+  b.aff_b = add_param(P, key + ".affine.bias", {2 * cout});
+  b.norm1 = make_norm(P, key + ".norm1", cout);
+  b.conv1 = make_conv(P, key + ".conv1", cout, cout, 3);
+  b.skip_kernel = -1;
+  if (cout != cin || up || down) {                           // adm_blocks.py:148-151
+    b.skip_kernel = (cout != cin) ? 1 : 0;
+    if (b.skip_kernel == 1) b.skip = make_conv(P, key + ".skip", cin, cout, 1);
+  }
+  if (b.attn) {
+    b.norm2 = make_norm(P, key + ".norm2", cout);
+    b.qkv = make_conv(P, key + ".qkv", cout, 3 * cout, 1, b.heads);
+    b.proj = make_conv(P, key + ".proj", cout, cout, 1);
+  }
+  return b;
+}
+
+static bool in_list(const int32_t* v, int n, int x) {
+  for (int i = 0; i < n; ++i) if (v[i] == x) return true;
+  return false;
+}
+
+struct Taker {
+  size_t cur = 0;
+  size_t take(size_t nfloats) { size_t o = cur; cur += align_up(nfloats, 64); return o; }
+};
+
+static void place_conv(Taker& t, ConvP& c, bool dgrad) {
+  c.wpk = t.take(conv_packed_floats(c.cout, c.cin, c.taps));
+  c.bias = t.take((size_t)(c.cout + 31) / 32 * 32);
+  if (dgrad) c.wpk_dgrad = t.take(conv_packed_floats(c.cin, c.cout, c.taps));
+}
+static void place_norm(Taker& t, NormP& n) { n.gamma = t.take(n.C); n.beta = t.take(n.C); }
+
+}  // namespace mcedm
+
+using namespace mcedm;
+
+extern "C" int mcedm_version(void) { return MCEDM_ABI_VERSION; }
+extern "C" const char* mcedm_last_error(void) { return g_err; }
+
+extern "C" int mcedm_unet_plan_create(const mcedm_unet_desc* d, mcedm_plan** out) {
+  MCEDM_REQUIRE(d && out, "plan_create: null argument");
+  MCEDM_REQUIRE(d->n_levels >= 1 && d->n_levels <= MCEDM_MAX_LEVELS, "plan_create: n_levels=%d out of range", d->n_levels);
+  MCEDM_REQUIRE(d->n_attn_resolutions >= 0 && d->n_attn_resolutions <= MCEDM_MAX_LEVELS, "plan_create: bad n_attn_resolutions");
+  MCEDM_REQUIRE(d->in_channels > 0 && d->out_channels > 0 && d->cond_channels >= 0, "plan_create: bad channel counts");
+  MCEDM_REQUIRE(d->ch > 0 && d->ch % 8 == 0, "plan_create: ch=%d must be a positive multiple of 8", d->ch);
+  MCEDM_REQUIRE(d->num_res_blocks >= 1, "plan_create: num_res_blocks must be >= 1");
+  if (d->channels_per_head != 64) {
+    set_error("plan_create: channels_per_head=%d unsupported (the hot path uses 64, adm_blocks.py:223)", d->channels_per_head);
+    return MCEDM_ERR_UNSUPPORTED;
+  }
+  for (int l = 0; l < d->n_levels; ++l) {
+    const int c = d->ch * d->ch_mult[l];
+    MCEDM_REQUIRE(d->ch_mult[l] >= 1 && c % 8 == 0, "plan_create: level %d width %d must be a multiple of 8", l, c);
+  }
+  mcedm_plan* Pp = new mcedm_plan();
+  mcedm_plan& P = *Pp;
+  P.desc = *d;
+  P.levels_div = 1 << (d->n_levels - 1);
+  const int ch = d->ch;
+  auto key = [&](const char* side, int res, const std::string& tail) {
+    return std::string(side) + "." + std::to_string(res) + "x" + std::to_string(res) + "_" + tail;
+  };
+  P.map0_w = add_param(P, "map_layer0.weight", {ch, ch});
+  P.map0_b = add_param(P, "map_layer0.bias", {ch});
+  P.map1_w = add_param(P, "map_layer1.weight", {ch, ch});
+  P.map1_b = add_param(P, "map_layer1.bias", {ch});
+  std::vector<int> skips;
+  int cout = d->in_channels + d->cond_channels;
+  for (int level = 0; level < d->n_levels; ++level) {
+    const int res = d->resolution >> level, mult = d->ch_mult[level];
+    if (level == 0) {
+      const int cin = cout;
+      cout = ch * mult;
+      P.conv_in = make_conv(P, key("enc", res, "conv"), cin, cout, 3);
+      skips.push_back(cout);
+    } else {
+      P.enc.push_back(make_block(P, key("enc", res, "down"), cout, cout, false, true, false));
+      skips.push_back(cout);
+    }
+    for (int idx = 0; idx < d->num_res_blocks; ++idx) {
+      const int cin = cout;
+      cout = ch * mult;
+      const bool attn = in_list(d->attn_resolutions, d->n_attn_resolutions, res);
+      P.enc.push_back(make_block(P, key("enc", res, "block" + std::to_string(idx)), cin, cout, false, false, attn));
+      skips.push_back(cout);
+    }
+  }
+  for (int level = d->n_levels - 1; level >= 0; --level) {
+    const int res = d->resolution >> level, mult = d->ch_mult[level];
+    if (level == d->n_levels - 1) {
+      P.dec.push_back(make_block(P, key("dec", res, "in0"), cout, cout, false, false, true));
+      P.dec.push_back(make_block(P, key("dec", res, "in1"), cout, cout, false, false, false));
+    } else {
+      P.dec.push_back(make_block(P, key("dec", res, "up"), cout, cout, true, false, false));
+    }
+    for (int idx = 0; idx < d->num_res_blocks + 1; ++idx) {
+      const int cin = cout + skips.back();
+      skips.pop_back();
+      cout = ch * mult;
+      const bool attn = in_list(d->attn_resolutions, d->n_attn_resolutions, res);
+      P.dec.push_back(make_block(P, key("dec", res, "block" + std::to_string(idx)), cin, cout, false, false, attn));
+    }
+  }
+  P.out_norm = make_norm(P, "out_norm", cout);
+  P.conv_out = make_conv(P, "out_conv", cout, d->out_channels, 3);
+
+  // packed-buffer layout
+  Taker t;
+  P.freqs = t.take(ch / 2);
+  P.w0 = t.take((size_t)ch * ch); P.b0 = t.take(ch);
+  P.w1 = t.take((size_t)ch * ch); P.b1 = t.take(ch);
+  int rows = 0;
+  for (auto* v : {&P.enc, &P.dec})
+    for (BlockP& b : *v) { b.film_row0 = rows; rows += 2 * b.cout; }
+  P.film_rows = rows;
+  P.waff = t.take((size_t)rows * ch);
+  P.baff = t.take(rows);
+  place_conv(t, P.conv_in, false);
+  for (auto* v : {&P.enc, &P.dec})
+    for (BlockP& b : *v) {
+      place_norm(t, b.norm0); place_conv(t, b.conv0, true);
+      place_norm(t, b.norm1); place_conv(t, b.conv1, true);
+      if (b.skip_kernel == 1) place_conv(t, b.skip, true);
+      if (b.attn) { place_norm(t, b.norm2); place_conv(t, b.qkv, true); place_conv(t, b.proj, true); }
+    }
+  place_norm(t, P.out_norm);
+  place_conv(t, P.conv_out, true);
+  P.packed_floats = t.cur;
+  *out = Pp;
+  return MCEDM_OK;
+}
+
+extern "C" void mcedm_unet_plan_destroy(mcedm_plan* plan) { delete plan; }
+
+extern "C" int mcedm_unet_param_count(const mcedm_plan* plan) { return plan ? (int)plan->params.size() : MCEDM_ERR_INVALID; }
+
+extern "C" int mcedm_unet_param_info(const mcedm_plan* plan, int index, const char** name, int64_t* numel, int32_t* ndim,
+                                     int64_t shape[4]) {
+  MCEDM_REQUIRE(plan && index >= 0 && index < (int)plan->params.size(), "param_info: index %d out of range", index);
+  const ParamInfo& p = plan->params[index];
+  if (name) *name = p.name.c_str();
+  if (numel) *numel = p.numel;
+  if (ndim) *ndim = p.ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_unet_packed_bytes(const mcedm_plan* plan, size_t* bytes) {
+  MCEDM_REQUIRE(plan && bytes, "packed_bytes: null argument");
+  *bytes = plan->packed_floats * sizeof(float);
+  return MCEDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+namespace mcedm {
+
+constexpr int COPY_MAX = 40;
+struct CopyBatch {
+  const float* src[COPY_MAX];
+  float* dst[COPY_MAX];
+  int n[COPY_MAX];
+};
+
+__global__ void batched_copy_kernel(CopyBatch b) {
+  const int j = blockIdx.y;
+  const float* s = b.src[j];
+  float* d = b.dst[j];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n[j]; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+// freqs[k] = (1/10000)^(k/half)   (adm_blocks.py:193-196, endpoint=False), fp32
+__global__ void freqs_kernel(float* f, int half) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < half) f[k] = powf(1.0f / 10000.0f, (float)k / (float)half);
+}
+
+struct Copier {
+  CopyBatch b;
+  int count = 0;
+  hipStream_t s;
+  int status = MCEDM_OK;
+  void flush() {
+    if (count == 0 || status != MCEDM_OK) { count = 0; return; }
+    hipLaunchKernelGGL(batched_copy_kernel, dim3(8, count), dim3(256), 0, s, b);
+    if (hipGetLastError() != hipSuccess) { set_error("batched_copy_kernel launch failed"); status = MCEDM_ERR_HIP; }
+    count = 0;
+  }
+  void add(const float* src, float* dst, size_t n) {
+    b.src[count] = src; b.dst[count] = dst; b.n[count] = (int)n;
+    if (++count == COPY_MAX) flush();
+  }
+};
+
+static int pack_conv(const ConvP& c, const float* const* params, float* pk, Copier& cp, hipStream_t s) {
+  int rc = launch_pack_conv(params[c.w], pk + c.wpk, c.cout, c.cin, c.taps, c.qkv_heads, 0, s);
+  if (rc) return rc;
+  if (c.qkv_heads > 0) rc = launch_pack_bias(params[c.b], pk + c.bias, c.cout, c.qkv_heads, s);
+  else cp.add(params[c.b], pk + c.bias, c.cout);
+  if (rc) return rc;
+  if (c.wpk_dgrad != NONE) {
+    // data-gradient GEMM: output channels = conv input channels.  For the qkv conv the incoming gradient is in
+    // packed (head, which, c) row order, so its K index must be permuted the same way -> handled by the
+    // backward (it un-permutes the gradient rows when it is written); here rows are in reference order.
+    rc = launch_pack_conv(params[c.w], pk + c.wpk_dgrad, c.cin, c.cout, c.taps, 0, 1, s);
+  }
+  return rc;
+}
+
+static void pack_norm(const NormP& n, const float* const* params, float* pk, Copier& cp) {
+  cp.add(params[n.w], pk + n.gamma, n.C);
+  cp.add(params[n.b], pk + n.beta, n.C);
+}
+
+}  // namespace mcedm
+
+extern "C" int mcedm_unet_pack_weights(const mcedm_plan* plan, const float* const* params, void* packed, void* stream) {
+  MCEDM_REQUIRE(plan && params && packed, "pack_weights: null argument");
+  const mcedm_plan& P = *plan;
+  for (size_t i = 0; i < P.params.size(); ++i)
+    MCEDM_REQUIRE(params[i] != nullptr, "pack_weights: parameter %zu (%s) is null", i, P.params[i].name.c_str());
+  hipStream_t s = (hipStream_t)stream;
+  float* pk = (float*)packed;
+  const int ch = P.desc.ch;
+  hipLaunchKernelGGL(freqs_kernel, dim3(ceil_div(ch / 2, 64)), dim3(64), 0, s, pk + P.freqs, ch / 2);
+  MCEDM_LAUNCH_CHECK("freqs_kernel");
+  Copier cp;
+  cp.s = s;
+  cp.add(params[P.map0_w], pk + P.w0, (size_t)ch * ch); cp.add(params[P.map0_b], pk + P.b0, ch);
+  cp.add(params[P.map1_w], pk + P.w1, (size_t)ch * ch); cp.add(params[P.map1_b], pk + P.b1, ch);
+  int rc = pack_conv(P.conv_in, params, pk, cp, s);
+  if (rc) return rc;
+  for (auto* v : {&P.enc, &P.dec})
+    for (const BlockP& b : *v) {
+      cp.add(params[b.aff_w], pk + P.waff + (size_t)b.film_row0 * ch, (size_t)2 * b.cout * ch);
+      cp.add(params[b.aff_b], pk + P.baff + b.film_row0, (size_t)2 * b.cout);
+      pack_norm(b.norm0, params, pk, cp);
+      pack_norm(b.norm1, params, pk, cp);
+      if ((rc = pack_conv(b.conv0, params, pk, cp, s))) return rc;
+      if ((rc = pack_conv(b.conv1, params, pk, cp, s))) return rc;
+      if (b.skip_kernel == 1 && (rc = pack_conv(b.skip, params, pk, cp, s))) return rc;
+      if (b.attn) {
+        pack_norm(b.norm2, params, pk, cp);
+        if ((rc = pack_conv(b.qkv, params, pk, cp, s))) return rc;
+        if ((rc = pack_conv(b.proj, params, pk, cp, s))) return rc;
+      }
+    }
+  pack_norm(P.out_norm, params, pk, cp);
+  if ((rc = pack_conv(P.conv_out, params, pk, cp, s))) return rc;
+  cp.flush();
+  return cp.status;
+}
+
+// ------------------------------------------------------------------------------------------
+// activation layout inside the workspace (first-fit pool, simulated on the host)
+// ------------------------------------------------------------------------------------------
+namespace mcedm {
+
+struct Pool {
+  std::vector<std::pair<size_t, size_t>> free_;   // (offset, bytes), sorted by offset
+  size_t top = 0, peak = 0;
+  bool keep_all = false;
+  size_t alloc(size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1, 256);
+    for (size_t i = 0; i < free_.size(); ++i)
+      if (free_[i].second >= bytes) {
+        const size_t off = free_[i].first;
+        if (free_[i].second == bytes) free_.erase(free_.begin() + i);
+        else { free_[i].first += bytes; free_[i].second -= bytes; }
+        return off;
+      }
+    const size_t off = top;
+    top += bytes;
+    peak = std::max(peak, top);
+    return off;
+  }
+  void release(size_t off, size_t bytes) {
+    if (keep_all) return;
+    bytes = align_up(bytes ? bytes : 1, 256);
+    auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(off, (size_t)0));
+    it = free_.insert(it, {off, bytes});
+    if (it + 1 != free_.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; free_.erase(it + 1); }
+    if (it != free_.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; it = free_.erase(it) - 1; }
+    if (it->first + it->second == top) { top = it->first; free_.erase(it); }
+  }
+};
+
+struct LayoutBuilder {
+  Layout& L;
+  Pool pool;
+  int B;
+  int make(int C, int H, int W, size_t bytes) {
+    TRef t;
+    t.C = C; t.H = H; t.W = W; t.bytes = bytes;
+    t.off = pool.alloc(bytes);
+    L.t.push_back(t);
+    return (int)L.t.size() - 1;
+  }
+  int act(int C, int H, int W) { return make(C, H, W, (size_t)B * C * H * W * sizeof(float)); }
+  int coef(int C) { return make(C, 1, 1, (size_t)B * C * sizeof(Coef)); }
+  int stats(int groups) { return make(groups, 1, 1, (size_t)B * groups * 2 * sizeof(float)); }
+  void retain(int id) { if (id >= 0) L.t[id].ref++; }
+  void release(int id) {
+    if (id < 0) return;
+    if (--L.t[id].ref == 0) pool.release(L.t[id].off, L.t[id].bytes);
+  }
+  void drop(int id) { if (id >= 0) pool.release(L.t[id].off, L.t[id].bytes); }   // un-refcounted temporaries
+};
+
+int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_noise, Layout* out) {
+  MCEDM_REQUIRE(B > 0 && H > 0 && W > 0, "layout: empty shape B=%d H=%d W=%d", B, H, W);
+  MCEDM_REQUIRE(H % P.levels_div == 0 && W % P.levels_div == 0,
+                "layout: H=%d W=%d must be multiples of %d (2^(levels-1))", H, W, P.levels_div);
+  MCEDM_REQUIRE(n_noise == 1 || n_noise == B, "layout: n_noise=%d must be 1 or B=%d", n_noise, B);
+  Layout& L = *out;
+  L = Layout();
+  LayoutBuilder lb{L, Pool(), B};
+  lb.pool.keep_all = training != 0;
+  L.film = lb.make(P.film_rows, 1, 1, (size_t)n_noise * P.film_rows * sizeof(float));
+  L.t0 = lb.act(P.conv_in.cout, H, W);
+  std::vector<int> skips;
+  int cur = L.t0;
+  lb.retain(cur);                 // chain reference
+  lb.retain(cur); skips.push_back(cur);
+
+  auto do_block = [&](const BlockP& b, int xa, int xb) {
+    BlockLayout bl;
+    bl.xa = xa; bl.xb = xb;
+    bl.Hin = L.t[xa].H; bl.Win = L.t[xa].W;
+    bl.H = b.up ? bl.Hin * 2 : (b.down ? bl.Hin / 2 : bl.Hin);
+    bl.W = b.up ? bl.Win * 2 : (b.down ? bl.Win / 2 : bl.Win);
+    bl.coef0 = lb.coef(b.cin);
+    if (training) bl.stats0 = lb.stats(b.norm0.groups);
+    bl.h = lb.act(b.cout, bl.H, bl.W);
+    lb.drop(bl.coef0);
+    bl.coef1 = lb.coef(b.cout);
+    if (training) bl.stats1 = lb.stats(b.norm1.groups);
+    if (b.skip_kernel == 1) bl.sk = lb.act(b.cout, bl.H, bl.W);
+    bl.y = lb.act(b.cout, bl.H, bl.W);
+    lb.drop(bl.h); lb.drop(bl.coef1); lb.drop(bl.sk);
+    bl.out = bl.y;
+    if (b.attn) {
+      bl.coef2 = lb.coef(b.cout);
+      if (training) bl.stats2 = lb.stats(b.norm2.groups);
+      bl.qkv = lb.act(3 * b.cout, bl.H, bl.W);
+      lb.drop(bl.coef2);
+      bl.a = lb.act(b.cout, bl.H, bl.W);
+      lb.drop(bl.qkv);
+      bl.z = lb.act(b.cout, bl.H, bl.W);
+      lb.drop(bl.a); lb.drop(bl.y);
+      bl.out = bl.z;
+    }
+    L.blocks.push_back(bl);
+    return bl.out;
+  };
+
+  for (const BlockP& b : P.enc) {
+    const int o = do_block(b, cur, -1);
+    lb.retain(o);                 // chain
+    lb.retain(o); skips.push_back(o);
+    lb.release(cur);
+    cur = o;
+  }
+  for (const BlockP& b : P.dec) {
+    int xb = -1;
+    if (L.t[cur].C != b.cin) {    // adm_blocks.py:400-401
+      MCEDM_REQUIRE(!skips.empty(), "layout: skip stack underflow at %s", b.key.c_str());
+      xb = skips.back(); skips.pop_back();
+      MCEDM_REQUIRE(L.t[cur].C + L.t[xb].C == b.cin && L.t[cur].H == L.t[xb].H && L.t[cur].W == L.t[xb].W,
+                    "layout: concat mismatch at %s", b.key.c_str());
+    }
+    const int o = do_block(b, cur, xb);
+    lb.retain(o);
+    lb.release(cur);
+    lb.release(xb);
+    cur = o;
+  }
+  L.last = cur;
+  L.coef_out = lb.coef(P.out_norm.C);
+  if (training) L.stats_out = lb.stats(P.out_norm.groups);
+  L.total_bytes = lb.pool.peak;
+  return MCEDM_OK;
+}
+
+// header in front of the U-Net activations: EDM coefficient rows, conv_in transform, F / F_uncond
+struct Header {
+  size_t coefs4, c_noise, coef_in, F, Fu, total;
+};
+static Header header_for(const mcedm_plan& P, int B, int H, int W) {
+  Header h;
+  size_t cur = 0;
+  auto take = [&](size_t bytes) { size_t o = cur; cur += align_up(bytes, 256); return o; };
+  const int Ct = P.desc.in_channels + P.desc.cond_channels;
+  h.coefs4 = take((size_t)B * 4 * sizeof(float));
+  h.c_noise = take((size_t)B * sizeof(float));
+  h.coef_in = take((size_t)B * Ct * sizeof(Coef));
+  h.F = take((size_t)B * P.desc.out_channels * H * W * sizeof(float));
+  h.Fu = take((size_t)B * P.desc.out_channels * H * W * sizeof(float));
+  h.total = cur;
+  return h;
+}
+
+template <class T>
+static inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
+
+// ------------------------------------------------------------------------------------------
+// forward schedule (adm_blocks.py:364-404 and :159-181)
+// ------------------------------------------------------------------------------------------
+static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl, const Layout& L, void* act,
+                     const float* pk, int B, int n_noise, hipStream_t s) {
+  auto T = [&](int id) -> float* { return id < 0 ? nullptr : at<float>(act, L.t[id].off); };
+  auto CF = [&](int id) -> Coef* { return id < 0 ? nullptr : at<Coef>(act, L.t[id].off); };
+  const float* xa = T(bl.xa);
+  const float* xb = T(bl.xb);
+  const int Ca = L.t[bl.xa].C, Cb = bl.xb >= 0 ? L.t[bl.xb].C : 0;
+  const float eps = P.desc.eps;
+  int rc;
+  // norm0 -> transform table for conv0
+  GnArgs g0{xa, xb, Ca, Cb, bl.Hin * bl.Win, B, b.norm0.groups, pk + b.norm0.gamma, pk + b.norm0.beta,
+            nullptr, 0, 0, eps, CF(bl.coef0), T(bl.stats0)};
+  if ((rc = launch_gn_coef(g0, s))) return rc;
+  // h = conv0(resample(silu(norm0(x))))
+  ConvArgs c0{};
+  c0.xa = xa; c0.xb = xb; c0.Ca = Ca; c0.Cb = Cb;
+  c0.coef = CF(bl.coef0); c0.coef_batch = 1; c0.act = 1;
+  c0.resample = b.up ? RS_UP : (b.down ? RS_DOWN : RS_NONE);
+  c0.Hs = bl.Hin; c0.Ws = bl.Win; c0.H = bl.H; c0.W = bl.W;
+  c0.wpk = pk + b.conv0.wpk; c0.bias = pk + b.conv0.bias;
+  c0.out = T(bl.h); c0.Cout = b.cout; c0.B = B;
+  if ((rc = launch_conv(c0, 9, s))) return rc;
+  // norm1 + FiLM -> transform table for conv1
+  const float* film = at<float>(act, L.t[L.film].off) + b.film_row0;
+  GnArgs g1{T(bl.h), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm1.groups, pk + b.norm1.gamma, pk + b.norm1.beta,
+            film, n_noise > 1 ? 1 : 0, P.film_rows, eps, CF(bl.coef1), T(bl.stats1)};
+  if ((rc = launch_gn_coef(g1, s))) return rc;
+  // skip path
+  const float* res = xa;
+  int res_mode = RS_NONE;
+  if (b.skip_kernel == 1) {
+    ConvArgs cs{};
+    cs.xa = xa; cs.xb = xb; cs.Ca = Ca; cs.Cb = Cb;
+    cs.resample = c0.resample; cs.Hs = bl.Hin; cs.Ws = bl.Win; cs.H = bl.H; cs.W = bl.W;
+    cs.wpk = pk + b.skip.wpk; cs.bias = pk + b.skip.bias;
+    cs.out = T(bl.sk); cs.Cout = b.cout; cs.B = B;
+    if ((rc = launch_conv(cs, 1, s))) return rc;
+    res = T(bl.sk);
+  } else if (b.skip_kernel == 0) {
+    res_mode = c0.resample;
+  }
+  // y = conv1(silu(film(norm1(h)))) + skip
+  ConvArgs c1{};
+  c1.xa = T(bl.h); c1.Ca = b.cout;
+  c1.coef = CF(bl.coef1); c1.coef_batch = 1; c1.act = 1;
+  c1.Hs = bl.H; c1.Ws = bl.W; c1.H = bl.H; c1.W = bl.W;
+  c1.wpk = pk + b.conv1.wpk; c1.bias = pk + b.conv1.bias;
+  c1.res = res; c1.res_mode = res_mode;
+  c1.out = T(bl.y); c1.Cout = b.cout; c1.B = B;
+  if ((rc = launch_conv(c1, 9, s))) return rc;
+  if (!b.attn) return MCEDM_OK;
+  // attention: z = proj(attn(qkv(norm2(y)))) + y
+  GnArgs g2{T(bl.y), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm2.groups, pk + b.norm2.gamma, pk + b.norm2.beta,
+            nullptr, 0, 0, eps, CF(bl.coef2), T(bl.stats2)};
+  if ((rc = launch_gn_coef(g2, s))) return rc;
+  ConvArgs cq{};
+  cq.xa = T(bl.y); cq.Ca = b.cout;
+  cq.coef = CF(bl.coef2); cq.coef_batch = 1; cq.act = 0;
+  cq.Hs = bl.H; cq.Ws = bl.W; cq.H = bl.H; cq.W = bl.W;
+  cq.wpk = pk + b.qkv.wpk; cq.bias = pk + b.qkv.bias;
+  cq.out = T(bl.qkv); cq.Cout = 3 * b.cout; cq.B = B;
+  if ((rc = launch_conv(cq, 1, s))) return rc;
+  if ((rc = launch_attention(T(bl.qkv), T(bl.a), B, b.heads, bl.H * bl.W, s))) return rc;
+  ConvArgs cp{};
+  cp.xa = T(bl.a); cp.Ca = b.cout;
+  cp.Hs = bl.H; cp.Ws = bl.W; cp.H = bl.H; cp.W = bl.W;
+  cp.wpk = pk + b.proj.wpk; cp.bias = pk + b.proj.bias;
+  cp.res = T(bl.y); cp.res_mode = RS_NONE;
+  cp.out = T(bl.z); cp.Cout = b.cout; cp.B = B;
+  return launch_conv(cp, 1, s);
+}
+
+// act = start of the activation region (after the header)
+static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, const float* x, const float* cond,
+                        const Coef* coef_in, int coef_batch, const float* noise_labels, int n_noise, float* out,
+                        void* act, int B, int H, int W, hipStream_t s) {
+  const int ch = P.desc.ch;
+  int rc;
+  EmbArgs e{noise_labels, n_noise, ch, pk + P.freqs, pk + P.w0, pk + P.b0, pk + P.w1, pk + P.b1,
+            pk + P.waff, pk + P.baff, P.film_rows, nullptr, at<float>(act, L.t[L.film].off)};
+  if ((rc = launch_embedding(e, s))) return rc;
+  // conv_in on cat(cond, x)  (cond FIRST, adm_blocks.py:332)
+  ConvArgs ci{};
+  ci.xa = cond; ci.Ca = P.desc.cond_channels;
+  ci.xb = x; ci.Cb = P.desc.in_channels;
+  ci.coef = coef_in; ci.coef_batch = coef_batch; ci.act = 0;
+  ci.Hs = H; ci.Ws = W; ci.H = H; ci.W = W;
+  ci.wpk = pk + P.conv_in.wpk; ci.bias = pk + P.conv_in.bias;
+  ci.out = at<float>(act, L.t[L.t0].off); ci.Cout = P.conv_in.cout; ci.B = B;
+  if ((rc = launch_conv(ci, 9, s))) return rc;
+  size_t bi = 0;
+  for (const BlockP& b : P.enc) if ((rc = run_block(P, b, L.blocks[bi++], L, act, pk, B, n_noise, s))) return rc;
+  for (const BlockP& b : P.dec) if ((rc = run_block(P, b, L.blocks[bi++], L, act, pk, B, n_noise, s))) return rc;
+  // out = out_conv(silu(out_norm(x)))
+  const TRef& last = L.t[L.last];
+  GnArgs go{at<float>(act, last.off), nullptr, last.C, 0, H * W, B, P.out_norm.groups, pk + P.out_norm.gamma,
+            pk + P.out_norm.beta, nullptr, 0, 0, 1e-5f, at<Coef>(act, L.t[L.coef_out].off),
+            L.stats_out >= 0 ? at<float>(act, L.t[L.stats_out].off) : nullptr};
+  if ((rc = launch_gn_coef(go, s))) return rc;
+  ConvArgs co{};
+  co.xa = at<float>(act, last.off); co.Ca = last.C;
+  co.coef = at<Coef>(act, L.t[L.coef_out].off); co.coef_batch = 1; co.act = 1;
+  co.Hs = H; co.Ws = W; co.H = H; co.W = W;
+  co.wpk = pk + P.conv_out.wpk; co.bias = pk + P.conv_out.bias;
+  co.out = out; co.Cout = P.desc.out_channels; co.B = B;
+  return launch_conv(co, 9, s);
+}
+
+__global__ void scale_to_coef_kernel(const float* __restrict__ x_scale, int n, int cond_ch, int in_ch, Coef* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int Ct = cond_ch + in_ch;
+  for (int c = 0; c < Ct; ++c) out[(size_t)i * Ct + c] = Coef{0.f, c < cond_ch ? 1.0f : x_scale[i], 0.f, 0.f};
+}
+
+// D = c_skip x + c_out F(c_in x; ln(sigma)/4; cond) with sigma from the device (n_sigma rows) or from the host
+static int denoise_impl(const mcedm_plan& P, const Layout& L, const Header& hd, const float* pk, const float* x,
+                        const float* sigma_dev, float sigma_host, int use_host, int n_sigma, const float* cond,
+                        float w, float* D_out, float* F_out, void* ws, int B, int H, int W, float sigma_data,
+                        hipStream_t s) {
+  int rc;
+  float* coefs4 = at<float>(ws, hd.coefs4);
+  float* c_noise = at<float>(ws, hd.c_noise);
+  Coef* coef_in = at<Coef>(ws, hd.coef_in);
+  float* Fbuf = at<float>(ws, hd.F);
+  void* act = at<char>(ws, hd.total);
+  if ((rc = launch_precond_prepare(sigma_dev, sigma_host, use_host, n_sigma, sigma_data, P.desc.cond_channels,
+                                   P.desc.in_channels, coefs4, c_noise, coef_in, s))) return rc;
+  if ((rc = forward_impl(P, L, pk, x, cond, coef_in, n_sigma > 1 ? 1 : 0, c_noise, n_sigma, Fbuf, act, B, H, W, s))) return rc;
+  const float* Fu = nullptr;
+  if (fabsf(w) >= 0.001f && cond != nullptr) {      // classifier-free branch, mcedm.py:453-458
+    float* Fubuf = at<float>(ws, hd.Fu);
+    if ((rc = forward_impl(P, L, pk, x, nullptr, coef_in, n_sigma > 1 ? 1 : 0, c_noise, n_sigma, Fubuf, act, B, H, W, s))) return rc;
+    Fu = Fubuf;
+  }
+  const size_t per = (size_t)P.desc.out_channels * H * W;
+  return launch_precond_finish(x, Fbuf, Fu, w, coefs4, n_sigma, per, per * B, D_out, F_out, s);
+}
+
+}  // namespace mcedm
+
+extern "C" int mcedm_unet_workspace_bytes(const mcedm_plan* plan, int B, int H, int W, int training, size_t* bytes) {
+  MCEDM_REQUIRE(plan && bytes, "workspace_bytes: null argument");
+  Layout L;
+  int rc = build_layout(*plan, B, H, W, training, B, &L);
+  if (rc) return rc;
+  *bytes = header_for(*plan, B, H, W).total + L.total_bytes;
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_unet_forward(const mcedm_plan* plan, const void* packed, const float* x, const float* cond,
+                                  const float* x_scale, const float* noise_labels, int n_noise, float* out,
+                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
+                                  void* stream) {
+  MCEDM_REQUIRE(plan && packed && x && noise_labels && out && workspace, "unet_forward: null argument");
+  Layout L;
+  int rc = build_layout(*plan, B, H, W, training, n_noise, &L);
+  if (rc) return rc;
+  const Header hd = header_for(*plan, B, H, W);
+  if (hd.total + L.total_bytes > workspace_bytes) {
+    set_error("unet_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, hd.total + L.total_bytes);
+    return MCEDM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const Coef* coef_in = nullptr;
+  if (x_scale) {
+    Coef* c = at<Coef>(workspace, hd.coef_in);
+    hipLaunchKernelGGL(scale_to_coef_kernel, dim3(ceil_div(n_noise, 64)), dim3(64), 0, s, x_scale, n_noise,
+                       plan->desc.cond_channels, plan->desc.in_channels, c);
+    MCEDM_LAUNCH_CHECK("scale_to_coef_kernel");
+    coef_in = c;
+  }
+  return forward_impl(*plan, L, (const float*)packed, x, cond, coef_in, n_noise > 1 ? 1 : 0, noise_labels, n_noise, out,
+                      at<char>(workspace, hd.total), B, H, W, s);
+}
+
+extern "C" int mcedm_edm_denoise(const mcedm_plan* plan, const void* packed, const float* x, const float* sigma,
+                                 int n_sigma, const float* cond, float* D_out, float* F_out, void* workspace,
+                                 size_t workspace_bytes, int B, int H, int W, int training, double sigma_data,
+                                 void* stream) {
+  MCEDM_REQUIRE(plan && packed && x && sigma && D_out && workspace, "edm_denoise: null argument");
+  Layout L;
+  int rc = build_layout(*plan, B, H, W, training, n_sigma, &L);
+  if (rc) return rc;
+  const Header hd = header_for(*plan, B, H, W);
+  if (hd.total + L.total_bytes > workspace_bytes) {
+    set_error("edm_denoise: workspace too small (%zu < %zu bytes)", workspace_bytes, hd.total + L.total_bytes);
+    return MCEDM_ERR_WORKSPACE;
+  }
+  return denoise_impl(*plan, L, hd, (const float*)packed, x, sigma, 0.f, 0, n_sigma, cond, 0.f, D_out, F_out, workspace,
+                      B, H, W, (float)sigma_data, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Heun sampler (models/mcedm.py:570-638)
+// ------------------------------------------------------------------------------------------
+extern "C" int mcedm_edm_t_steps(const mcedm_sampler_desc* sp, double* t) {
+  MCEDM_REQUIRE(sp && t, "t_steps: null argument");
+  MCEDM_REQUIRE(sp->timesteps >= 2, "t_steps: timesteps=%d (the reference divides by timesteps-1)", sp->timesteps);
+  const double smin = std::max(sp->sigma_min, sp->net_sigma_min);   // mcedm.py:579-580
+  const double smax = std::min(sp->sigma_max, sp->net_sigma_max);
+  const int N = sp->timesteps;
+  const double a = std::pow(smax, 1.0 / sp->rho), b = std::pow(smin, 1.0 / sp->rho) - std::pow(smax, 1.0 / sp->rho);
+  for (int i = 0; i < N; ++i) t[i] = std::pow(a + (double)i / (double)(N - 1) * b, sp->rho);
+  t[N] = 0.0;
+  return MCEDM_OK;
+}
+
+namespace mcedm {
+struct SamplerBufs { size_t x, xn, d, x32, D, total; };
+static SamplerBufs sampler_bufs(const mcedm_plan& P, int B, int H, int W) {
+  SamplerBufs s;
+  size_t cur = 0;
+  auto take = [&](size_t bytes) { size_t o = cur; cur += align_up(bytes, 256); return o; };
+  const size_t n = (size_t)B * P.desc.in_channels * H * W;
+  s.x = take(n * 8); s.xn = take(n * 8); s.d = take(n * 8); s.x32 = take(n * 4); s.D = take(n * 4);
+  s.total = cur;
+  return s;
+}
+}  // namespace mcedm
+
+extern "C" int mcedm_sampler_workspace_bytes(const mcedm_plan* plan, int B, int H, int W, size_t* bytes) {
+  MCEDM_REQUIRE(plan && bytes, "sampler_workspace_bytes: null argument");
+  size_t u = 0;
+  int rc = mcedm_unet_workspace_bytes(plan, B, H, W, 0, &u);
+  if (rc) return rc;
+  *bytes = sampler_bufs(*plan, B, H, W).total + u;
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                                 const float* cond, const float* mask, const float* init_noise,
+                                 const double* step_noise, double* out, int return_last, void* workspace,
+                                 size_t workspace_bytes, int B, int H, int W, void* stream) {
+  MCEDM_REQUIRE(plan && packed && sp && cond && mask && init_noise && out && workspace, "heun_sample: null argument");
+  const mcedm_plan& P = *plan;
+  MCEDM_REQUIRE(P.desc.in_channels == P.desc.out_channels, "heun_sample: in_channels != out_channels");
+  MCEDM_REQUIRE(P.desc.cond_channels >= P.desc.in_channels, "heun_sample: cond must carry hu_known in its first %d channels",
+                P.desc.in_channels);
+  MCEDM_REQUIRE(sp->timesteps >= 2 && sp->timesteps <= 4096, "heun_sample: timesteps=%d out of range", sp->timesteps);
+  const int N = sp->timesteps;
+  std::vector<double> t(N + 1);
+  int rc = mcedm_edm_t_steps(sp, t.data());
+  if (rc) return rc;
+  std::vector<double> gammas(N);
+  for (int i = 0; i < N; ++i) {
+    const bool in_range = sp->S_min <= t[i] && t[i] <= sp->S_max;                    // mcedm.py:606
+    gammas[i] = in_range ? std::min(sp->S_churn / N, std::sqrt(2.0) - 1.0) : 0.0;
+    MCEDM_REQUIRE(gammas[i] == 0.0 || step_noise != nullptr, "heun_sample: S_churn > 0 needs step_noise");
+  }
+  Layout L;
+  if ((rc = build_layout(P, B, H, W, 0, 1, &L))) return rc;
+  const Header hd = header_for(P, B, H, W);
+  const SamplerBufs sb = sampler_bufs(P, B, H, W);
+  if (sb.total + hd.total + L.total_bytes > workspace_bytes) {
+    set_error("heun_sample: workspace too small (%zu < %zu bytes)", workspace_bytes, sb.total + hd.total + L.total_bytes);
+    return MCEDM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const float* pk = (const float*)packed;
+  double* x = at<double>(workspace, sb.x);
+  double* xn = at<double>(workspace, sb.xn);
+  double* dcur = at<double>(workspace, sb.d);
+  float* x32 = at<float>(workspace, sb.x32);
+  float* D = at<float>(workspace, sb.D);
+  void* uws = at<char>(workspace, sb.total);
+  const int C = P.desc.in_channels;
+  const size_t hw = (size_t)H * W, total = (size_t)B * C * hw;
+  const int Tout = return_last ? 1 : N + 1;
+  const float w = (float)sp->w;
+  const float sd = (float)sp->sigma_data;
+
+  if ((rc = launch_heun_init(cond, P.desc.cond_channels, C, hw, mask, init_noise, t[0], total, x, x32, s))) return rc;
+  if (!return_last && (rc = launch_heun_store(x, C, hw, 0, Tout, total, out, s))) return rc;
+  for (int i = 0; i < N; ++i) {
+    const double t_cur = t[i], t_next = t[i + 1];
+    const double t_hat = t_cur + gammas[i] * t_cur;                                   // mcedm.py:607
+    if (gammas[i] != 0.0) {
+      const double c = std::sqrt(t_hat * t_hat - t_cur * t_cur) * sp->S_noise;
+      if ((rc = launch_heun_churn(x, step_noise + (size_t)i * total, mask, c, total, x32, s))) return rc;
+    }
+    // Euler step (mcedm.py:611-618)
+    if ((rc = denoise_impl(P, L, hd, pk, x32, nullptr, (float)t_hat, 1, 1, cond, w, D, nullptr, uws, B, H, W, sd, s))) return rc;
+    if ((rc = launch_heun_euler(x, D, mask, t_hat, t_next - t_hat, total, dcur, xn, x32, s))) return rc;
+    // 2nd-order correction (mcedm.py:621-628)
+    if (i < N - 1) {
+      if ((rc = denoise_impl(P, L, hd, pk, x32, nullptr, (float)t_next, 1, 1, cond, w, D, nullptr, uws, B, H, W, sd, s))) return rc;
+      if ((rc = launch_heun_correct(x, dcur, D, mask, t_next, t_next - t_hat, total, xn, x32, s))) return rc;
+    }
+    std::swap(x, xn);
+    if (!return_last && (rc = launch_heun_store(x, C, hw, i + 1, Tout, total, out, s))) return rc;
+  }
+  if (return_last && (rc = launch_heun_store(x, C, hw, 0, 1, total, out, s))) return rc;
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_edm_denoise_backward(const mcedm_plan*, const void*, const float* const*, const float*, const float*,
+                                          int, const float*, const float*, float* const*, void*, size_t, int, int, int,
+                                          double, void*) {
+  set_error("edm_denoise_backward: not implemented in this build");
+  return MCEDM_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,88 @@
+// plan.hpp -- host-side description of the network (block list, parameter table, packed-weight
+// layout) and of the activation layout inside the caller's workspace.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace mcedm {
+
+constexpr size_t NONE = (size_t)-1;
+
+struct ParamInfo {
+  std::string name;
+  int ndim = 0;
+  int64_t shape[4] = {1, 1, 1, 1};
+  int64_t numel = 0;
+};
+
+struct ConvP {   // one Conv2d with weights
+  int w = -1, b = -1;          // parameter indices
+  int cin = 0, cout = 0, taps = 0;
+  int qkv_heads = 0;           // > 0: output rows re-ordered to (head, {q,k,v}, c)
+  size_t wpk = NONE, bias = NONE;      // float offsets into the packed buffer
+  size_t wpk_dgrad = NONE;             // transposed + mirrored weights for the data gradient
+};
+
+struct NormP {
+  int w = -1, b = -1;
+  int C = 0, groups = 0;
+  size_t gamma = NONE, beta = NONE;    // float offsets into the packed buffer
+};
+
+struct BlockP {
+  std::string key;
+  int cin = 0, cout = 0;
+  bool up = false, down = false, attn = false;
+  int heads = 0;
+  int skip_kernel = -1;        // -1 none (identity), 0 resample only, 1 1x1 conv
+  NormP norm0, norm1, norm2;
+  ConvP conv0, conv1, skip, qkv, proj;
+  int aff_w = -1, aff_b = -1;
+  int film_row0 = 0;           // first row of this block's (scale|shift) in the film table
+};
+
+// a tensor inside the workspace
+struct TRef {
+  size_t off = NONE;           // byte offset
+  int C = 0, H = 0, W = 0;
+  size_t bytes = 0;
+  int ref = 0;                 // live references while the layout is being simulated
+};
+
+struct BlockLayout {
+  int xa = -1, xb = -1;        // input tensor ids (xb = popped skip for concat blocks)
+  int coef0 = -1, h = -1, coef1 = -1, sk = -1, y = -1, coef2 = -1, qkv = -1, a = -1, z = -1;
+  int stats0 = -1, stats1 = -1, stats2 = -1;
+  int out = -1;                // y or z
+  int Hin = 0, Win = 0, H = 0, W = 0;
+};
+
+struct Layout {
+  std::vector<TRef> t;         // all tensors
+  std::vector<BlockLayout> blocks;   // encoder blocks then decoder blocks
+  int film = -1, t0 = -1, coef_out = -1, stats_out = -1, last = -1;
+  size_t total_bytes = 0;
+};
+
+}  // namespace mcedm
+
+struct mcedm_plan {
+  mcedm_unet_desc desc;
+  std::vector<mcedm::ParamInfo> params;
+  mcedm::ConvP conv_in, conv_out;
+  mcedm::NormP out_norm;
+  std::vector<mcedm::BlockP> enc, dec;
+  int map0_w = -1, map0_b = -1, map1_w = -1, map1_b = -1;
+  // packed buffer (float offsets)
+  size_t freqs = mcedm::NONE, w0 = mcedm::NONE, b0 = mcedm::NONE, w1 = mcedm::NONE, b1 = mcedm::NONE;
+  size_t waff = mcedm::NONE, baff = mcedm::NONE;
+  int film_rows = 0;
+  size_t packed_floats = 0;
+  int levels_div = 1;          // 2^(n_levels-1)
+};
+
+namespace mcedm {
+int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_noise, Layout* out);
+}

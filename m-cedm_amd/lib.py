@@ -1,0 +1,359 @@
+"""ctypes binding of libmcedm_hip.so (include/mcedm_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  Build it with ``python m-cedm_amd/build.py`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcedm_hip.so")
+MAX_LEVELS = 8
+
+# every symbol include/mcedm_hip.h declares
+EXPORTS = [
+    "mcedm_version", "mcedm_last_error", "mcedm_unet_plan_create", "mcedm_unet_plan_destroy",
+    "mcedm_unet_param_count", "mcedm_unet_param_info", "mcedm_unet_packed_bytes", "mcedm_unet_pack_weights",
+    "mcedm_unet_workspace_bytes", "mcedm_unet_forward", "mcedm_edm_denoise", "mcedm_sampler_workspace_bytes",
+    "mcedm_heun_sample", "mcedm_edm_t_steps", "mcedm_edm_loss", "mcedm_edm_noise_inputs",
+    "mcedm_edm_denoise_backward", "mcedm_sqnorm", "mcedm_adam_ema_step",
+]
+
+
+class UNetDesc(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("cond_channels", C.c_int32), ("out_channels", C.c_int32),
+                ("ch", C.c_int32), ("n_levels", C.c_int32), ("ch_mult", C.c_int32 * MAX_LEVELS),
+                ("num_res_blocks", C.c_int32), ("resolution", C.c_int32), ("n_attn_resolutions", C.c_int32),
+                ("attn_resolutions", C.c_int32 * MAX_LEVELS), ("channels_per_head", C.c_int32), ("eps", C.c_float)]
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [("timesteps", C.c_int32), ("sigma_min", C.c_double), ("sigma_max", C.c_double), ("rho", C.c_double),
+                ("S_churn", C.c_double), ("S_min", C.c_double), ("S_max", C.c_double), ("S_noise", C.c_double),
+                ("w", C.c_double), ("sigma_data", C.c_double), ("net_sigma_min", C.c_double),
+                ("net_sigma_max", C.c_double)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python m-cedm_amd/build.py` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32p, f64p, sz = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t
+    lib.mcedm_version.restype = C.c_int
+    lib.mcedm_last_error.restype = C.c_char_p
+    lib.mcedm_unet_plan_create.argtypes = [C.POINTER(UNetDesc), C.POINTER(vp)]
+    lib.mcedm_unet_plan_destroy.argtypes = [vp]
+    lib.mcedm_unet_plan_destroy.restype = None
+    lib.mcedm_unet_param_count.argtypes = [vp]
+    lib.mcedm_unet_param_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int64 * 4)]
+    lib.mcedm_unet_packed_bytes.argtypes = [vp, C.POINTER(sz)]
+    lib.mcedm_unet_pack_weights.argtypes = [vp, C.POINTER(vp), vp, vp]
+    lib.mcedm_unet_workspace_bytes.argtypes = [vp, i32, i32, i32, i32, C.POINTER(sz)]
+    lib.mcedm_unet_forward.argtypes = [vp, vp, f32p, f32p, f32p, f32p, i32, f32p, vp, sz, i32, i32, i32, i32, vp]
+    lib.mcedm_edm_denoise.argtypes = [vp, vp, f32p, f32p, i32, f32p, f32p, f32p, vp, sz, i32, i32, i32, i32,
+                                      C.c_double, vp]
+    lib.mcedm_sampler_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
+    lib.mcedm_heun_sample.argtypes = [vp, vp, C.POINTER(SamplerDesc), f32p, f32p, f32p, f64p, f64p, i32, vp, sz,
+                                      i32, i32, i32, vp]
+    lib.mcedm_edm_t_steps.argtypes = [C.POINTER(SamplerDesc), C.POINTER(C.c_double)]
+    lib.mcedm_edm_loss.argtypes = [f32p, f32p, f32p, f32p, i32, i32, i32, i32, C.c_double, f32p, f32p, vp]
+    lib.mcedm_edm_noise_inputs.argtypes = [f32p, f32p, f32p, f32p, i32, i32, i32, i32, C.c_double, C.c_double, f32p,
+                                           f32p, vp]
+    lib.mcedm_edm_denoise_backward.argtypes = [vp, vp, C.POINTER(vp), f32p, f32p, i32, f32p, f32p, C.POINTER(vp), vp,
+                                               sz, i32, i32, i32, C.c_double, vp]
+    lib.mcedm_sqnorm.argtypes = [f32p, sz, f64p, vp]
+    lib.mcedm_adam_ema_step.argtypes = [f32p, f32p, f32p, f32p, f32p, sz, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.c_double, f64p, C.c_double, C.c_double, C.c_double, C.c_int64, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)          # AttributeError here == header/library drift
+        if name not in ("mcedm_last_error", "mcedm_unet_plan_destroy"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mcedm_last_error().decode(errors="replace")
+        raise RuntimeError(f"libmcedm_hip {what} failed ({rc}): {msg}")
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libmcedm_hip needs device tensors (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def sampler_desc(sp, sigma_data=1.0, net_sigma_min=0.002, net_sigma_max=80.0) -> SamplerDesc:
+    """Build the C sampler description from the reference's ``sparams`` (attribute access, DictConfig or DotDict)."""
+    return SamplerDesc(int(sp.timesteps), float(sp.sigma_min), float(sp.sigma_max), float(sp.rho), float(sp.S_churn),
+                       float(sp.S_min), float(sp.S_max), float(sp.S_noise), float(sp.w), float(sigma_data),
+                       float(net_sigma_min), float(net_sigma_max))
+
+
+def edm_t_steps(sd: SamplerDesc) -> List[float]:
+    arr = (C.c_double * (sd.timesteps + 1))()
+    check(load().mcedm_edm_t_steps(C.byref(sd), arr), "edm_t_steps")
+    return list(arr)
+
+
+class Workspace:
+    """Grow-only byte buffer on one device (the library never allocates device memory itself)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = None
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class Plan:
+    """Host-side handle of one network architecture (mcedm_unet_plan_create)."""
+
+    def __init__(self, in_channels: int, cond_channels: int, out_channels: int, ch: int, ch_mult: Sequence[int],
+                 num_res_blocks: int, attn_resolutions: Sequence[int], resolution: int, channels_per_head: int = 64,
+                 eps: float = 1e-5):
+        lib = load()
+        if len(ch_mult) > MAX_LEVELS or len(attn_resolutions) > MAX_LEVELS:
+            raise RuntimeError("too many levels / attention resolutions")
+        d = UNetDesc()
+        d.in_channels, d.cond_channels, d.out_channels, d.ch = in_channels, cond_channels, out_channels, ch
+        d.n_levels = len(ch_mult)
+        for i, m in enumerate(ch_mult):
+            d.ch_mult[i] = int(m)
+        d.num_res_blocks, d.resolution = num_res_blocks, resolution
+        d.n_attn_resolutions = len(attn_resolutions)
+        for i, r in enumerate(attn_resolutions):
+            d.attn_resolutions[i] = int(r)
+        d.channels_per_head, d.eps = channels_per_head, eps
+        self.desc = d
+        h = C.c_void_p()
+        check(lib.mcedm_unet_plan_create(C.byref(d), C.byref(h)), "plan_create")
+        self._h = h
+        self._lib = lib
+        n = lib.mcedm_unet_param_count(h)
+        self.param_names: List[str] = []
+        self.param_shapes: List[tuple] = []
+        for i in range(n):
+            name, numel, ndim, shape = C.c_char_p(), C.c_int64(), C.c_int32(), (C.c_int64 * 4)()
+            check(lib.mcedm_unet_param_info(h, i, C.byref(name), C.byref(numel), C.byref(ndim), C.byref(shape)))
+            self.param_names.append(name.value.decode())
+            self.param_shapes.append(tuple(shape[j] for j in range(ndim.value)))
+        sz = C.c_size_t()
+        check(lib.mcedm_unet_packed_bytes(h, C.byref(sz)))
+        self.packed_bytes = sz.value
+        self.in_channels, self.cond_channels, self.out_channels = in_channels, cond_channels, out_channels
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mcedm_unet_plan_destroy(h)
+
+    # ---- derived weights ---------------------------------------------------------------
+    def pack(self, params: Dict[str, torch.Tensor], packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Pack the named fp32 device parameters (keys = DhariwalUNet.state_dict() names)."""
+        tens = []
+        for name, shape in zip(self.param_names, self.param_shapes):
+            t = params[name]
+            if tuple(t.shape) != shape:
+                raise RuntimeError(f"parameter {name}: shape {tuple(t.shape)} != {shape}")
+            tens.append(t.detach())
+        dev = tens[0].device
+        if packed is None:
+            packed = torch.empty(self.packed_bytes, dtype=torch.uint8, device=dev)
+        arr = (C.c_void_p * len(tens))(*[_ptr(t) for t in tens])
+        check(self._lib.mcedm_unet_pack_weights(self._h, arr, packed.data_ptr(), _stream()), "pack_weights")
+        return packed
+
+    # ---- sizes -----------------------------------------------------------------------------
+    def workspace_bytes(self, B: int, H: int, W: int, training: bool = False) -> int:
+        sz = C.c_size_t()
+        check(self._lib.mcedm_unet_workspace_bytes(self._h, B, H, W, int(training), C.byref(sz)), "workspace_bytes")
+        return sz.value
+
+    def sampler_workspace_bytes(self, B: int, H: int, W: int) -> int:
+        sz = C.c_size_t()
+        check(self._lib.mcedm_sampler_workspace_bytes(self._h, B, H, W, C.byref(sz)), "sampler_workspace_bytes")
+        return sz.value
+
+    # ---- compute ---------------------------------------------------------------------------
+    def forward(self, packed, x, noise_labels, cond=None, x_scale=None, ws: Optional[Workspace] = None,
+                training: bool = False) -> torch.Tensor:
+        B, _, H, W = x.shape
+        n_noise = noise_labels.numel()
+        ws = ws or Workspace()
+        need = self.workspace_bytes(B, H, W, training)
+        buf = ws.get(need, x.device)
+        out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        check(self._lib.mcedm_unet_forward(self._h, packed.data_ptr(), _ptr(x), _ptr(cond), _ptr(x_scale),
+                                           _ptr(noise_labels), n_noise, _ptr(out), buf.data_ptr(), buf.numel(), B, H, W,
+                                           int(training), _stream()), "unet_forward")
+        return out
+
+    def denoise(self, packed, x, sigma, cond=None, ws: Optional[Workspace] = None, training: bool = False,
+                sigma_data: float = 1.0, want_F: bool = False):
+        B, _, H, W = x.shape
+        n_sigma = sigma.numel()
+        ws = ws or Workspace()
+        buf = ws.get(self.workspace_bytes(B, H, W, training), x.device)
+        D = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        F = torch.empty_like(D) if want_F else None
+        check(self._lib.mcedm_edm_denoise(self._h, packed.data_ptr(), _ptr(x), _ptr(sigma), n_sigma, _ptr(cond), _ptr(D),
+                                          _ptr(F), buf.data_ptr(), buf.numel(), B, H, W, int(training), float(sigma_data),
+                                          _stream()), "edm_denoise")
+        return (D, F) if want_F else D
+
+    def sample(self, packed, sd: SamplerDesc, cond, mask, init_noise, step_noise=None, return_last: bool = True,
+               ws: Optional[Workspace] = None) -> torch.Tensor:
+        B, _, H, W = init_noise.shape
+        ws = ws or Workspace()
+        buf = ws.get(self.sampler_workspace_bytes(B, H, W), cond.device)
+        T = 1 if return_last else sd.timesteps + 1
+        out = torch.empty((B, T, H, W, self.in_channels), dtype=torch.float64, device=cond.device)
+        check(self._lib.mcedm_heun_sample(self._h, packed.data_ptr(), C.byref(sd), _ptr(cond), _ptr(mask),
+                                          _ptr(init_noise), _ptr(step_noise, torch.float64), _ptr(out, torch.float64),
+                                          int(return_last), buf.data_ptr(), buf.numel(), B, H, W, _stream()),
+              "heun_sample")
+        return out
+
+
+# ---- flat-buffer training helpers -------------------------------------------------------------
+def edm_noise_inputs(x, mask, noise, rnd_normal, P_mean=-1.2, P_std=1.2):
+    B, Cc, H, W = x.shape
+    x_noise = torch.empty_like(x)
+    sigma = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(load().mcedm_edm_noise_inputs(_ptr(x), _ptr(mask), _ptr(noise), _ptr(rnd_normal), B, Cc, H, W, P_mean, P_std,
+                                        _ptr(x_noise), _ptr(sigma), _stream()), "edm_noise_inputs")
+    return x_noise, sigma
+
+
+def edm_loss(D, x, mask, sigma, sigma_data=1.0, want_grad=True):
+    B, Cc, H, W = D.shape
+    loss = torch.empty(1, dtype=torch.float32, device=D.device)
+    dD = torch.empty_like(D) if want_grad else None
+    check(load().mcedm_edm_loss(_ptr(D), _ptr(x), _ptr(mask), _ptr(sigma), B, Cc, H, W, float(sigma_data), _ptr(loss),
+                                _ptr(dD), _stream()), "edm_loss")
+    return loss, dD
+
+
+def sqnorm(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty(1, dtype=torch.float64, device=g.device)
+    check(load().mcedm_sqnorm(_ptr(g), g.numel(), _ptr(out, torch.float64), _stream()), "sqnorm")
+    return out
+
+
+def adam_ema_step(param, grad, exp_avg, exp_avg_sq, ema, step, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8,
+                  weight_decay=0.0, sqnorm_t=None, max_norm=1.0, grad_scale=1.0, ema_beta=0.999):
+    check(load().mcedm_adam_ema_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(ema), param.numel(),
+                                     lr, beta1, beta2, eps, weight_decay, _ptr(sqnorm_t, torch.float64), max_norm,
+                                     grad_scale, ema_beta, int(step), _stream()), "adam_ema_step")
+
+
+# ---- kernel-level ops (tests, per-kernel timing) ---------------------------------------------------
+_OPS_BOUND = False
+
+
+def _bind_ops():
+    global _OPS_BOUND
+    lib = load()
+    if _OPS_BOUND:
+        return lib
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.mcedm_op_conv_packed_floats.argtypes = [i32, i32, i32]
+    lib.mcedm_op_conv_packed_floats.restype = sz
+    lib.mcedm_op_pack_conv.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.mcedm_op_gn_coef.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp]
+    lib.mcedm_op_conv.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32,
+                                  i32, i32, vp]
+    lib.mcedm_op_attention.argtypes = [vp, vp, i32, i32, i32, vp]
+    for n in ("mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv", "mcedm_op_attention"):
+        getattr(lib, n).restype = C.c_int
+    _OPS_BOUND = True
+    return lib
+
+
+OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv",
+              "mcedm_op_attention", "mcedm_op_set_conv_tile"]
+
+
+def set_conv_tile(mt: int = 0, ph: int = 0, pw: int = 0) -> None:
+    """Test hook: force the conv tile configuration; () restores the heuristic."""
+    lib = _bind_ops()
+    lib.mcedm_op_set_conv_tile.argtypes = [C.c_int, C.c_int, C.c_int]
+    check(lib.mcedm_op_set_conv_tile(mt, ph, pw), "set_conv_tile")
+RS_NONE, RS_UP, RS_DOWN = 0, 1, 2
+
+
+def op_pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], qkv_heads: int = 0, dgrad: bool = False):
+    lib = _bind_ops()
+    Cout, Cin, k, _ = w.shape
+    rows, cols = (Cin, Cout) if dgrad else (Cout, Cin)
+    n = lib.mcedm_op_conv_packed_floats(rows, cols, k)
+    wpk = torch.empty(n, dtype=torch.float32, device=w.device)
+    bpk = torch.zeros((Cout + 31) // 32 * 32, dtype=torch.float32, device=w.device) if b is not None else None
+    check(lib.mcedm_op_pack_conv(_ptr(w), _ptr(b), Cout, Cin, k, qkv_heads, int(dgrad), _ptr(wpk), _ptr(bpk), _stream()),
+          "op_pack_conv")
+    return wpk, bpk
+
+
+def op_gn_coef(xa, xb, gamma, beta, film=None, film_batch=0, film_stride=0, eps=1e-5, want_stats=False):
+    lib = _bind_ops()
+    B, Ca = xa.shape[:2]
+    Cb = xb.shape[1] if xb is not None else 0
+    HW = xa[0, 0].numel()
+    Ct = Ca + Cb
+    coef = torch.empty((B, Ct, 4), dtype=torch.float32, device=xa.device)
+    stats = torch.empty((B, min(32, Ct // 4), 2), dtype=torch.float32, device=xa.device) if want_stats else None
+    check(lib.mcedm_op_gn_coef(_ptr(xa), _ptr(xb), Ca, Cb, B, HW, _ptr(gamma), _ptr(beta), _ptr(film), film_batch,
+                               film_stride, eps, _ptr(coef), _ptr(stats), _stream()), "op_gn_coef")
+    return (coef, stats) if want_stats else coef
+
+
+def op_conv(xa, xb, wpk, bias_pk, Cout, k, coef=None, coef_batch=1, act=0, resample=RS_NONE, res=None,
+            res_mode=RS_NONE, out=None):
+    lib = _bind_ops()
+    B, Ca, Hs, Ws = xa.shape
+    Cb = xb.shape[1] if xb is not None else 0
+    H, W = (Hs * 2, Ws * 2) if resample == RS_UP else ((Hs // 2, Ws // 2) if resample == RS_DOWN else (Hs, Ws))
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xa.device)
+    check(lib.mcedm_op_conv(_ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, resample, Hs, Ws, H, W, _ptr(wpk),
+                            _ptr(bias_pk), _ptr(res), res_mode, _ptr(out), Cout, B, k, _stream()), "op_conv")
+    return out
+
+
+def op_attention(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """qkv [B, heads*3*64, H, W] in packed (head, {q,k,v}, c) channel order -> [B, heads*64, H, W]."""
+    lib = _bind_ops()
+    B, C3, H, W = qkv.shape
+    out = torch.empty((B, C3 // 3, H, W), dtype=torch.float32, device=qkv.device)
+    check(lib.mcedm_op_attention(_ptr(qkv), _ptr(out), B, heads, H * W, _stream()), "op_attention")
+    return out
