@@ -192,6 +192,14 @@ int mcedm_op_attention(const float* qkv, float* out, int B, int heads, int T, vo
  * (0,0,0) restores the size heuristic.  Process-global, not thread-safe. */
 int mcedm_op_set_conv_tile(int mt, int ph, int pw);
 
+/* ---- measurement ---------------------------------------------------------------------------
+ * Per-launch timing with HIP event pairs recorded on the launch stream (bench.py's roofline leg).
+ * mcedm_prof_report waits for the events, then writes a JSON array
+ *   [{"name", "launches", "total_ms", "flops", "bytes"}, ...]   (flops / bytes: algorithmic sums)
+ * into buf and clears the records.  Not for use under graph capture. */
+int mcedm_prof_enable(int on);
+int mcedm_prof_report(char* buf, size_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

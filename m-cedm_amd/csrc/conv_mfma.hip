@@ -15,6 +15,7 @@
 // stays NCHW: lanes run along W, so both the staging loads and the epilogue stores are
 // contiguous 128-byte row segments.
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace mcedm {
 
@@ -315,6 +316,16 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
     set_error("conv grid out of range (%lld blocks)", blocks);
     return MCEDM_ERR_INVALID;
   }
+  // algorithmic cost of this launch: 2*MAC flops; bytes = input read once + output written once + weights + residual
+  static char name[96];
+  if (prof_enabled())
+    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d>>", C::MT, C::PH, C::PW, C::WM,
+             C::WN, C::TAPS, C::KC);
+  const double px = (double)a.B * a.H * a.W;
+  const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
+  const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
+                              (double)a.Cout * (a.Ca + a.Cb) * C::TAPS);
+  ProfScope ps(name, flops, bytes, stream);
   hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y, mtiles,
                      nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_mfma_kernel");

@@ -1,6 +1,7 @@
 // norm_emb_attn.hip -- K1 (GroupNorm statistics -> per-channel transform table), K6 (sigma
 // embedding MLP + every FiLM affine row) and K5 (fused softmax attention on fp32 MFMA).
 #include "common.hpp"
+#include "prof.hpp"
 
 namespace mcedm {
 
@@ -87,6 +88,7 @@ int launch_gn_coef(const GnArgs& a, hipStream_t stream) {
   MCEDM_REQUIRE(a.Cb == 0 || a.Ca % cpg == 0, "group_norm: a group straddles the concat boundary (Ca=%d cpg=%d)", a.Ca, cpg);
   MCEDM_REQUIRE(cpg <= 256, "group_norm: too many channels per group (%d)", cpg);
   MCEDM_REQUIRE(a.xa != nullptr && (a.Cb == 0 || a.xb != nullptr), "group_norm: null input");
+  ProfScope ps("gn_coef_kernel", 3.0 * a.B * (double)C * a.HW, 4.0 * a.B * (double)C * a.HW, stream);
   hipLaunchKernelGGL(gn_coef_kernel, dim3(a.B * a.groups), dim3(256), 0, stream, a);
   MCEDM_LAUNCH_CHECK("gn_coef_kernel");
   return MCEDM_OK;
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
 int launch_attention(const float* qkv, float* out, int B, int heads, int T, hipStream_t stream) {
   MCEDM_REQUIRE(B > 0 && heads > 0 && T > 0, "attention: empty shape");
   MCEDM_REQUIRE((long long)B * heads <= 65535, "attention: B*heads too large for grid.y");
+  ProfScope ps("attention_kernel", 4.0 * B * heads * (double)T * T * 64, 4.0 * 4 * B * heads * 64.0 * T, stream);
   hipLaunchKernelGGL(attention_kernel, dim3(ceil_div(T, 32), B * heads), dim3(64), 0, stream, qkv, out, T);
   MCEDM_LAUNCH_CHECK("attention_kernel");
   return MCEDM_OK;

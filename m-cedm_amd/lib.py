@@ -301,7 +301,23 @@ def _bind_ops():
 
 
 OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv",
-              "mcedm_op_attention", "mcedm_op_set_conv_tile"]
+              "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report"]
+
+
+def prof_enable(on: bool) -> None:
+    lib = load()
+    lib.mcedm_prof_enable.argtypes = [C.c_int]
+    check(lib.mcedm_prof_enable(int(on)), "prof_enable")
+
+
+def prof_report() -> list:
+    """Kernel-level timing rows collected since prof_enable(True) (synchronises the recorded events)."""
+    import json
+    lib = load()
+    lib.mcedm_prof_report.argtypes = [C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(1 << 16)
+    check(lib.mcedm_prof_report(buf, len(buf)), "prof_report")
+    return json.loads(buf.value.decode())
 
 
 def set_conv_tile(mt: int = 0, ph: int = 0, pw: int = 0) -> None:
