@@ -37,24 +37,68 @@ struct ConvCfg {
   static_assert(MT % 4 == 0 && KC % 2 == 0, "vector widths");
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+// SiLU with the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each); relative error ~1e-6, far inside the
+// 1e-4 parity bar, and a third of the VALU work of expf() + IEEE division in the staging path.
+// SiLU with the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each); relative error ~1e-6, far inside the
+// 1e-4 parity bar, and a third of the VALU work of expf() + IEEE division in the staging path.
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ float apply_coef(float v, const Coef& c, int act) {
   float t = (v - c.mean) * c.scale + c.offset;
   return act ? silu_f(t) : t;
 }
 
-// Stage one KC-channel slab of the (transformed, resampled, zero-padded) input into LDS.
-// The channel loop is outermost so that the per-(sample, channel) coefficient row and the source
-// plane pointer are wave-uniform (scalar loads); all global loads of the slab are issued before
-// the first one is consumed.
+// ---- staging -----------------------------------------------------------------------------------------
+// Split into an issue half (global loads -> registers) and a commit half (transform + LDS writes) so the
+// loads of chunk c+1 are in flight while the MFMAs of chunk c run.  Everything that does not depend on the
+// channel (tile coordinates, bounds, clamped source offsets) is computed once per workgroup; the loads are
+// unconditional from clamped addresses (no exec-masked branches) and out-of-image / padded-channel elements
+// are zeroed at commit.  The per-(sample, channel) transform rows are wave-uniform (scalar loads) and are
+// prefetched together with the inputs.
 template <class C, int RS>
-__device__ __forceinline__ void stage_input(const ConvArgs& p, float* xl, int n, int c0, int y0, int x0, int tid) {
+struct TileGeom {
+  static constexpr int NL = (RS == RS_DOWN) ? 4 : 1;
+  static constexpr int SUB = (C::PLANE + 255) / 256;
+  int soff[SUB][NL];   // clamped source offsets inside one channel plane
+  bool inb[SUB];       // element lies inside the image (else it is conv zero padding)
+  bool inp[SUB];       // element index lies inside the LDS plane
+};
+
+template <class C, int RS>
+__device__ __forceinline__ void make_geom(const ConvArgs& p, TileGeom<C, RS>& G, int y0, int x0, int tid) {
+#pragma unroll
+  for (int sub = 0; sub < TileGeom<C, RS>::SUB; ++sub) {
+    const int e = tid + sub * 256;
+    const int r = e / C::PITCH;
+    const int c = e - r * C::PITCH;
+    const int y = y0 + r - C::HALO;
+    const int x = x0 + c - C::HALO;
+    G.inp[sub] = e < C::PLANE;
+    G.inb[sub] = G.inp[sub] && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
+    const int yc = G.inb[sub] ? y : 0, xc = G.inb[sub] ? x : 0;
+    if (RS == RS_NONE) {
+      G.soff[sub][0] = yc * p.Ws + xc;
+    } else if (RS == RS_UP) {
+      G.soff[sub][0] = (yc >> 1) * p.Ws + (xc >> 1);
+    } else {
+      const int o = (2 * yc) * p.Ws + 2 * xc;
+      G.soff[sub][0] = o; G.soff[sub][1] = o + 1; G.soff[sub][2] = o + p.Ws; G.soff[sub][3] = o + p.Ws + 1;
+    }
+  }
+}
+
+template <class C, int RS>
+struct InputRegs {
+  float raw[C::KC][TileGeom<C, RS>::SUB][TileGeom<C, RS>::NL];
+  Coef cf[C::KC];
+};
+
+template <class C, int RS>
+__device__ __forceinline__ void load_input(const ConvArgs& p, const TileGeom<C, RS>& G, InputRegs<C, RS>& R, int n,
+                                           int c0) {
   const int Cin = p.Ca + p.Cb;
-  constexpr int NL = (RS == RS_DOWN) ? 4 : 1;
-  constexpr int SUB = (C::PLANE + 255) / 256;
-  float raw[C::KC][SUB][NL];
   const size_t src_plane = (size_t)p.Hs * p.Ws;
+  const float* safe = p.xa ? p.xa : p.xb;     // any valid plane for padded channels (values are discarded)
 #pragma unroll
   for (int cil = 0; cil < C::KC; ++cil) {
     const int ci = c0 + cil;
@@ -63,67 +107,124 @@ __device__ __forceinline__ void stage_input(const ConvArgs& p, float* xl, int n,
     const int cc = in_a ? ci : ci - p.Ca;
     const int CC = in_a ? p.Ca : p.Cb;
     const bool chan_ok = (ci < Cin) && (src != nullptr);
-    const float* plane = chan_ok ? src + ((size_t)n * CC + cc) * src_plane : nullptr;
+    const float* plane = chan_ok ? src + ((size_t)n * CC + cc) * src_plane : safe;
+    R.cf[cil] = (chan_ok && p.coef) ? p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + ci] : Coef{0.f, 1.f, 0.f, 0.f};
 #pragma unroll
-    for (int sub = 0; sub < SUB; ++sub) {
-      const int e = tid + sub * 256;
-      const int r = e / C::PITCH;
-      const int c = e - r * C::PITCH;
-      const int y = y0 + r - C::HALO;
-      const int x = x0 + c - C::HALO;
-      const bool ok = chan_ok && (e < C::PLANE) && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
+    for (int sub = 0; sub < TileGeom<C, RS>::SUB; ++sub)
 #pragma unroll
-      for (int q = 0; q < NL; ++q) raw[cil][sub][q] = 0.f;
-      if (ok) {
-        if (RS == RS_NONE) {
-          raw[cil][sub][0] = plane[(size_t)y * p.Ws + x];
-        } else if (RS == RS_UP) {
-          raw[cil][sub][0] = plane[(size_t)(y >> 1) * p.Ws + (x >> 1)];
-        } else {
-          const float* q0 = plane + (size_t)(2 * y) * p.Ws + 2 * x;
-          raw[cil][sub][0] = q0[0];
-          raw[cil][sub][1] = q0[1];
-          raw[cil][sub][2] = q0[p.Ws];
-          raw[cil][sub][3] = q0[p.Ws + 1];
-        }
-      }
-    }
+      for (int q = 0; q < TileGeom<C, RS>::NL; ++q) R.raw[cil][sub][q] = plane[G.soff[sub][q]];
   }
+}
+
+template <class C, int RS>
+__device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C, RS>& G, float* xl,
+                                            const InputRegs<C, RS>& R, int c0, int tid) {
+  const int Cin = p.Ca + p.Cb;
 #pragma unroll
   for (int cil = 0; cil < C::KC; ++cil) {
     const int ci = c0 + cil;
     const bool chan_ok = (ci < Cin) && ((ci < p.Ca ? p.xa : p.xb) != nullptr);
-    Coef cf{0.f, 1.f, 0.f, 0.f};
-    if (chan_ok && p.coef) cf = p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + ci];
 #pragma unroll
-    for (int sub = 0; sub < SUB; ++sub) {
-      const int e = tid + sub * 256;
-      const int r = e / C::PITCH;
-      const int c = e - r * C::PITCH;
-      const int y = y0 + r - C::HALO;
-      const int x = x0 + c - C::HALO;
-      const bool ok = chan_ok && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
-      float v = 0.f;
-      if (ok) {
-        if (RS == RS_DOWN) {
-          // 2x2 box filter of the ACTIVATED source (adm_blocks.py:75-77 runs after silu(norm(x)))
-          v = 0.25f * ((apply_coef(raw[cil][sub][0], cf, p.act) + apply_coef(raw[cil][sub][1], cf, p.act)) +
-                       (apply_coef(raw[cil][sub][2], cf, p.act) + apply_coef(raw[cil][sub][3], cf, p.act)));
-        } else {
-          v = apply_coef(raw[cil][sub][0], cf, p.act);
-        }
+    for (int sub = 0; sub < TileGeom<C, RS>::SUB; ++sub) {
+      float v;
+      if (RS == RS_DOWN) {
+        // 2x2 box filter of the ACTIVATED source (adm_blocks.py:75-77 runs after silu(norm(x)))
+        v = 0.25f * ((apply_coef(R.raw[cil][sub][0], R.cf[cil], p.act) + apply_coef(R.raw[cil][sub][1], R.cf[cil], p.act)) +
+                     (apply_coef(R.raw[cil][sub][2], R.cf[cil], p.act) + apply_coef(R.raw[cil][sub][3], R.cf[cil], p.act)));
+      } else {
+        v = apply_coef(R.raw[cil][sub][0], R.cf[cil], p.act);
       }
-      if (e < C::PLANE) xl[cil * C::PLANE + e] = v;
+      v = (chan_ok && G.inb[sub]) ? v : 0.f;
+      if (G.inp[sub]) xl[cil * C::PLANE + tid + sub * 256] = v;
     }
   }
 }
 
+// weights: rows of MT floats out of the packed [chunk][tap][ci_local][CoutP] table
 template <class C>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles,
-                                                        int nchunks, int coutp) {
-  __shared__ __attribute__((aligned(16))) float xl[C::XL];
-  __shared__ __attribute__((aligned(16))) float wl[C::WL];
+struct WeightRegs {
+  static constexpr int NV4 = C::WL / 4;
+  static constexpr int IT = (NV4 + 255) / 256;
+  f32x4 v[IT];   // native vector type: HIP's float4 class defeats SROA here and lands in scratch
+};
 
+template <class C>
+__device__ __forceinline__ void load_weights(const float* wpk, WeightRegs<C>& R, int ch, int m0, int coutp, int tid) {
+  constexpr int V4_PER_ROW = C::MT / 4;
+  const float* wbase = wpk + (size_t)ch * (C::TAPS * C::KC) * coutp + m0;
+#pragma unroll
+  for (int it = 0; it < WeightRegs<C>::IT; ++it) {
+    int i = tid + it * 256;
+    if (i >= WeightRegs<C>::NV4) i = WeightRegs<C>::NV4 - 1;     // clamp instead of branching; the store is guarded
+    const int row = i / V4_PER_ROW;
+    const int c4 = i - row * V4_PER_ROW;
+    R.v[it] = *reinterpret_cast<const f32x4*>(wbase + (size_t)row * coutp + c4 * 4);
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void store_weights(float* wl, const WeightRegs<C>& R, int tid) {
+#pragma unroll
+  for (int it = 0; it < WeightRegs<C>::IT; ++it) {
+    const int i = tid + it * 256;
+    if (i < WeightRegs<C>::NV4) reinterpret_cast<f32x4*>(wl)[i] = R.v[it];
+  }
+}
+
+// FULL: every output channel of the tile exists (m0 + MT <= Cout); RM: -1 no residual, else its Resample mode.
+template <class C, bool FULL, int RM>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C::TM][C::TN], int n, int m0, int y0,
+                                              int x0, int wm, int wn, int lane) {
+  const size_t HW = (size_t)p.H * p.W;
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) {
+    const int cbase = m0 + (wm * C::TM + i) * 32 + 4 * (lane >> 5);     // + (r&3) + 8*(r>>2)
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cbase + (r & 3) + 8 * (r >> 2);
+      const int cc = FULL ? co : (co < p.Cout ? co : p.Cout - 1);
+      bv[r] = p.bias ? p.bias[cc] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+      const int pix = (wn * C::TN + j) * 32 + (lane & 31);
+      const int y = y0 + pix / C::PW;
+      const int x = x0 + pix % C::PW;
+      if (y < p.H && x < p.W) {
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cbase + (r & 3) + 8 * (r >> 2);
+          const int cc = FULL ? co : (co < p.Cout ? co : p.Cout - 1);
+          const size_t plane = (size_t)n * p.Cout + cc;
+          if (RM == -1) {
+            rv[r] = 0.f;
+          } else if (RM == RS_NONE) {
+            rv[r] = p.res[plane * HW + (size_t)y * p.W + x];
+          } else if (RM == RS_UP) {
+            rv[r] = p.res[plane * (HW >> 2) + (size_t)(y >> 1) * (p.W >> 1) + (x >> 1)];
+          } else {
+            const int Wr = p.W * 2;
+            const float* q0 = p.res + plane * (HW * 4) + (size_t)(2 * y) * Wr + 2 * x;
+            rv[r] = 0.25f * ((q0[0] + q0[1]) + (q0[Wr] + q0[Wr + 1]));
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cbase + (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r] + bv[r];
+          if (RM != -1) v += rv[r];
+          if (FULL || co < p.Cout) p.out[((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x] = v;
+        }
+      }
+    }
+  }
+}
+
+template <class C, int RS>
+__device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* wl, int tiles_x, int tiles_y,
+                                          int mtiles, int nchunks, int coutp) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -154,87 +255,95 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p, int tiles
   }
   const int aoff = (lane >> 5) * C::MT + wm * C::TM * 32 + (lane & 31);
 
+  TileGeom<C, RS> geom;
+  make_geom<C, RS>(p, geom, y0, x0, tid);
+  InputRegs<C, RS> xin;
+  WeightRegs<C> win;
+  load_weights<C>(p.wpk, win, 0, m0, coutp, tid);
+  load_input<C, RS>(p, geom, xin, n, 0);
+
   for (int ch = 0; ch < nchunks; ++ch) {
-    // ---- weights: rows of MT floats out of the packed [chunk][tap][ci_local][CoutP] table
-    {
-      constexpr int V4_PER_ROW = C::MT / 4;
-      constexpr int NV4 = C::WL / 4;
-      const float* wbase = p.wpk + (size_t)ch * (C::TAPS * C::KC) * coutp + m0;
+    store_weights<C>(wl, win, tid);
+    store_input<C, RS>(p, geom, xl, xin, ch * C::KC, tid);
+    __syncthreads();
+    if (ch + 1 < nchunks) {   // next chunk's global loads fly while this chunk's MFMAs run
+      load_weights<C>(p.wpk, win, ch + 1, m0, coutp, tid);
+      load_input<C, RS>(p, geom, xin, n, (ch + 1) * C::KC);
+    }
+    if (wave < C::NWAVE) {
+      // Register double-buffered operand fragments: the LDS reads of k-step s+1 are issued before the MFMAs
+      // of k-step s.  The tap loop stays rolled (a fully unrolled chunk pushes the prefetch registers into
+      // scratch); the fragment for the next tap's first k-step is fetched at the end of the current tap.
+      float fa[2][C::TM], fb[2][C::TN];
 #pragma unroll
-      for (int it = 0; it < (NV4 + 255) / 256; ++it) {
-        const int i = tid + it * 256;
-        if (i < NV4) {
-          const int row = i / V4_PER_ROW;
-          const int c4 = i - row * V4_PER_ROW;
-          const float4 v = *reinterpret_cast<const float4*>(wbase + (size_t)row * coutp + c4 * 4);
-          reinterpret_cast<float4*>(wl)[i] = v;
+      for (int i = 0; i < C::TM; ++i) fa[0][i] = wl[aoff + i * 32];
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) fb[0][j] = xl[boff[j]];
+#pragma unroll 1
+      for (int tap = 0; tap < C::TAPS; ++tap) {
+        const int toff = (C::TAPS == 9) ? (tap / 3) * C::PITCH + (tap % 3) : 0;
+        const int tn = (tap + 1 < C::TAPS) ? tap + 1 : tap;         // clamped: the last prefetch is discarded
+        const int toff_n = (C::TAPS == 9) ? (tn / 3) * C::PITCH + (tn % 3) : 0;
+        const float* wt = wl + aoff + tap * C::KC * C::MT;
+        const float* wt_n = wl + aoff + tn * C::KC * C::MT;
+#pragma unroll
+        for (int kk = 0; kk < C::KC / 2; ++kk) {
+          const int cur = kk & 1, nxt = cur ^ 1;
+          if (kk + 1 < C::KC / 2) {
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) fa[nxt][i] = wt[2 * (kk + 1) * C::MT + i * 32];
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) fb[nxt][j] = xl[boff[j] + toff + 2 * (kk + 1) * C::PLANE];
+          } else {
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) fa[nxt][i] = wt_n[i * 32];
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) fb[nxt][j] = xl[boff[j] + toff_n];
+          }
+#pragma unroll
+          for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+          // pin the order: this step's LDS reads (next fragments) first, then this step's MFMAs, so the reads'
+          // latency hides under TM*TN * 64 cycles of matrix work and the wait before the MFMAs is a counted one
+          __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
         }
       }
-    }
-    // ---- inputs
-    if (p.resample == RS_NONE) stage_input<C, RS_NONE>(p, xl, n, ch * C::KC, y0, x0, tid);
-    else if (p.resample == RS_UP) stage_input<C, RS_UP>(p, xl, n, ch * C::KC, y0, x0, tid);
-    else stage_input<C, RS_DOWN>(p, xl, n, ch * C::KC, y0, x0, tid);
-    __syncthreads();
-
-    if (wave < C::NWAVE) {
-#pragma unroll
-    for (int tap = 0; tap < C::TAPS; ++tap) {
-      const int ky = (C::TAPS == 9) ? tap / 3 : 0;
-      const int kx = (C::TAPS == 9) ? tap % 3 : 0;
-#pragma unroll
-      for (int kk = 0; kk < C::KC / 2; ++kk) {
-        float a[C::TM], b[C::TN];
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i) a[i] = wl[aoff + (tap * C::KC + 2 * kk) * C::MT + i * 32];
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j) b[j] = xl[boff[j] + 2 * kk * C::PLANE + ky * C::PITCH + kx];
-#pragma unroll
-        for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-          for (int j = 0; j < C::TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-    }
     }
     __syncthreads();
   }
   if (wave >= C::NWAVE) return;
 
-  // ---- epilogue: + bias, + (resampled) residual, store NCHW
-  const size_t HW = (size_t)p.H * p.W;
-#pragma unroll
-  for (int j = 0; j < C::TN; ++j) {
-    const int pix = (wn * C::TN + j) * 32 + (lane & 31);
-    const int y = y0 + pix / C::PW;
-    const int x = x0 + pix % C::PW;
-    if (y >= p.H || x >= p.W) continue;
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + (wm * C::TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < p.Cout) {
-          float v = acc[i][j][r];
-          if (p.bias) v += p.bias[co];
-          if (p.res) {
-            const float* rp = p.res;
-            if (p.res_mode == RS_NONE) {
-              v += rp[((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x];
-            } else if (p.res_mode == RS_UP) {
-              const int Wr = p.W >> 1;
-              v += rp[((size_t)n * p.Cout + co) * (HW >> 2) + (size_t)(y >> 1) * Wr + (x >> 1)];
-            } else {
-              const int Wr = p.W * 2;
-              const float* q0 = rp + ((size_t)n * p.Cout + co) * (HW * 4) + (size_t)(2 * y) * Wr + 2 * x;
-              v += 0.25f * ((q0[0] + q0[1]) + (q0[Wr] + q0[Wr + 1]));
-            }
-          }
-          p.out[((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x] = v;
-        }
-      }
-    }
+  // ---- epilogue: + bias, + (resampled) residual, store NCHW.  Dispatch on wave-uniform conditions once, so
+  // that inside a variant the 16 residual loads of an accumulator tile are issued back to back (one wait)
+  // instead of one load -> wait -> store round trip per element.
+  const bool full = (m0 + C::MT <= p.Cout);
+  const int rm = p.res ? p.res_mode : -1;
+  if (full) {
+    if (rm == -1) conv_epilogue<C, true, -1>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    else if (rm == RS_NONE) conv_epilogue<C, true, RS_NONE>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    else if (rm == RS_UP) conv_epilogue<C, true, RS_UP>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    else conv_epilogue<C, true, RS_DOWN>(p, acc, n, m0, y0, x0, wm, wn, lane);
+  } else {
+    if (rm == -1) conv_epilogue<C, false, -1>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    else if (rm == RS_NONE) conv_epilogue<C, false, RS_NONE>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    else if (rm == RS_UP) conv_epilogue<C, false, RS_UP>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    else conv_epilogue<C, false, RS_DOWN>(p, acc, n, m0, y0, x0, wm, wn, lane);
   }
+}
+
+// RESAMPLED = false is the hot instantiation (no up/down sampling): keeping it in a kernel of its own gives
+// it its own register allocation (the 2x2-mean variant prefetches 4 source pixels per tile element).
+template <class C, bool RESAMPLED>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles,
+                                                           int nchunks, int coutp) {
+  __shared__ __attribute__((aligned(16))) float xl[C::XL];
+  __shared__ __attribute__((aligned(16))) float wl[C::WL];
+  if (!RESAMPLED) conv_body<C, RS_NONE>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
+  else if (p.resample == RS_UP) conv_body<C, RS_UP>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
+  else conv_body<C, RS_DOWN>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -319,15 +428,19 @@ static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
   // algorithmic cost of this launch: 2*MAC flops; bytes = input read once + output written once + weights + residual
   static char name[96];
   if (prof_enabled())
-    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d>>", C::MT, C::PH, C::PW, C::WM,
-             C::WN, C::TAPS, C::KC);
+    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d>, %s>", C::MT, C::PH, C::PW,
+             C::WM, C::WN, C::TAPS, C::KC, a.resample == RS_NONE ? "false" : "true");
   const double px = (double)a.B * a.H * a.W;
   const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
   const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
                               (double)a.Cout * (a.Ca + a.Cb) * C::TAPS);
   ProfScope ps(name, flops, bytes, stream);
-  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y, mtiles,
-                     nchunks, cout_padded(a.Cout));
+  if (a.resample == RS_NONE)
+    hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
+                       mtiles, nchunks, cout_padded(a.Cout));
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
+                       mtiles, nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_mfma_kernel");
   return MCEDM_OK;
 }

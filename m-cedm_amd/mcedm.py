@@ -1,0 +1,398 @@
+"""Drop-in ``PlMcedm`` for the reference's ``models/mcedm.py`` (M-CEDM LightningModule).
+
+Same constructor (``PlMcedm(hparams)``), attributes, state_dict keys and method signatures as the
+reference (models/mcedm.py:16-639): Hydra can instantiate it with ``_target_`` pointed here and
+Lightning drives ``training_step`` / ``validation_step`` / ``test_step`` unchanged.  Everything from
+``model_precond`` / ``get_denoised`` / ``sample_edm`` / the training loss downwards runs in
+libmcedm_hip.so; the metric bookkeeping around it (MAE, PDE residual, return dicts for the plotting
+callbacks) stays in Python like the reference's.
+
+Deliberate differences, all documented in INTEGRATION.md:
+  * sample_edm draws the per-step churn noise only for steps with gamma > 0 (the reference draws and
+    multiplies by zero otherwise, mcedm.py:608), so device RNG streams differ for S_churn = 0;
+  * PDE guidance (guide_dx / dx_cond) is outside the hot path and raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import lib as _lib
+from .adm_blocks import DhariwalUNet, EmaModel
+
+try:  # Lightning is the reference's runtime; the build/test containers do not ship it
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - exercised where Lightning is absent
+    class _Base(nn.Module):
+        """Minimal stand-in so the module is usable (and testable) without pytorch_lightning."""
+        current_epoch = 0
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+
+class DotDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+    __delattr__ = dict.__delitem__
+
+
+class Normalizer(nn.Module):
+    """(x - subtract) / divide and its inverse; stats travel as buffers (models/normalizer.py:5-29)."""
+
+    def __init__(self, stats_shape=()):
+        super().__init__()
+        self.register_buffer("subtract", torch.zeros(stats_shape))
+        self.register_buffer("divide", torch.ones(stats_shape))
+
+    def set_stats(self, subtract, divide):
+        self.subtract = torch.as_tensor(subtract)
+        self.divide = torch.as_tensor(divide)
+
+    def forward(self, x, inverse=False):
+        if inverse:
+            return x * self.divide.to(x.device) + self.subtract.to(x.device)
+        return (x - self.subtract.to(x.device)) / self.divide.to(x.device)
+
+
+def masked_l1(pred, target, mask, loss_dim=None):
+    """MaskedLoss('l1') of models/losses.py:62-78: sum |pred*m - target*m| / sum(m)."""
+    pred, target = pred * mask, target * mask
+    if loss_dim is not None:
+        pred, target, mask = pred[..., loss_dim], target[..., loss_dim], mask[..., loss_dim]
+    return (pred - target).abs().sum() / mask.sum()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+class _EdmTrainLoss(torch.autograd.Function):
+    """loss = mean_b sum_chw w(sigma_b) (D*m - x*m)^2 with D = model_precond(x_noise, sigma, cond): forward and
+    backward both run in the HIP library (mcedm_edm_denoise / mcedm_edm_loss / mcedm_edm_denoise_backward).
+    Parameters enter as inputs so that Lightning's automatic optimisation and DDP see ordinary .grad tensors."""
+
+    @staticmethod
+    def forward(ctx, module, x, x_noise, sigma, cond, mask, *params):
+        net: DhariwalUNet = module.model
+        plan, packed = net.plan, net.packed_weights()
+        B, _, H, W = x.shape
+        ws = module._train_ws
+        D = plan.denoise(packed, x_noise, sigma, cond=cond, ws=ws, training=True, sigma_data=module.sigma_data)
+        loss, dD = _lib.edm_loss(D, x, mask, sigma, sigma_data=module.sigma_data, want_grad=True)
+        ctx.module, ctx.saved = module, (x_noise, sigma, cond, dD)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        module = ctx.module
+        net: DhariwalUNet = module.model
+        x_noise, sigma, cond, dD = ctx.saved
+        params = list(net.parameters())
+        grads = module._grad_views(params)
+        net.plan.denoise_backward(net.packed_weights(), net.named_param_dict(), x_noise, sigma, cond, dD, grads,
+                                  ws=module._train_ws, sigma_data=module.sigma_data)
+        scale = g.to(torch.float32)
+        return (None, None, None, None, None, None) + tuple(gr * scale for gr in grads)
+
+
+class PlMcedm(_Base):
+    def __init__(self, hparams):
+        super().__init__()
+        self.save_hyperparameters()
+        m, o, d = hparams.model, hparams.optimization, hparams.data
+        self.cond_p = 1.0
+        for flag in ("dx_cond", "add_cond_mask", "add_xt"):
+            if getattr(m, flag, False) if hasattr(m, flag) else False:
+                raise NotImplementedError(f"hparams.model.{flag}=True is outside the MI355X hot path (SURVEY.md 8a)")
+        if not str(hparams.name).startswith("adm"):
+            raise NotImplementedError("only the ADM/EDM U-Net (hparams.name = 'adm*') is on the hot path")
+        self.dx_cond = self.add_cond_mask = self.add_xt = False
+        self.model = DhariwalUNet(hparams)
+        self.ema_model = EmaModel(self.model, beta=m.ema_rate) if m.ema else None
+        # EDM preconditioning constants (mcedm.py:45-50)
+        self.P_mean, self.P_std, self.sigma_data = -1.2, 1.2, 1.0
+        self.sigma_min, self.sigma_max = 0.002, 80
+        self.normalization = d.normalization
+        self.uniform_dequantization = d.uniform_dequantization
+        self.gaussian_dequantization = d.gaussian_dequantization
+        self.rescaled = d.rescaled
+        n_state = m.out_ch // 2
+        shape = (n_state,) if n_state > 1 else ()
+        self.normalizer_input = Normalizer(shape)
+        self.normalizer_target = Normalizer(shape)
+        self.optimizer, self.lr, self.weight_decay = o.optimizer, o.lr, o.weight_decay
+        self.beta1, self.amsgrad, self.eps = o.beta1, o.amsgrad, o.eps
+        self.factor, self.step_size, self.loss = o.factor, o.step_size, o.loss
+        self.pde_loss_lambda = getattr(o, "pde_loss_lambda", 0.0) if hasattr(o, "pde_loss_lambda") else 0.0
+        if self.pde_loss_lambda:
+            raise NotImplementedError("pde_loss_lambda != 0 is outside the hot path")
+        self.pde_loss = None
+        self.pde_loss_simulator = None
+        self.sparams = self.get_sampler_params(hparams)
+        self.test_sparams = self.sparams
+        self.h_ch = self.u_ch = n_state
+        self._train_ws = _lib.Workspace()
+        self._sample_ws = _lib.Workspace()
+        self._grad_buf = None
+
+    # ---- configuration hooks (same names as the reference) ------------------------------------------
+    @staticmethod
+    def get_sampler_params(params):
+        if params.get("sampler", None) is None:
+            return DotDict(type="ddim", timesteps=50, skip_type="uniform", eta=0.0, n_samples=1, n_repeat=5,
+                           n_time_h=128, n_time_u=0)
+        return params.sampler
+
+    def set_test_sampler_params(self, params):
+        self.test_sparams = params
+
+    def set_pde_loss_function(self, system, flip_xy):
+        """The PDE residual is a host-side metric of the reference (models/pde_loss.py); when this module is used
+        inside the reference tree its own implementation is picked up, otherwise the metric is skipped."""
+        try:
+            from models.loss_helper import get_pde_loss_function      # the host repository's, if importable
+            self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system, flip_xy)
+        except Exception:
+            self.pde_loss = self.pde_loss_simulator = None
+
+    def setup(self, stage: str = None) -> None:
+        if stage == "fit":
+            st = self.trainer.datamodule.get_norm_stats()
+            if self.normalization == "min_max":
+                self.normalizer_input.set_stats(st["input_min"], st["input_min_max"])
+                self.normalizer_target.set_stats(st["target_min"], st["target_min_max"])
+            else:
+                self.normalizer_input.set_stats(st["input_mean"], st["input_std"])
+                self.normalizer_target.set_stats(st["target_mean"], st["target_std"])
+
+    def configure_optimizers(self):
+        if self.optimizer == "Adam":
+            opt = torch.optim.Adam(self.model.parameters(), lr=self.lr, weight_decay=self.weight_decay,
+                                   betas=(self.beta1, 0.999), amsgrad=self.amsgrad, eps=self.eps)
+        elif self.optimizer == "RMSProp":
+            opt = torch.optim.RMSprop(self.model.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        elif self.optimizer == "SGD":
+            opt = torch.optim.SGD(self.model.parameters(), lr=self.lr, momentum=0.9)
+        else:
+            raise NotImplementedError(f"Optimizer {self.optimizer} not understood.")
+        return {"optimizer": opt}
+
+    def optimizer_step(self, *args, **kwargs):
+        super().optimizer_step(*args, **kwargs)
+        if self.ema_model is not None:
+            self.ema_model.update(self.model)
+
+    # ---- data transforms (host-side elementwise, mcedm.py:170-197) --------------------------------------
+    def data_transform(self, h, u):
+        x = torch.cat([self.normalizer_input(h), self.normalizer_target(u)], dim=-1)
+        if self.uniform_dequantization:
+            x = x / 256.0 * 255.0 + torch.rand_like(x) / 256.0
+        if self.gaussian_dequantization:
+            x = x + torch.randn_like(x) * 0.01
+        if self.rescaled:
+            x = 2 * x - 1.0
+        return x
+
+    def inverse_data_transform(self, h, u):
+        if self.rescaled:
+            h, u = (h + 1.0) / 2.0, (u + 1.0) / 2.0
+        if self.normalization == "min_max":
+            h, u = torch.clamp(h, 0.0, 1.0), torch.clamp(u, 0.0, 1.0)
+        return self.normalizer_input(h, inverse=True), self.normalizer_target(u, inverse=True)
+
+    def get_loss_weight(self, sigma):
+        return (sigma ** 2 + self.sigma_data ** 2) / (sigma * self.sigma_data) ** 2
+
+    def get_cond_in(self, x, mask, dx=None, dt=None):
+        return x * (1 - mask) + torch.randn_like(x) * mask
+
+    # ---- preconditioned network (HIP) ------------------------------------------------------------------
+    def _net(self, model):
+        if isinstance(model, EmaModel):
+            return model.ma_model
+        if isinstance(model, nn.parallel.DistributedDataParallel):
+            return model.module
+        return model
+
+    def model_precond(self, x_noise, sigma, cond=None, x_self_cond=None, dx=None):
+        if x_self_cond is not None or dx is not None:
+            raise NotImplementedError("x_self_cond / dx are outside the hot path")
+        net = self.model
+        with torch.no_grad():
+            return net.plan.denoise(net.packed_weights(), x_noise.float().contiguous(),
+                                    sigma.to(torch.float32).reshape(-1).contiguous(),
+                                    cond=None if cond is None else cond.float().contiguous(), ws=net._ws,
+                                    sigma_data=self.sigma_data)
+
+    def get_denoised(self, model, xt, t, cond=None, x_self_cond=None, dx=None, w=None):
+        if x_self_cond is not None or dx is not None:
+            raise NotImplementedError("x_self_cond / dx are outside the hot path")
+        net = self._net(model)
+        xt = xt.to(torch.float32).contiguous()
+        sigma = torch.as_tensor(t).to(torch.float32).reshape(-1).contiguous().to(xt.device)
+        cond = None if cond is None else cond.float().contiguous()
+        packed = net.packed_weights()
+        with torch.no_grad():
+            D, F = net.plan.denoise(packed, xt, sigma, cond=cond, ws=net._ws, sigma_data=self.sigma_data, want_F=True)
+            if not (w is None or abs(w) < 0.001 or cond is None):          # classifier-free blend, mcedm.py:453-458
+                _, Fu = net.plan.denoise(packed, xt, sigma, cond=None, ws=net._ws, sigma_data=self.sigma_data, want_F=True)
+                F = (w + 1) * F - w * Fu
+                s = sigma.reshape(-1, 1, 1, 1)
+                D = self.sigma_data ** 2 / (s ** 2 + self.sigma_data ** 2) * xt + \
+                    s * self.sigma_data / (s ** 2 + self.sigma_data ** 2).sqrt() * F
+        return D, F
+
+    def round_sigma(self, sigma, return_index=False):
+        return 0 if return_index else torch.as_tensor(sigma)
+
+    def forward(self, x, sigma, noise, cond=None, mask=None):
+        x_noise = x + (mask * noise * sigma if mask is not None else noise * sigma)
+        if torch.rand(1) >= self.cond_p:
+            cond = None
+        return self.model_precond(x_noise, sigma.float(), cond)
+
+    # ---- training ------------------------------------------------------------------------------------
+    def _grad_views(self, params):
+        n = sum(p.numel() for p in params)
+        if self._grad_buf is None or self._grad_buf.numel() != n or self._grad_buf.device != params[0].device:
+            self._grad_buf = torch.empty(n, dtype=torch.float32, device=params[0].device)
+        views, off = [], 0
+        for p in params:
+            views.append(self._grad_buf[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return views
+
+    def training_step(self, train_batch, batch_idx):
+        h_unnorm, dx, dt, u_unnorm, mask = train_batch
+        self.h_ch, self.u_ch = h_unnorm.shape[-1], u_unnorm.shape[-1]
+        x = self.data_transform(h_unnorm, u_unnorm)                       # b h w c
+        cond_in = _nchw(self.get_cond_in(x, mask, dx, dt))
+        x = _nchw(x)
+        noise = torch.randn_like(x)
+        rnd_normal = torch.randn([x.shape[0], 1, 1, 1]).type_as(x)        # CPU generator, like mcedm.py:269-270
+        mask_c = _nchw(mask).to(torch.float32)
+        x_noise, sigma = _lib.edm_noise_inputs(x, mask_c, noise, rnd_normal.reshape(-1).contiguous(), self.P_mean, self.P_std)
+        torch.rand(1)                                                      # the cond_p draw of mcedm.py:231 (cond_p = 1: never drops)
+        loss = _EdmTrainLoss.apply(self, x, x_noise, sigma, cond_in, mask_c, *self.model.parameters())
+        self.log("train_loss", loss, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
+        return loss
+
+    # ---- sampling -------------------------------------------------------------------------------------
+    def sample_edm(self, hu, cond, hu_mask, sparams, return_last=True, guide_dx=False):
+        if guide_dx:
+            raise NotImplementedError("guide_dx=True (PDE guidance) is outside the hot path")
+        model = self.ema_model if self.ema_model is not None else self.model
+        net = self._net(model)
+        n_state = self.h_ch + self.u_ch
+        if cond.shape[1] < n_state:
+            raise RuntimeError("cond must carry the known state in its first h_ch+u_ch channels (mcedm.py:590)")
+        sd = _lib.sampler_desc(sparams, self.sigma_data, self.sigma_min, self.sigma_max)
+        hu_noise = torch.randn_like(hu, dtype=torch.float32)
+        N = sd.timesteps
+        t = _lib.edm_t_steps(sd)
+        churn = any((min(sd.S_churn / N, math.sqrt(2) - 1) if sd.S_min <= t[i] <= sd.S_max else 0) > 0 for i in range(N))
+        step_noise = torch.randn((N,) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if churn else None
+        with torch.no_grad():
+            return net.plan.sample(net.packed_weights(), sd, cond.float().contiguous(), hu_mask.float().contiguous(),
+                                   hu_noise.contiguous(), step_noise, return_last=return_last, ws=self._sample_ws)
+
+    # ---- evaluation loops (host-side bookkeeping, mcedm.py:283-441) ----------------------------------------
+    def get_pde_loss(self, x_denoised, x_gt_unnorm=None, noise_level=None, clamp_loss=True, do_rearrange=True,
+                     reduce=True):
+        if self.pde_loss is None:
+            return None
+        if do_rearrange:
+            x_denoised = x_denoised.permute(0, 2, 3, 1)
+        h = x_denoised[..., 0:self.h_ch].to(torch.float32)
+        u = x_denoised[..., self.h_ch:self.h_ch + self.u_ch].to(torch.float32)
+        x_un = torch.cat(self.inverse_data_transform(h, u), dim=-1)
+        err = self.pde_loss(x_un, x_un if x_gt_unnorm is None else x_gt_unnorm, self.normalizer_input,
+                            self.normalizer_target, return_d=False, calc_prob=False, clamp_loss=clamp_loss)
+        if noise_level is not None:
+            err = err / (noise_level.reshape(-1, 1, 1, 1) + 1.0)
+        return torch.sum(err) if reduce else err
+
+    def _unnormalised_mae(self, hu_last, h_unnorm, u_unnorm, mask, loss_dim=None):
+        h_un, u_un = self.inverse_data_transform(hu_last[..., 0:self.h_ch], hu_last[..., self.h_ch:self.h_ch + self.u_ch])
+        return masked_l1(torch.cat([h_un, u_un], dim=-1), torch.cat([h_unnorm, u_unnorm], dim=-1), mask, loss_dim)
+
+    def validation_step(self, val_batch, batch_idx):
+        if (self.current_epoch + 1) % 100 != 0 and self.current_epoch != 0:
+            return {"epoch": self.current_epoch}
+        h_unnorm, dx, dt, u_unnorm, masks = val_batch
+        self.h_ch, self.u_ch = h_unnorm.shape[-1], u_unnorm.shape[-1]
+        state_gt = self.data_transform(h_unnorm, u_unnorm)
+        noise = torch.randn_like(_nchw(state_gt))
+        out = {"epoch": self.current_epoch}
+        if self.sparams.type != "edm":
+            raise RuntimeError("Non EDM sampler is not supported for the model")
+        for name, mask in masks.items():
+            cond_in = _nchw(self.get_cond_in(state_gt, mask, dx, dt))
+            xs = self.sample_edm(noise, cond_in, _nchw(mask), self.sparams, return_last=True,
+                                 guide_dx=self.sparams.guide_dx)
+            hu_last = xs[:, -1]
+            loss_hu = masked_l1(hu_last, state_gt, mask)
+            loss_hu_un = self._unnormalised_mae(hu_last, h_unnorm, u_unnorm, mask)
+            self.log(f"val_mae_{name}", loss_hu, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
+            self.log(f"val_mae_{name}_un", loss_hu_un, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
+            pde = self.get_pde_loss(hu_last, clamp_loss=False, do_rearrange=False)
+            if pde is not None:
+                self.log(f"val_pde_loss_{name}", pde / len(h_unnorm), prog_bar=True, on_epoch=True, on_step=False,
+                         sync_dist=True)
+            out[f"loss_{name}"], out[f"loss_{name}_un"] = loss_hu, loss_hu_un
+            out[f"traj_{name}"], out[f"gt_{name}"] = hu_last.unsqueeze(1), state_gt
+        return out
+
+    def test_step(self, test_batch, test_idx):
+        h_unnorm, dx, dt, u_unnorm, masks = test_batch
+        self.h_ch, self.u_ch = h_ch, u_ch = h_unnorm.shape[-1], u_unnorm.shape[-1]
+        dm = self.trainer.datamodule
+        down_factor = dm.down_factor if dm.down_interp else 1
+        state_gt = self.data_transform(h_unnorm, u_unnorm)
+        sp = self.test_sparams
+        n = sp.n_samples
+        state_rep = _nchw(state_gt).repeat(n, 1, 1, 1)
+        if sp.type != "edm":
+            raise RuntimeError("Non EDM sampler is not supported for the model")
+        out = {}
+        nb = len(h_unnorm)
+        for name, mask in masks.items():
+            lo = 0 if name.startswith("h") else h_ch
+            loss_dim = torch.arange(lo, lo + (h_ch if name.startswith("h") else u_ch)).long()
+            cond_rep = _nchw(self.get_cond_in(state_gt, mask, dx, dt)).repeat(n, 1, 1, 1)
+            mask_rep = _nchw(mask).repeat(n, 1, 1, 1)
+            noise = torch.randn_like(state_rep)
+            xs = self.sample_edm(noise, cond_rep, mask_rep, sp, return_last=sp.return_last, guide_dx=sp.guide_dx)
+            xs_mean = xs.reshape(n, nb, *xs.shape[1:]).mean(dim=0)            # '(n b) t h w c -> n b t h w c'
+            hu_last = xs_mean[:, -1]
+            mask_loss = mask
+            if down_factor > 1:
+                each = 2 ** (down_factor - 1)
+                sel = torch.zeros_like(mask)
+                sel[:, ::each, ::each] = 1.0
+                mask_loss = mask * sel
+            loss_hu = masked_l1(hu_last, state_gt, mask_loss, loss_dim)
+            loss_hu_un = self._unnormalised_mae(hu_last, h_unnorm, u_unnorm, mask_loss, loss_dim)
+            print(f"\nLoss {name} {loss_hu}, loss {name} un {loss_hu_un}")
+            self.log(f"test_mae_{name}", loss_hu, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
+            self.log(f"test_mae_{name}_un", loss_hu_un, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
+            pde = self.get_pde_loss(xs[:, -1], clamp_loss=False, do_rearrange=False)
+            if pde is not None:
+                self.log(f"test_pde_loss_{name}", pde / n / nb, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
+                pde_gt = self.get_pde_loss(state_gt, clamp_loss=False, do_rearrange=False)
+                self.log("test_pde_loss_gt", pde_gt / nb, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
+            out[f"loss_{name}"], out[f"loss_{name}_un"] = loss_hu, loss_hu_un
+            if n < 15:
+                last = xs[:, -1]
+                # '(n b) h w c -> b h w n c', then a singleton time axis: [b, 1, T, X, n, 2]
+                out[f"traj_{name}"] = last.reshape(n, nb, *last.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)
+                out[f"gt_{name}"] = state_gt
+        return out
