@@ -14,6 +14,8 @@
 // A workgroup = 4 waves = MT output channels x (PH x PW) pixels of one sample.  HBM layout
 // stays NCHW: lanes run along W, so both the staging loads and the epilogue stores are
 // contiguous 128-byte row segments.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "prof.hpp"
 
@@ -416,7 +418,8 @@ int launch_pack_bias(const float* b, float* dst, int Cout, int qkv_heads, hipStr
 }
 
 template <class C>
-static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
+  const ConvArgs& a = a_in;
   const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
   const int mtiles = ceil_div(a.Cout, C::MT);
   const int nchunks = ceil_div(a.Ca + a.Cb, C::KC);
