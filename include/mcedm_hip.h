@@ -188,6 +188,28 @@ int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, const mcedm_
 /* a = softmax(q^T k / sqrt(64)) v per (sample, head) (models/adm_blocks.py:103-109,174-178);
  * qkv is [B][heads][3][64][T] (the packed qkv conv's output), out [B][heads*64][T]. */
 int mcedm_op_attention(const float* qkv, float* out, int B, int heads, int T, void* stream);
+/* Backward building blocks.
+ * conv weight / bias gradient: dw [Cout, Cin, k, k], db [Cout] (may be NULL) for the conv described as in mcedm_op_conv
+ * (the input transform is recomputed on the fly); scratch holds mcedm_op_wgrad_scratch_floats() floats; qkv_heads > 0:
+ * dy rows are in packed qkv order.  Data gradient = mcedm_op_conv on weights packed with dgrad = 1. */
+size_t mcedm_op_wgrad_scratch_floats(int Cout, int Cin, int k);
+int mcedm_op_conv_wgrad(const float* dy, const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef,
+                        int coef_batch, int act, int resample, int Hs, int Ws, int H, int W, int Cout, int B, int k,
+                        int qkv_heads, float* scratch, float* dw, float* db, void* stream);
+/* Backward of resample(act(film(group_norm(cat(xa, xb))))): dact is the gradient w.r.t. the conv input (conv
+ * resolution), coef / stats come from mcedm_op_gn_coef of the forward.  Writes (or accumulates into) dxa / dxb, adds
+ * `add` (add_mode 1: source resolution [B, C, Hs, Ws]; 2: conv resolution, mapped back through the resampling),
+ * and returns dgamma, dbeta [C] and, when film != NULL, dfilm rows (d scale | d shift) with stride dfilm_stride.
+ * ab is a [B][C][2] scratch. */
+int mcedm_op_gn_bwd(const float* dact, int resample, const float* xa, const float* xb, int Ca, int Cb, int Hs, int Ws,
+                    int B, const mcedm_coef* coef, const float* stats, const float* gamma, const float* beta,
+                    const float* film, int film_batch, int film_stride, int act, float* dxa, float* dxb, int accumulate,
+                    const float* add, int add_mode, float* ab, float* dgamma, float* dbeta, float* dfilm,
+                    int dfilm_stride, void* stream);
+/* Attention backward (models/adm_blocks.py:111-118): qkv / dqkv packed [B][heads][3][64][T]; a, da [B][heads*64][T];
+ * lse_scratch holds B*heads*T*2 floats. */
+int mcedm_op_attention_bwd(const float* qkv, const float* a, const float* da, float* dqkv, float* lse_scratch, int B,
+                           int heads, int T, void* stream);
 /* Test hook: force the conv tile (channel tile mt in {32,64,128}, pixel tile ph x pw in {8x32,16x16,8x8});
  * (0,0,0) restores the size heuristic.  Process-global, not thread-safe. */
 int mcedm_op_set_conv_tile(int mt, int ph, int pw);

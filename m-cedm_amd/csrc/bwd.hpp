@@ -1,0 +1,55 @@
+// bwd.hpp -- launchers of the backward kernels (wgrad_mfma.hip, bwd_kernels.hip).
+#pragma once
+#include "common.hpp"
+
+namespace mcedm {
+
+// weight / bias gradient of the fused conv (same input description as ConvArgs)
+struct WgradArgs {
+  const float* dy;   // [B, Cout, H, W] gradient of the conv output
+  const float* xa; const float* xb; int Ca, Cb;
+  const Coef* coef; int coef_batch; int act; int resample;
+  int Hs, Ws, H, W;
+  int Cout, B;
+  float* dwp;        // scratch: wgrad_scratch_floats(Cout, Cin, taps) floats
+  float* dbp;        // set by the launcher (inside dwp)
+};
+size_t wgrad_scratch_floats(int Cout, int Cin, int taps);
+// dw [Cout][Cin][kh][kw], db [Cout] (may be null).  qkv_heads > 0: dy rows are in packed qkv order.
+int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, hipStream_t s);
+
+// backward through  act(film(group_norm(cat(xa,xb))))  followed by an optional 2x resampling
+struct GnBwdArgs {
+  const float* dact;   // gradient w.r.t. the conv input, [B, C, Hc, Wc] at the conv resolution
+  int resample;        // forward Resample between the activation and the conv
+  const float* xa; const float* xb; int Ca, Cb;
+  int Hs, Ws;          // source (= x) spatial size
+  int B, groups;
+  const Coef* coef;    // forward transform rows [B][C]
+  const float* stats;  // [B][groups][2] (mean, rstd)
+  const float* gamma;  // [C]
+  const float* film; int film_batch, film_stride;   // forward FiLM rows (scale | shift) or null
+  int act;             // forward applied SiLU
+  float* dxa; float* dxb;   // outputs [B, Ca, Hs, Ws], [B, Cb, Hs, Ws]
+  int accumulate;      // 1: add to what dxa/dxb already hold
+  const float* add;    // optional extra gradient to add, or null
+  int add_mode;        // 1: [B, C, Hs, Ws] (source resolution); 2: conv resolution, mapped back like dact
+  int add_C;           // channel count of `add` when add_mode == 2 (== C)
+  float* ab;           // out [B][C][2]: sum(dt), sum(dt * xhat) per (sample, channel)
+};
+int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s);
+
+// dgamma/dbeta (summed over the batch, overwritten) and the FiLM-row gradients from the ab table
+int launch_gn_param_grads(const float* ab, const float* gamma, const float* beta, const float* film, int film_batch,
+                          int film_stride, int B, int C, float* dgamma, float* dbeta, float* dfilm, int dfilm_stride,
+                          hipStream_t s);
+
+// tiny dense helpers for the embedding MLP backward:  C[m][n] (+)= sum_k op(A)[m][k] * op(B)[k][n]
+int launch_small_gemm(const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc,
+                      int transA, int transB, int accumulate, hipStream_t s);
+
+// attention backward: qkv, dqkv in packed [B][heads][3][64][T]; a, da [B][heads*64][T]; lse scratch [B*heads][T][2]
+int launch_attention_bwd(const float* qkv, const float* a, const float* da, float* dqkv, float* lse, int B, int heads,
+                         int T, hipStream_t s);
+
+}  // namespace mcedm

@@ -1,0 +1,388 @@
+// bwd_kernels.hip -- K10b: backward of GroupNorm+FiLM+SiLU(+2x resampling), parameter-gradient reductions,
+// the tiny dense products of the embedding MLP backward, and the attention backward (flash-style recompute).
+#include "bwd.hpp"
+#include "prof.hpp"
+
+namespace mcedm {
+
+// =========================================================================================================
+// Backward through  u = resample(act(t)),  t = (x - mean) * rstd * g_c + o_c,  g_c = gamma_c (1 + s_nc)
+// (adm_blocks.py:94-97,161,166 and the resampling of :72-77).  One workgroup per (sample, group), two passes
+// over the group's data (the second mostly L2-resident): pass 1 reduces A_c = sum dt and B_c = sum dt*xhat per
+// channel, pass 2 writes  dx = rstd * (g_c dt - mean_grp(g dt) - xhat * mean_grp(g dt xhat))  (+ extra gradient).
+// The activation gradient dt is recomputed from x in both passes and never stored.
+// =========================================================================================================
+__device__ __forceinline__ float dsilu(float t) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+  return sg * (1.0f + t * (1.0f - sg));
+}
+
+// gradient arriving at source pixel (ys, xs) through the forward resampling
+__device__ __forceinline__ float fetch_resampled(const float* plane, int mode, int ys, int xs, int Ws) {
+  if (mode == RS_NONE) return plane[(size_t)ys * Ws + xs];
+  if (mode == RS_UP) {      // forward nearest-2x: each source pixel fed a 2x2 patch of the conv input
+    const int Wc = 2 * Ws;
+    const float* q = plane + (size_t)(2 * ys) * Wc + 2 * xs;
+    return (q[0] + q[1]) + (q[Wc] + q[Wc + 1]);
+  }
+  const int Wc = Ws >> 1;   // forward 2x2 mean: each source pixel contributed a quarter
+  return 0.25f * plane[(size_t)(ys >> 1) * Wc + (xs >> 1)];
+}
+
+constexpr int GN_MAX_CPG = 32;
+
+__global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
+  const int C = a.Ca + a.Cb;
+  const int cpg = C / a.groups;
+  const int n = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
+  const int c0 = g * cpg;
+  const int HWs = a.Hs * a.Ws;
+  const int HWc = a.resample == RS_UP ? HWs * 4 : (a.resample == RS_DOWN ? HWs / 4 : HWs);
+  const float mean = a.stats[((size_t)n * a.groups + g) * 2], rstd = a.stats[((size_t)n * a.groups + g) * 2 + 1];
+  const int tid = threadIdx.x;
+  __shared__ double red[2][4];
+  __shared__ float sA[GN_MAX_CPG], sB[GN_MAX_CPG], sM[2];
+
+  for (int cl = 0; cl < cpg; ++cl) {
+    const int c = c0 + cl;
+    const float* x = (c < a.Ca) ? a.xa + ((size_t)n * a.Ca + c) * HWs : a.xb + ((size_t)n * a.Cb + (c - a.Ca)) * HWs;
+    const float* dpl = a.dact + ((size_t)n * C + c) * HWc;
+    const Coef cf = a.coef[(size_t)n * C + c];
+    float pa = 0.f, pb = 0.f;
+    for (int p = tid; p < HWs; p += 256) {
+      const int ys = p / a.Ws, xs = p - ys * a.Ws;
+      const float xv = x[p];
+      float dt = fetch_resampled(dpl, a.resample, ys, xs, a.Ws);
+      if (a.act) dt *= dsilu((xv - cf.mean) * cf.scale + cf.offset);
+      pa += dt;
+      pb += dt * ((xv - mean) * rstd);
+    }
+    double da = pa, db = pb;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { da += __shfl_xor(da, off); db += __shfl_xor(db, off); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = da; red[1][tid >> 6] = db; }
+    __syncthreads();
+    if (tid == 0) {
+      const float A = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+      const float Bs = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+      sA[cl] = A; sB[cl] = Bs;
+      a.ab[((size_t)n * C + c) * 2] = A;
+      a.ab[((size_t)n * C + c) * 2 + 1] = Bs;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double m1 = 0, m2 = 0;
+    for (int cl = 0; cl < cpg; ++cl) {
+      const int c = c0 + cl;
+      float gc = a.gamma[c];
+      if (a.film) gc *= 1.0f + a.film[(size_t)(a.film_batch ? n : 0) * a.film_stride + c];
+      m1 += (double)gc * sA[cl];
+      m2 += (double)gc * sB[cl];
+    }
+    const double N = (double)cpg * HWs;
+    sM[0] = (float)(m1 / N); sM[1] = (float)(m2 / N);
+  }
+  __syncthreads();
+  const float m1 = sM[0], m2 = sM[1];
+  for (int cl = 0; cl < cpg; ++cl) {
+    const int c = c0 + cl;
+    const bool in_a = c < a.Ca;
+    const size_t xo = in_a ? ((size_t)n * a.Ca + c) * HWs : ((size_t)n * a.Cb + (c - a.Ca)) * HWs;
+    const float* x = (in_a ? a.xa : a.xb) + xo;
+    float* dx = (in_a ? a.dxa : a.dxb) + xo;
+    const float* dpl = a.dact + ((size_t)n * C + c) * HWc;
+    const float* addp = a.add ? a.add + ((size_t)n * C + c) * (a.add_mode == 2 ? HWc : HWs) : nullptr;
+    const Coef cf = a.coef[(size_t)n * C + c];
+    for (int p = tid; p < HWs; p += 256) {
+      const int ys = p / a.Ws, xs = p - ys * a.Ws;
+      const float xv = x[p];
+      float dt = fetch_resampled(dpl, a.resample, ys, xs, a.Ws);
+      if (a.act) dt *= dsilu((xv - cf.mean) * cf.scale + cf.offset);
+      const float xh = (xv - mean) * rstd;
+      float v = cf.scale * dt - rstd * (m1 + xh * m2);      // cf.scale == rstd * g_c
+      if (addp) v += (a.add_mode == 2) ? fetch_resampled(addp, a.resample, ys, xs, a.Ws) : addp[p];
+      if (a.accumulate) v += dx[p];
+      dx[p] = v;
+    }
+  }
+}
+
+int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
+  const int C = a.Ca + a.Cb;
+  MCEDM_REQUIRE(a.groups > 0 && C % a.groups == 0 && C / a.groups <= GN_MAX_CPG, "gn_bwd: bad groups (C=%d groups=%d)", C, a.groups);
+  MCEDM_REQUIRE(a.Cb == 0 || a.Ca % (C / a.groups) == 0, "gn_bwd: a group straddles the concat boundary");
+  MCEDM_REQUIRE(a.dact && a.xa && a.coef && a.stats && a.gamma && a.dxa && a.ab && (a.Cb == 0 || (a.xb && a.dxb)), "gn_bwd: null pointer");
+  MCEDM_REQUIRE(a.resample != RS_DOWN || (a.Hs % 2 == 0 && a.Ws % 2 == 0), "gn_bwd: odd source size for a 2x2 mean");
+  ProfScope ps("gn_bwd_kernel", 20.0 * a.B * (double)C * a.Hs * a.Ws, 4.0 * 3 * a.B * (double)C * a.Hs * a.Ws, s);
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(a.B * a.groups), dim3(256), 0, s, a);
+  MCEDM_LAUNCH_CHECK("gn_bwd_kernel");
+  return MCEDM_OK;
+}
+
+// dgamma_c = sum_n (1+s_nc) B_nc ; dbeta_c = sum_n (1+s_nc) A_nc ;
+// d scale_nc = gamma_c B_nc + beta_c A_nc ; d shift_nc = A_nc          (t = xhat*gamma*(1+s) + beta*(1+s) + shift)
+__global__ void gn_param_grads_kernel(const float* __restrict__ ab, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ film, int film_batch,
+                                      int film_stride, int B, int C, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, float* __restrict__ dfilm, int dfilm_stride) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float gm = gamma[c], bt = beta[c];
+  double dg = 0, db = 0;
+  float ds0 = 0.f, dh0 = 0.f;
+  for (int n = 0; n < B; ++n) {
+    const float A = ab[((size_t)n * C + c) * 2], Bs = ab[((size_t)n * C + c) * 2 + 1];
+    float sc = 1.f;
+    if (film) sc += film[(size_t)(film_batch ? n : 0) * film_stride + c];
+    dg += (double)sc * Bs;
+    db += (double)sc * A;
+    if (dfilm) {
+      const float dsc = gm * Bs + bt * A;
+      if (film_batch) {
+        dfilm[(size_t)n * dfilm_stride + c] = dsc;
+        dfilm[(size_t)n * dfilm_stride + C + c] = A;
+      } else {
+        ds0 += dsc; dh0 += A;
+      }
+    }
+  }
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)db;
+  if (dfilm && !film_batch) { dfilm[c] = ds0; dfilm[C + c] = dh0; }
+}
+
+int launch_gn_param_grads(const float* ab, const float* gamma, const float* beta, const float* film, int film_batch,
+                          int film_stride, int B, int C, float* dgamma, float* dbeta, float* dfilm, int dfilm_stride,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(gn_param_grads_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, s, ab, gamma, beta, film, film_batch,
+                     film_stride, B, C, dgamma, dbeta, dfilm, dfilm_stride);
+  MCEDM_LAUNCH_CHECK("gn_param_grads_kernel");
+  return MCEDM_OK;
+}
+
+// C[m][n] (+)= sum_k opA(m,k) * opB(k,n); one thread per output element (embedding-MLP sized problems only)
+__global__ void small_gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm, int M,
+                                  int N, int K, int lda, int ldb, int ldc, int tA, int tB, int acc) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float av = tA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+    const float bv = tB ? Bm[(size_t)n * ldb + k] : Bm[(size_t)k * ldb + n];
+    s = fmaf(av, bv, s);
+  }
+  float* o = Cm + (size_t)m * ldc + n;
+  *o = acc ? *o + s : s;
+}
+
+int launch_small_gemm(const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc,
+                      int transA, int transB, int accumulate, hipStream_t s) {
+  const size_t total = (size_t)M * N;
+  hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, Bm, Cm, M, N, K, lda,
+                     ldb, ldc, transA, transB, accumulate);
+  MCEDM_LAUNCH_CHECK("small_gemm_kernel");
+  return MCEDM_OK;
+}
+
+// =========================================================================================================
+// Attention backward (adm_blocks.py:111-118 + autograd of the einsum at :178), recomputing the probabilities
+// from q, k and the per-query log-sum-exp instead of storing the [T x T] weights.
+//   P = softmax_k(q.k/8); a = P v;  dv = P^T da;  dP = da^T v;  dS = P o (dP - delta), delta_q = sum_c da a;
+//   dq = dS k / 8;  dk = dS^T q / 8
+// Three single-wave kernels per 32-token tile, all on fp32 MFMA with operands read straight from global memory:
+//   (1) lse_q, delta_q          (2) dq (query on the lanes)          (3) dk, dv (key on the lanes)
+// =========================================================================================================
+#define MCEDM_KEY_OF(r, h) ((r & 3) + 8 * (r >> 2) + 4 * (h))
+
+__global__ __launch_bounds__(64) void attn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ a,
+                                                            const float* __restrict__ da, float* __restrict__ lse, int T) {
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32;
+  const size_t bh = blockIdx.y;
+  const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
+  const int q = q0 + l31, qc = q < T ? q : T - 1;
+  float qreg[32];
+  float delta = 0.f;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const size_t o = (size_t)(2 * s + h) * T + qc;
+    qreg[s] = Q[o] * 0.125f;
+    delta += da[bh * 64 * (size_t)T + o] * a[bh * 64 * (size_t)T + o];
+  }
+  delta += __shfl_xor(delta, 32);
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    const int kk = k0 + l31, kc = kk < T ? kk : T - 1;
+    f32x16 sc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 32; ++st)
+      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(K[(size_t)(2 * st + h) * T + kc], qreg[st], sc, 0, 0, 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (k0 + MCEDM_KEY_OF(r, h) >= T) sc[r] = -INFINITY;
+      mx = fmaxf(mx, sc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs += expf(sc[r] - mn);
+    rs += __shfl_xor(rs, 32);
+    l = l * expf(m - mn) + rs;
+    m = mn;
+  }
+  if (q < T && h == 0) {
+    lse[(bh * T + q) * 2] = m + logf(l);
+    lse[(bh * T + q) * 2 + 1] = delta;
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
+                                                         const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32;
+  const size_t bh = blockIdx.y;
+  const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
+  const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
+  const float* dA = da + bh * 64 * (size_t)T;
+  const int q = q0 + l31, qc = q < T ? q : T - 1;
+  float qreg[32], dareg[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    qreg[s] = Q[(size_t)(2 * s + h) * T + qc] * 0.125f;
+    dareg[s] = dA[(size_t)(2 * s + h) * T + qc];
+  }
+  const float L = lse[(bh * T + qc) * 2], delta = lse[(bh * T + qc) * 2 + 1];
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    const int kk = k0 + l31, kc = kk < T ? kk : T - 1;
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(K[(size_t)(2 * st + h) * T + kc], qreg[st], sc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(size_t)(2 * st + h) * T + kc], dareg[st], dp, 0, 0, 0);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = k0 + MCEDM_KEY_OF(r, h) < T;
+      const float pv = ok ? expf(sc[r] - L) : 0.f;
+      ds[r] = pv * (dp[r] - delta);
+    }
+    // dq[c][q] += sum_key K[c][key] * dS[key][q]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* krow = K + (size_t)(32 * i + l31) * T;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + MCEDM_KEY_OF(r, h);
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[key < T ? key : T - 1], ds[r], o[i], 0, 0, 0);
+      }
+    }
+  }
+  if (q < T) {
+    float* dQ = dqkv + (bh * 3 + 0) * 64 * (size_t)T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dQ[(size_t)(32 * i + MCEDM_KEY_OF(r, h)) * T + q] = o[i][r] * 0.125f;
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
+                                                          const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int k0 = blockIdx.x * 32;
+  const size_t bh = blockIdx.y;
+  const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
+  const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
+  const float* dA = da + bh * 64 * (size_t)T;
+  const int key = k0 + l31, kc = key < T ? key : T - 1;
+  float kreg[32], vreg[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    kreg[s] = K[(size_t)(2 * s + h) * T + kc];
+    vreg[s] = V[(size_t)(2 * s + h) * T + kc];
+  }
+  f32x16 ok[2], ov[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ok[i][r] = 0.f; ov[i][r] = 0.f; }
+  for (int q0 = 0; q0 < T; q0 += 32) {
+    const int qq = q0 + l31, qc = qq < T ? qq : T - 1;
+    // S[q][k] and dP[q][k]: rows = queries (registers), column = this lane's key
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(Q[(size_t)(2 * st + h) * T + qc] * 0.125f, kreg[st], sc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[(size_t)(2 * st + h) * T + qc], vreg[st], dp, 0, 0, 0);
+    }
+    float pr[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = q0 + MCEDM_KEY_OF(r, h);
+      const int qj = qi < T ? qi : T - 1;
+      const float L = lse[(bh * T + qj) * 2], delta = lse[(bh * T + qj) * 2 + 1];
+      pr[r] = qi < T ? expf(sc[r] - L) : 0.f;
+      ds[r] = pr[r] * (dp[r] - delta);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* darow = dA + (size_t)(32 * i + l31) * T;
+      const float* qrow = Q + (size_t)(32 * i + l31) * T;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = q0 + MCEDM_KEY_OF(r, h);
+        const int qj = qi < T ? qi : T - 1;
+        ov[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(darow[qj], pr[r], ov[i], 0, 0, 0);
+        ok[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[qj], ds[r], ok[i], 0, 0, 0);
+      }
+    }
+  }
+  if (key < T) {
+    float* dK = dqkv + (bh * 3 + 1) * 64 * (size_t)T;
+    float* dV = dqkv + (bh * 3 + 2) * 64 * (size_t)T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const size_t c = 32 * i + MCEDM_KEY_OF(r, h);
+        dK[c * T + key] = ok[i][r] * 0.125f;
+        dV[c * T + key] = ov[i][r];
+      }
+  }
+}
+
+int launch_attention_bwd(const float* qkv, const float* a, const float* da, float* dqkv, float* lse, int B, int heads,
+                         int T, hipStream_t s) {
+  MCEDM_REQUIRE(qkv && a && da && dqkv && lse, "attention_bwd: null pointer");
+  MCEDM_REQUIRE(B > 0 && heads > 0 && T > 0 && (long long)B * heads <= 65535, "attention_bwd: bad shape");
+  const dim3 grid(ceil_div(T, 32), B * heads);
+  ProfScope ps("attention_bwd", 10.0 * B * heads * (double)T * T * 64, 4.0 * 8 * B * heads * 64.0 * T, s);
+  hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(64), 0, s, qkv, a, da, lse, T);
+  MCEDM_LAUNCH_CHECK("attn_bwd_stats_kernel");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64), 0, s, qkv, da, lse, dqkv, T);
+  MCEDM_LAUNCH_CHECK("attn_bwd_dq_kernel");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64), 0, s, qkv, da, lse, dqkv, T);
+  MCEDM_LAUNCH_CHECK("attn_bwd_dkv_kernel");
+  return MCEDM_OK;
+}
+
+}  // namespace mcedm

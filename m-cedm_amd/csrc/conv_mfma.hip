@@ -379,9 +379,16 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict_
         }
         v = w[((size_t)cs * Cin + ci) * taps + tap];
       } else {
-        // dgrad: out channel of this GEMM = conv input channel; src w is [Cin_gemm = conv Cout][.. ]
-        // here (Cout, Cin) are the GEMM's: w is stored [Cin][Cout][taps]; taps mirrored
-        v = w[((size_t)ci * Cout + co) * taps + (taps - 1 - tap)];
+        // dgrad: the GEMM's output channels are the conv's input channels and its K index runs over the conv's
+        // output channels; w is stored [K = Cin][Cout][taps], taps mirrored.  For the qkv conv the incoming
+        // gradient rows are in packed (head, which, c) order, so K index ci reads reference row (head, c, which).
+        int kk = ci;
+        if (qkv_heads > 0) {
+          const int per = Cin / qkv_heads, d = per / 3;
+          const int h = ci / per, rr = ci % per, which = rr / d, c = rr % d;
+          kk = h * per + c * 3 + which;
+        }
+        v = w[((size_t)kk * Cout + co) * taps + (taps - 1 - tap)];
       }
     }
     dst[i] = v;

@@ -1,5 +1,6 @@
 // ops_api.hip -- kernel-level C entry points (tests, per-kernel timing).
 #include "common.hpp"
+#include "bwd.hpp"
 
 using namespace mcedm;
 
@@ -57,4 +58,41 @@ extern "C" int mcedm_op_attention(const float* qkv, float* out, int B, int heads
 extern "C" int mcedm_op_set_conv_tile(int mt, int ph, int pw) {
   set_conv_tile_override(mt, ph, pw);
   return MCEDM_OK;
+}
+
+extern "C" size_t mcedm_op_wgrad_scratch_floats(int Cout, int Cin, int k) {
+  if (Cout <= 0 || Cin <= 0 || (k != 1 && k != 3)) return 0;
+  return wgrad_scratch_floats(Cout, Cin, k * k);
+}
+
+extern "C" int mcedm_op_conv_wgrad(const float* dy, const float* xa, const float* xb, int Ca, int Cb,
+                                   const mcedm_coef* coef, int coef_batch, int act, int resample, int Hs, int Ws, int H,
+                                   int W, int Cout, int B, int k, int qkv_heads, float* scratch, float* dw, float* db,
+                                   void* stream) {
+  MCEDM_REQUIRE(k == 1 || k == 3, "op_conv_wgrad: k must be 1 or 3");
+  MCEDM_REQUIRE(dy && scratch && dw, "op_conv_wgrad: null pointer");
+  WgradArgs a{dy, xa, xb, Ca, Cb, reinterpret_cast<const Coef*>(coef), coef_batch, act, resample, Hs, Ws, H, W, Cout, B,
+              scratch, nullptr};
+  return launch_wgrad(a, k * k, dw, db, qkv_heads, (hipStream_t)stream);
+}
+
+extern "C" int mcedm_op_gn_bwd(const float* dact, int resample, const float* xa, const float* xb, int Ca, int Cb, int Hs,
+                               int Ws, int B, const mcedm_coef* coef, const float* stats, const float* gamma,
+                               const float* beta, const float* film, int film_batch, int film_stride, int act,
+                               float* dxa, float* dxb, int accumulate, const float* add, int add_mode, float* ab,
+                               float* dgamma, float* dbeta, float* dfilm, int dfilm_stride, void* stream) {
+  MCEDM_REQUIRE(dact && xa && coef && stats && gamma && beta && dxa && ab && dgamma && dbeta, "op_gn_bwd: null pointer");
+  const int C = Ca + Cb;
+  MCEDM_REQUIRE(C >= 4, "op_gn_bwd: C < 4");
+  GnBwdArgs a{dact, resample, xa, xb, Ca, Cb, Hs, Ws, B, C / 4 < 32 ? C / 4 : 32, reinterpret_cast<const Coef*>(coef),
+              stats, gamma, film, film_batch, film_stride, act, dxa, dxb, accumulate, add, add_mode, C, ab};
+  int rc = launch_gn_bwd(a, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_gn_param_grads(ab, gamma, beta, film, film_batch, film_stride, B, C, dgamma, dbeta, dfilm, dfilm_stride,
+                               (hipStream_t)stream);
+}
+
+extern "C" int mcedm_op_attention_bwd(const float* qkv, const float* a, const float* da, float* dqkv, float* lse_scratch,
+                                      int B, int heads, int T, void* stream) {
+  return launch_attention_bwd(qkv, a, da, dqkv, lse_scratch, B, heads, T, (hipStream_t)stream);
 }

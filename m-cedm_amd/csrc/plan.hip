@@ -263,10 +263,9 @@ static int pack_conv(const ConvP& c, const float* const* params, float* pk, Copi
   else cp.add(params[c.b], pk + c.bias, c.cout);
   if (rc) return rc;
   if (c.wpk_dgrad != NONE) {
-    // data-gradient GEMM: output channels = conv input channels.  For the qkv conv the incoming gradient is in
-    // packed (head, which, c) row order, so its K index must be permuted the same way -> handled by the
-    // backward (it un-permutes the gradient rows when it is written); here rows are in reference order.
-    rc = launch_pack_conv(params[c.w], pk + c.wpk_dgrad, c.cin, c.cout, c.taps, 0, 1, s);
+    // data-gradient GEMM: output channels = conv input channels; for the qkv conv the K index follows the packed
+    // (head, which, c) order of the incoming gradient rows
+    rc = launch_pack_conv(params[c.w], pk + c.wpk_dgrad, c.cin, c.cout, c.taps, c.qkv_heads, 1, s);
   }
   return rc;
 }
@@ -447,10 +446,7 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
 }
 
 // header in front of the U-Net activations: EDM coefficient rows, conv_in transform, F / F_uncond
-struct Header {
-  size_t coefs4, c_noise, coef_in, F, Fu, total;
-};
-static Header header_for(const mcedm_plan& P, int B, int H, int W) {
+Header header_for(const mcedm_plan& P, int B, int H, int W) {
   Header h;
   size_t cur = 0;
   auto take = [&](size_t bytes) { size_t o = cur; cur += align_up(bytes, 256); return o; };
@@ -464,8 +460,6 @@ static Header header_for(const mcedm_plan& P, int B, int H, int W) {
   return h;
 }
 
-template <class T>
-static inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
 
 // ------------------------------------------------------------------------------------------
 // forward schedule (adm_blocks.py:364-404 and :159-181)
@@ -616,7 +610,7 @@ extern "C" int mcedm_unet_workspace_bytes(const mcedm_plan* plan, int B, int H, 
   Layout L;
   int rc = build_layout(*plan, B, H, W, training, B, &L);
   if (rc) return rc;
-  *bytes = header_for(*plan, B, H, W).total + L.total_bytes;
+  *bytes = header_for(*plan, B, H, W).total + L.total_bytes + (training ? backward_scratch_bytes(*plan, L, B, H, W) : 0);
   return MCEDM_OK;
 }
 
@@ -766,9 +760,3 @@ extern "C" int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, con
   return MCEDM_OK;
 }
 
-extern "C" int mcedm_edm_denoise_backward(const mcedm_plan*, const void*, const float* const*, const float*, const float*,
-                                          int, const float*, const float*, float* const*, void*, size_t, int, int, int,
-                                          double, void*) {
-  set_error("edm_denoise_backward: not implemented in this build");
-  return MCEDM_ERR_UNSUPPORTED;
-}

@@ -85,4 +85,16 @@ struct mcedm_plan {
 
 namespace mcedm {
 int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_noise, Layout* out);
+
+// header in front of the U-Net activations: EDM coefficient rows, conv_in transform, F / F_uncond
+struct Header {
+  size_t coefs4, c_noise, coef_in, F, Fu, total;
+};
+Header header_for(const mcedm_plan& P, int B, int H, int W);
+
+template <class T>
+static inline T* at(void* ws, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + off); }
+
+// bytes the backward needs behind the training-mode activations (gradient buffers + scratch)
+size_t backward_scratch_bytes(const mcedm_plan& P, const Layout& L, int B, int H, int W);
 }

@@ -230,6 +230,17 @@ class Plan:
                                           _stream()), "edm_denoise")
         return (D, F) if want_F else D
 
+    def denoise_backward(self, packed, params: Dict[str, torch.Tensor], x, sigma, cond, dD, grads: Sequence[torch.Tensor],
+                         ws: Workspace, sigma_data: float = 1.0) -> None:
+        """Backward of denoise(..., training=True) on the SAME workspace: grads[i] <- dLoss/dparam_i (overwritten)."""
+        B, _, H, W = x.shape
+        buf = ws.get(self.workspace_bytes(B, H, W, True), x.device)
+        parr = (C.c_void_p * len(self.param_names))(*[_ptr(params[n].detach()) for n in self.param_names])
+        garr = (C.c_void_p * len(self.param_names))(*[_ptr(g) for g in grads])
+        check(self._lib.mcedm_edm_denoise_backward(self._h, packed.data_ptr(), parr, _ptr(x), _ptr(sigma), sigma.numel(),
+                                                   _ptr(cond), _ptr(dD), garr, buf.data_ptr(), buf.numel(), B, H, W,
+                                                   float(sigma_data), _stream()), "edm_denoise_backward")
+
     def sample(self, packed, sd: SamplerDesc, cond, mask, init_noise, step_noise=None, return_last: bool = True,
                ws: Optional[Workspace] = None) -> torch.Tensor:
         B, _, H, W = init_noise.shape
@@ -294,14 +305,23 @@ def _bind_ops():
     lib.mcedm_op_conv.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32,
                                   i32, i32, vp]
     lib.mcedm_op_attention.argtypes = [vp, vp, i32, i32, i32, vp]
-    for n in ("mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv", "mcedm_op_attention"):
+    lib.mcedm_op_wgrad_scratch_floats.argtypes = [i32, i32, i32]
+    lib.mcedm_op_wgrad_scratch_floats.restype = sz
+    lib.mcedm_op_conv_wgrad.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                        vp, vp, vp, vp]
+    lib.mcedm_op_gn_bwd.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp,
+                                    i32, vp, i32, vp, vp, vp, vp, i32, vp]
+    lib.mcedm_op_attention_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    for n in ("mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv", "mcedm_op_attention", "mcedm_op_conv_wgrad",
+              "mcedm_op_gn_bwd", "mcedm_op_attention_bwd"):
         getattr(lib, n).restype = C.c_int
     _OPS_BOUND = True
     return lib
 
 
 OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv",
-              "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report"]
+              "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report",
+              "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd"]
 
 
 def prof_enable(on: bool) -> None:
@@ -373,3 +393,47 @@ def op_attention(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     out = torch.empty((B, C3 // 3, H, W), dtype=torch.float32, device=qkv.device)
     check(lib.mcedm_op_attention(_ptr(qkv), _ptr(out), B, heads, H * W, _stream()), "op_attention")
     return out
+
+
+def op_conv_wgrad(dy, xa, xb, k, coef=None, coef_batch=1, act=0, resample=RS_NONE, qkv_heads=0):
+    """-> (dw [Cout, Cin, k, k], db [Cout])"""
+    lib = _bind_ops()
+    B, Cout, H, W = dy.shape
+    Ca, Hs, Ws = xa.shape[1], xa.shape[2], xa.shape[3]
+    Cb = xb.shape[1] if xb is not None else 0
+    Cin = Ca + Cb
+    scratch = torch.empty(lib.mcedm_op_wgrad_scratch_floats(Cout, Cin, k), dtype=torch.float32, device=dy.device)
+    dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dy.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+    check(lib.mcedm_op_conv_wgrad(_ptr(dy), _ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, resample, Hs, Ws, H,
+                                  W, Cout, B, k, qkv_heads, _ptr(scratch), _ptr(dw), _ptr(db), _stream()), "op_conv_wgrad")
+    return dw, db
+
+
+def op_gn_bwd(dact, xa, xb, coef, stats, gamma, beta, film=None, film_batch=0, film_stride=0, act=1,
+              resample=RS_NONE, add=None, add_mode=0, dx_init=None):
+    """-> (dxa, dxb, dgamma, dbeta, dfilm or None); dx_init (tuple) makes the call accumulate into copies of it."""
+    lib = _bind_ops()
+    B, Ca, Hs, Ws = xa.shape
+    Cb = xb.shape[1] if xb is not None else 0
+    Ct = Ca + Cb
+    dxa = dx_init[0].clone() if dx_init else torch.empty_like(xa)
+    dxb = (dx_init[1].clone() if dx_init else torch.empty_like(xb)) if xb is not None else None
+    ab = torch.empty((B, Ct, 2), dtype=torch.float32, device=xa.device)
+    dg, dbt = torch.empty(Ct, device=xa.device), torch.empty(Ct, device=xa.device)
+    dfilm = torch.zeros((B if film_batch else 1, 2 * Ct), dtype=torch.float32, device=xa.device) if film is not None else None
+    check(lib.mcedm_op_gn_bwd(_ptr(dact), resample, _ptr(xa), _ptr(xb), Ca, Cb, Hs, Ws, B, _ptr(coef), _ptr(stats),
+                              _ptr(gamma), _ptr(beta), _ptr(film), film_batch, film_stride, act, _ptr(dxa), _ptr(dxb),
+                              int(dx_init is not None), _ptr(add), add_mode, _ptr(ab), _ptr(dg), _ptr(dbt), _ptr(dfilm),
+                              2 * Ct, _stream()), "op_gn_bwd")
+    return dxa, dxb, dg, dbt, dfilm
+
+
+def op_attention_bwd(qkv, a, da, heads):
+    lib = _bind_ops()
+    B, C3, H, W = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    lse = torch.empty(B * heads * H * W * 2, dtype=torch.float32, device=qkv.device)
+    check(lib.mcedm_op_attention_bwd(_ptr(qkv), _ptr(a), _ptr(da), _ptr(dqkv), _ptr(lse), B, heads, H * W, _stream()),
+          "op_attention_bwd")
+    return dqkv

@@ -1,0 +1,237 @@
+"""GPU parity of the backward path (through the C ABI): weight/data gradients of the fused conv, GroupNorm/FiLM/SiLU
+backward, attention backward, and the complete training step (loss + every parameter gradient) against autograd
+through the oracle and against the golden vectors the reference produced (tests/golden/training_P.npz).
+
+Tolerance: rtol 1e-4 with atol = 1e-5 x max|ref| per tensor (gradients span several orders of magnitude).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fixtures as fx
+from oracle import mcedm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd import lib as L
+    assert torch.cuda.is_available()
+    L.load()
+    return L
+
+
+def dev(t):
+    return t.detach().contiguous().cuda()
+
+
+def close(got, ref, rtol=1e-4, rel_atol=1e-5, what=""):
+    got = got.detach().cpu().double()
+    ref = torch.as_tensor(ref).detach().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs()
+    lim = rel_atol * ref.abs().max() + rtol * ref.abs()
+    bad = err > lim
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {err.max():.3e} (max ref {ref.abs().max():.3e})"
+
+
+def apply_coef(x, coef, act):
+    y = (x - coef[:, :, 0, None, None]) * coef[:, :, 1, None, None] + coef[:, :, 2, None, None]
+    return F.silu(y) if act else y
+
+
+def rand_coef(tag, B, C):
+    return torch.stack([fx.randn(tag + "/mean", B, C) * 0.3, 1 + 0.3 * fx.randn(tag + "/scale", B, C),
+                        0.2 * fx.randn(tag + "/off", B, C), torch.zeros(B, C)], dim=-1)
+
+
+CONV_SHAPES = [
+    # (B, Ca, Cb, Cout, H, W, k, resample, act)
+    (2, 64, 0, 64, 32, 32, 3, 0, 1), (2, 72, 64, 128, 20, 24, 3, 0, 1), (2, 64, 0, 64, 16, 16, 3, 1, 1),
+    (2, 64, 0, 64, 16, 16, 3, 2, 1), (3, 2, 2, 64, 32, 32, 3, 0, 0), (2, 64, 0, 2, 32, 32, 3, 0, 1),
+    (2, 128, 0, 64, 16, 16, 1, 0, 0), (1, 8, 0, 8, 4, 4, 3, 0, 1), (2, 40, 0, 24, 8, 8, 1, 0, 1),
+    (4, 128, 0, 128, 64, 64, 3, 0, 1),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_wgrad_and_dgrad(lib, shape):
+    B, Ca, Cb, Cout, H, W, k, rs, act = shape
+    tag = "t/bwd/conv/" + "_".join(map(str, shape))
+    Cin = Ca + Cb
+    Hs, Ws = (H // 2, W // 2) if rs == 1 else ((H * 2, W * 2) if rs == 2 else (H, W))
+    xa = fx.randn(tag + "/xa", B, Ca, Hs, Ws)
+    xb = fx.randn(tag + "/xb", B, Cb, Hs, Ws) if Cb else None
+    w = fx.param(tag, "conv.weight", (Cout, Cin, k, k)).requires_grad_(True)
+    b = fx.param(tag, "conv.bias", (Cout,)).requires_grad_(True)
+    coef = rand_coef(tag, B, Cin)
+    dy = fx.randn(tag + "/dy", B, Cout, H, W)
+    x = torch.cat([xa, xb], 1) if Cb else xa
+    u = apply_coef(x, coef, act)
+    if rs == 1:
+        u = orc.resample_up(u)
+    elif rs == 2:
+        u = orc.resample_down(u)
+    u = u.detach().requires_grad_(True)
+    y = F.conv2d(u, w, b, padding=k // 2)
+    gu, gw, gb = torch.autograd.grad(y, (u, w, b), dy)
+    dw, db = lib.op_conv_wgrad(dev(dy), dev(xa), dev(xb) if Cb else None, k, coef=dev(coef), act=act, resample=rs)
+    close(dw, gw, what="dW")
+    close(db, gb, what="db")
+    wpk, _ = lib.op_pack_conv(dev(w), None, dgrad=True)
+    du = lib.op_conv(dev(dy), None, wpk, None, Cin, k)
+    close(du, gu, what="d(conv input)")
+
+
+@pytest.mark.parametrize("case", [
+    # (B, Ca, Cb, Hs, Ws, resample, act, film, add_mode, accumulate)
+    (2, 64, 0, 8, 8, 0, 1, True, 0, False), (2, 64, 64, 8, 12, 0, 1, False, 1, False), (2, 64, 0, 8, 8, 1, 1, False, 2, True),
+    (2, 64, 0, 16, 16, 2, 1, False, 2, False), (3, 128, 0, 6, 6, 0, 0, False, 1, True), (2, 256, 0, 4, 4, 0, 1, True, 0, False),
+])
+def test_gn_film_silu_backward(lib, case):
+    B, Ca, Cb, Hs, Ws, rs, act, use_film, add_mode, accumulate = case
+    tag = "t/bwd/gn/" + "_".join(map(str, case))
+    C = Ca + Cb
+    Hc, Wc = (Hs * 2, Ws * 2) if rs == 1 else ((Hs // 2, Ws // 2) if rs == 2 else (Hs, Ws))
+    xa = (fx.randn(tag + "/xa", B, Ca, Hs, Ws) * 1.3 + 0.4).requires_grad_(True)
+    xb = (fx.randn(tag + "/xb", B, Cb, Hs, Ws) * 0.7).requires_grad_(True) if Cb else None
+    gamma = fx.param(tag, "norm.weight", (C,)).requires_grad_(True)
+    beta = fx.param(tag, "norm.bias", (C,)).requires_grad_(True)
+    film = (fx.randn(tag + "/film", B, 2 * C) * 0.3).requires_grad_(True) if use_film else None
+    dact = fx.randn(tag + "/dact", B, C, Hc, Wc)
+    add = None
+    if add_mode == 1:
+        add = fx.randn(tag + "/add", B, C, Hs, Ws)
+    elif add_mode == 2:
+        add = fx.randn(tag + "/add", B, C, Hc, Wc)
+    init = (fx.randn(tag + "/ia", B, Ca, Hs, Ws), fx.randn(tag + "/ib", B, Cb, Hs, Ws) if Cb else None) if accumulate else None
+    # reference
+    x = torch.cat([xa, xb], 1) if Cb else xa
+    t = orc.group_norm(x, gamma, beta)
+    if use_film:
+        t = torch.addcmul(film[:, C:, None, None], t, film[:, :C, None, None] + 1)
+    u = F.silu(t) if act else t
+    res = (lambda v: orc.resample_up(v)) if rs == 1 else ((lambda v: orc.resample_down(v)) if rs == 2 else (lambda v: v))
+    loss = (res(u) * dact).sum()
+    if add_mode == 1:
+        loss = loss + (x * add).sum()
+    elif add_mode == 2:
+        loss = loss + (res(x) * add).sum()
+    ins = [xa, gamma, beta] + ([xb] if Cb else []) + ([film] if use_film else [])
+    gr = torch.autograd.grad(loss, ins)
+    gxa, gg, gb = gr[0], gr[1], gr[2]
+    gxb = gr[3] if Cb else None
+    gfilm = gr[-1] if use_film else None
+    if accumulate:
+        gxa = gxa + init[0]
+        gxb = gxb + init[1] if Cb else None
+    # HIP
+    coef, stats = lib.op_gn_coef(dev(xa), dev(xb) if Cb else None, dev(gamma), dev(beta), film=dev(film) if use_film else None,
+                                 film_batch=1, film_stride=2 * C, want_stats=True)
+    dxa, dxb, dg, dbt, dfilm = lib.op_gn_bwd(dev(dact), dev(xa), dev(xb) if Cb else None, coef, stats, dev(gamma), dev(beta),
+                                             film=dev(film) if use_film else None, film_batch=1, film_stride=2 * C, act=act,
+                                             resample=rs, add=dev(add) if add is not None else None, add_mode=add_mode,
+                                             dx_init=(dev(init[0]), dev(init[1]) if Cb else None) if accumulate else None)
+    close(dxa, gxa, what="dxa")
+    if Cb:
+        close(dxb, gxb, what="dxb")
+    close(dg, gg, what="dgamma")
+    close(dbt, gb, what="dbeta")
+    if use_film:
+        close(dfilm, gfilm, what="dfilm")
+
+
+def packed_qkv(qkv, heads):
+    B, C3, H, W = qkv.shape
+    d = C3 // heads // 3
+    return qkv.reshape(B, heads, d, 3, H, W).permute(0, 1, 3, 2, 4, 5).reshape(B, C3, H, W).contiguous()
+
+
+def unpacked_qkv(p, heads):
+    B, C3, H, W = p.shape
+    d = C3 // heads // 3
+    return p.reshape(B, heads, 3, d, H, W).permute(0, 1, 3, 2, 4, 5).reshape(B, C3, H, W).contiguous()
+
+
+@pytest.mark.parametrize("T", list(fx.ATTN_CASES))
+def test_attention_backward_golden(lib, golden, T):
+    g = golden("ops.npz")
+    B, hw = fx.ATTN_CASES[T]
+    qkv = fx.randn(f"ops/attn{T}/qkv", B, 384, *hw)
+    da = fx.randn(f"ops/attn{T}/da", B, 128, *hw)
+    pq = dev(packed_qkv(qkv, 2))
+    a = lib.op_attention(pq, 2)
+    dqkv = lib.op_attention_bwd(pq, a, dev(da), 2)
+    close(unpacked_qkv(dqkv.cpu(), 2), g[f"attn{T}_dqkv"], what=f"dqkv T={T}")
+
+
+@pytest.mark.parametrize("B,heads,hw", [(1, 1, (6, 6)), (2, 1, (32, 32)), (1, 2, (2, 2))])
+def test_attention_backward_vs_oracle(lib, B, heads, hw):
+    qkv = fx.randn(f"t/bwd/attn/{B}{heads}{hw}", B, heads * 192, *hw).requires_grad_(True)
+    da = fx.randn(f"t/bwd/attn/da/{B}{heads}{hw}", B, heads * 64, *hw)
+    a = orc.attention(qkv, heads)
+    (ref,) = torch.autograd.grad(a, qkv, da)
+    pq = dev(packed_qkv(qkv.detach(), heads))
+    dqkv = lib.op_attention_bwd(pq, lib.op_attention(pq, heads), dev(da), heads)
+    close(unpacked_qkv(dqkv.cpu(), heads), ref, what="dqkv")
+
+
+def make_plan(L, cfg):
+    return L.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks,
+                  cfg.attn_resolutions, cfg.resolution)
+
+
+def run_training_step(L, cfg, P, xc, cond_in, mc, noise, rnd_normal):
+    plan = make_plan(L, cfg)
+    params = {k: dev(v) for k, v in P.items()}
+    packed = plan.pack(params)
+    ws = L.Workspace()
+    x_noise, sigma = L.edm_noise_inputs(dev(xc), dev(mc), dev(noise), dev(rnd_normal.flatten()))
+    D = plan.denoise(packed, x_noise, sigma, cond=dev(cond_in), ws=ws, training=True)
+    loss, dD = L.edm_loss(D, dev(xc), dev(mc), sigma)
+    grads = [torch.full_like(params[n], float("nan")) for n in plan.param_names]
+    plan.denoise_backward(packed, params, x_noise, sigma, dev(cond_in), dD, grads, ws)
+    return plan, loss, dict(zip(plan.param_names, grads))
+
+
+def test_training_step_golden(lib, golden):
+    """training_step loss and gradients (config P: B=4, 32x32, ch=64) vs the reference's own numbers."""
+    g = golden("training_P.npz")
+    P = orc.make_params(fx.CFG_P, int(g["seed"]))
+    h, u, mask, cond_noise, noise, rnd_normal = fx.training_inputs()
+    xc, cond_in, mc = fx.training_nchw(h, u, mask, cond_noise)
+    plan, loss, grads = run_training_step(lib, fx.CFG_P, P, xc, cond_in, mc, noise, rnd_normal)
+    close(loss, torch.as_tensor(g["loss"]).reshape(1), what="loss")
+    for n in fx.TRAIN_GRAD_NAMES:
+        close(grads[n], g[f"grad::{n}"], rtol=1e-3, rel_atol=1e-4, what=f"grad {n}")
+    sq = sum(float((v.double() ** 2).sum()) for v in grads.values())
+    assert abs(sq - float(g["grad_sqnorm_total"])) <= 1e-3 * float(g["grad_sqnorm_total"])
+    each = np.array([float((grads[n].double() ** 2).sum()) for n in plan.param_names])
+    np.testing.assert_allclose(each, g["grad_sqnorm_each"], rtol=5e-3)
+
+
+@pytest.mark.parametrize("cfg_name", ["P", "W"])
+def test_training_step_all_grads_vs_oracle(lib, cfg_name):
+    """every parameter gradient vs autograd through the oracle (P: ch=64 3 levels; W: ch=128, 4 levels, 2-head attention)"""
+    cfg = fx.CFG_P if cfg_name == "P" else fx.CFG_W
+    B, H, W = (2, 32, 32) if cfg_name == "P" else (2, 16, 16)
+    tag = f"t/bwd/train/{cfg_name}"
+    P = orc.make_params(cfg, 3)
+    xc = fx.randn(tag + "/x", B, 2, H, W)
+    mc = torch.zeros(B, 2, H, W)
+    mc[0, 1] = 1
+    mc[1, 0] = 1
+    mc[1, 1, : H // 2] = 1
+    cond_in = xc * (1 - mc) + fx.randn(tag + "/cn", B, 2, H, W) * mc
+    noise = fx.randn(tag + "/noise", B, 2, H, W)
+    rnd_normal = fx.randn(tag + "/rnd", B, 1, 1, 1)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref_loss = orc.training_loss(Pg, cfg, xc, cond_in, mc, noise, rnd_normal)
+    ref_loss.backward()
+    plan, loss, grads = run_training_step(lib, cfg, P, xc, cond_in, mc, noise, rnd_normal)
+    close(loss, ref_loss.detach().reshape(1), what="loss")
+    for n in plan.param_names:
+        close(grads[n], Pg[n].grad, rtol=1e-3, rel_atol=1e-4, what=f"grad {n}")
