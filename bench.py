@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--workload", default="s128", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="states per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the (untimed) training-step measurement")
     ap.add_argument("--cpu-states", type=int, default=0, help="states in the CPU baseline sample (default: auto)")
     args = ap.parse_args()
 
@@ -146,6 +147,45 @@ def main():
     torch.cuda.synchronize()
     fwd_ms = e0.elapsed_time(e1) / nf
 
+    # one data-parallel training step (models/mcedm.py:254-281 + clip/Adam/EMA), outside the timed region:
+    # noise -> denoise(training) -> loss -> backward -> gradient all-reduce -> fused clip+Adam+EMA
+    train_ms = None
+    if not args.no_train:
+        from mcedm_amd.train import allreduce_mean_, views_like
+        names = plan.param_names
+        flat_p = torch.cat([params[n].reshape(-1) for n in names])
+        pviews = dict(zip(names, views_like(flat_p, [params[n] for n in names])))
+        flat_g, flat_m, flat_v, flat_e = (torch.zeros_like(flat_p) for _ in range(4))
+        flat_e.copy_(flat_p)
+        gviews = views_like(flat_g, [params[n] for n in names])
+        sq = torch.zeros(1, dtype=torch.float64, device=device)
+        gen = torch.Generator(device="cpu").manual_seed(7 + rank)
+        xs = torch.randn(B, 2, H, W, generator=gen).to(device)
+        nz = torch.randn(B, 2, H, W, generator=gen).to(device)
+        rn = torch.randn(B, generator=gen).to(device)
+        tws = lib.Workspace()
+
+        def train_step(k):
+            pk = plan.pack(pviews, packed)
+            x_noise, sigma = lib.edm_noise_inputs(xs, mask, nz, rn)
+            D = plan.denoise(pk, x_noise, sigma, cond=cond, ws=tws, training=True)
+            loss, dD = lib.edm_loss(D, xs, mask, sigma)
+            plan.denoise_backward(pk, pviews, x_noise, sigma, cond, dD, gviews, tws)
+            allreduce_mean_(flat_g, average=False)
+            lib.sqnorm(flat_g, sq)
+            lib.adam_ema_step(flat_p, flat_g, flat_m, flat_v, flat_e, k, sqnorm_t=sq, grad_scale=1.0 / world)
+            return loss
+
+        train_step(1)
+        barrier()
+        t1 = time.perf_counter()
+        nt = 3
+        for k in range(nt):
+            loss = train_step(2 + k)
+        barrier()
+        train_ms = (time.perf_counter() - t1) / nt * 1e3
+        assert torch.isfinite(loss).all()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -175,7 +215,8 @@ def main():
         "config": {"workload": wl["name"], "states_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
                    "sampler": "EDM Heun, 18 steps, 35 NFE/state, S_churn=0, w=0, fp64 state / fp32 net",
                    "parallelism": f"batch-sharded x{world}, no data-path collective"},
-        "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B,
+        "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B, "train_step_ms": train_ms,
+        "train_samples_per_sec": (B * world / (train_ms * 1e-3)) if train_ms else None,
         "roofline": roofline, "kernels": kernels[:8],
     }
     if not args.no_cpu_baseline:
