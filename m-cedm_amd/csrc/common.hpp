@@ -72,9 +72,14 @@ struct ConvArgs {
   float* out;        // [B, Cout, H, W]
   int Cout;
   int B;
+  float* gsum;       // optional [B][tiles][ceil(Cout/4)][2]: per output tile and 4-channel group, (sum, sum of squares)
+                     // of the OUTPUT written by the epilogue (no atomics); feeds the next GroupNorm without a stats
+                     // pass.  Must hold B * conv_max_tiles(H, W) * ceil(Cout/4) * 2 floats.
+  int* gsum_tiles;   // host out: tiles per sample the launcher used (row count of gsum per sample)
 };
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t stream);
+static inline int conv_max_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 7) / 8); }   // smallest pixel tile is 8x8
 void set_conv_tile_override(int mt, int ph, int pw);   // test hook; (0,0,0) restores the heuristic
 // geometry the packer must use for a given (Cout, taps): tile height over Cout and K-chunk
 int conv_mt_for(int Cout);
@@ -97,7 +102,10 @@ struct GnArgs {
   float eps;
   Coef* coef;        // out [B][C]
   float* stats;      // out [B][groups][2] (mean, rstd) or null (kept for backward)
+  const float* suma; const float* sumb;     // launch_gn_coef_from_sums: per-tile (sum, sumsq) tables of xa / xb
+  int tiles_a, tiles_b;                     // tiles per sample in those tables
 };
+int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream);
 int launch_gn_coef(const GnArgs& a, hipStream_t stream);
 
 // sigma-embedding MLP + all FiLM affine rows (K6)

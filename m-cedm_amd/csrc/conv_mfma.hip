@@ -174,9 +174,9 @@ __device__ __forceinline__ void store_weights(float* wl, const WeightRegs<C>& R,
 }
 
 // FULL: every output channel of the tile exists (m0 + MT <= Cout); RM: -1 no residual, else its Resample mode.
-template <class C, bool FULL, int RM>
+template <class C, bool FULL, int RM, bool STATS>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C::TM][C::TN], int n, int m0, int y0,
-                                              int x0, int wm, int wn, int lane) {
+                                              int x0, int wm, int wn, int lane, float* red) {
   const size_t HW = (size_t)p.H * p.W;
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) {
@@ -188,6 +188,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
       const int cc = FULL ? co : (co < p.Cout ? co : p.Cout - 1);
       bv[r] = p.bias ? p.bias[cc] : 0.f;
     }
+    float gs1[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
       const int pix = (wn * C::TN + j) * 32 + (lane & 31);
@@ -217,7 +218,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
           const int co = cbase + (r & 3) + 8 * (r >> 2);
           float v = acc[i][j][r] + bv[r];
           if (RM != -1) v += rv[r];
-          if (FULL || co < p.Cout) p.out[((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x] = v;
+          if (FULL || co < p.Cout) {
+            p.out[((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x] = v;
+            if (STATS) { gs1[r >> 2] += v; gs2[r >> 2] += v * v; }
+          }
+        }
+      }
+    }
+    if (STATS) {
+      // fused GroupNorm statistics of the output tile: lane -> 32-lane half (pixels) -> LDS slot of this wave.
+      // 4-channel group inside the MT tile: gl = 8 (wm TM + i) + 2 (r>>2) + (lane>>5).
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = gs1[q], b = gs2[q];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+        if ((lane & 31) == 0) {
+          const int gl = (wm * C::TM + i) * 8 + 2 * q + (lane >> 5);
+          red[(wn * (C::MT / 4) + gl) * 2] = a;
+          red[(wn * (C::MT / 4) + gl) * 2 + 1] = b;
         }
       }
     }
@@ -316,23 +335,49 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
     }
     __syncthreads();
   }
-  if (wave >= C::NWAVE) return;
-
   // ---- epilogue: + bias, + (resampled) residual, store NCHW.  Dispatch on wave-uniform conditions once, so
   // that inside a variant the 16 residual loads of an accumulator tile are issued back to back (one wait)
   // instead of one load -> wait -> store round trip per element.
   const bool full = (m0 + C::MT <= p.Cout);
   const int rm = p.res ? p.res_mode : -1;
-  if (full) {
-    if (rm == -1) conv_epilogue<C, true, -1>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else if (rm == RS_NONE) conv_epilogue<C, true, RS_NONE>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else if (rm == RS_UP) conv_epilogue<C, true, RS_UP>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else conv_epilogue<C, true, RS_DOWN>(p, acc, n, m0, y0, x0, wm, wn, lane);
-  } else {
-    if (rm == -1) conv_epilogue<C, false, -1>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else if (rm == RS_NONE) conv_epilogue<C, false, RS_NONE>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else if (rm == RS_UP) conv_epilogue<C, false, RS_UP>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else conv_epilogue<C, false, RS_DOWN>(p, acc, n, m0, y0, x0, wm, wn, lane);
+  float* red = xl;            // the input tile is dead after the last chunk's closing barrier
+  if (wave < C::NWAVE) {
+    if (p.gsum) {
+      if (full) {
+        if (rm == -1) conv_epilogue<C, true, -1, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+        else if (rm == RS_NONE) conv_epilogue<C, true, RS_NONE, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+        else if (rm == RS_UP) conv_epilogue<C, true, RS_UP, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+        else conv_epilogue<C, true, RS_DOWN, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      } else {
+        if (rm == -1) conv_epilogue<C, false, -1, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+        else if (rm == RS_NONE) conv_epilogue<C, false, RS_NONE, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+        else if (rm == RS_UP) conv_epilogue<C, false, RS_UP, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+        else conv_epilogue<C, false, RS_DOWN, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      }
+    } else if (full) {
+      if (rm == -1) conv_epilogue<C, true, -1, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else if (rm == RS_NONE) conv_epilogue<C, true, RS_NONE, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else if (rm == RS_UP) conv_epilogue<C, true, RS_UP, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else conv_epilogue<C, true, RS_DOWN, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+    } else {
+      if (rm == -1) conv_epilogue<C, false, -1, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else if (rm == RS_NONE) conv_epilogue<C, false, RS_NONE, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else if (rm == RS_UP) conv_epilogue<C, false, RS_UP, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else conv_epilogue<C, false, RS_DOWN, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+    }
+  }
+  if (p.gsum) {               // wave-uniform: every wave of the workgroup reaches this barrier
+    __syncthreads();
+    constexpr int NG2 = C::MT / 4 * 2;            // (sum, sumsq) pairs of the tile's 4-channel groups
+    if (tid < NG2) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < C::WN; ++w) t += red[w * NG2 + tid];        // fixed order: bitwise reproducible
+      const int g = m0 / 4 + tid / 2;
+      const int ngroups = (p.Cout + 3) / 4;
+      const int ntiles = tiles_x * tiles_y;
+      if (g < ngroups) p.gsum[(((size_t)n * ntiles + ty * tiles_x + tx) * ngroups + g) * 2 + (tid & 1)] = t;
+    }
   }
 }
 
@@ -452,6 +497,7 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
     hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
                        mtiles, nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_mfma_kernel");
+  if (a.gsum_tiles) *a.gsum_tiles = tiles_x * tiles_y;
   return MCEDM_OK;
 }
 
@@ -476,24 +522,25 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
       default: set_error("conv: no such tile configuration (%d, %d, %d)", g_force_mt, g_force_ph, g_force_pw); return MCEDM_ERR_INVALID;
     }
   }
-  // Pixel tile from the image width; channel tile as large as possible while the grid still
-  // covers the 256 CUs about twice (each CU holds 2-3 of these workgroups).
+  // The PIXEL tile is a function of the image size only (so that the fused GroupNorm partial sums, and with them
+  // every output bit, do not depend on the batch size: exact batch shardability); the CHANNEL tile is the largest
+  // one that still gives the 256 CUs about two workgroups each.
   auto blocks_for = [&](int mt, int ph, int pw) {
     return (long long)a.B * ceil_div(a.H, ph) * ceil_div(a.W, pw) * ceil_div(a.Cout, mt);
   };
   const long long want = 512;
+  if ((long long)a.H * a.W <= 256 || a.W < 12) {          // <= 16x16 images: 8x8-pixel tiles
+    if (coutp % 64 == 0) return launch_cfg<ConvCfg<64, 8, 8, 2, 2, TAPS, KC>>(a, stream);
+    return launch_cfg<ConvCfg<32, 8, 8, 1, 2, TAPS, KC>>(a, stream);
+  }
   if (a.W >= 24) {
     if (coutp % 128 == 0 && blocks_for(128, 8, 32) >= want) return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);
     if (coutp % 64 == 0 && blocks_for(64, 8, 32) >= want) return launch_cfg<ConvCfg<64, 8, 32, 1, 4, TAPS, KC>>(a, stream);
-    if (blocks_for(32, 8, 32) >= want) return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);
-  } else if (a.W >= 12) {
-    if (coutp % 128 == 0 && blocks_for(128, 16, 16) >= want) return launch_cfg<ConvCfg<128, 16, 16, 1, 4, TAPS, KC>>(a, stream);
-    if (coutp % 64 == 0 && blocks_for(64, 16, 16) >= want) return launch_cfg<ConvCfg<64, 16, 16, 1, 4, TAPS, KC>>(a, stream);
-    if (blocks_for(32, 16, 16) >= want) return launch_cfg<ConvCfg<32, 16, 16, 1, 4, TAPS, KC>>(a, stream);
+    return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);
   }
-  // small images or small grids: 8x8-pixel tiles
-  if (coutp % 64 == 0) return launch_cfg<ConvCfg<64, 8, 8, 2, 2, TAPS, KC>>(a, stream);
-  return launch_cfg<ConvCfg<32, 8, 8, 1, 2, TAPS, KC>>(a, stream);
+  if (coutp % 128 == 0 && blocks_for(128, 16, 16) >= want) return launch_cfg<ConvCfg<128, 16, 16, 1, 4, TAPS, KC>>(a, stream);
+  if (coutp % 64 == 0 && blocks_for(64, 16, 16) >= want) return launch_cfg<ConvCfg<64, 16, 16, 1, 4, TAPS, KC>>(a, stream);
+  return launch_cfg<ConvCfg<32, 16, 16, 1, 4, TAPS, KC>>(a, stream);
 }
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {

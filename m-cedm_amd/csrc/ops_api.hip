@@ -31,7 +31,7 @@ extern "C" int mcedm_op_gn_coef(const float* xa, const float* xb, int Ca, int Cb
   const int C = Ca + Cb;
   MCEDM_REQUIRE(C >= 4, "op_gn_coef: C=%d < 4 gives zero groups (adm_blocks.py:89)", C);
   GnArgs a{xa, xb, Ca, Cb, HW, B, C / 4 < 32 ? C / 4 : 32, gamma, beta, film, film_batch, film_stride, eps,
-           reinterpret_cast<Coef*>(coef_out), stats_out};
+           reinterpret_cast<Coef*>(coef_out), stats_out, nullptr, nullptr, 0, 0};
   return launch_gn_coef(a, (hipStream_t)stream);
 }
 

@@ -380,7 +380,28 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
   LayoutBuilder lb{L, Pool(), B};
   lb.pool.keep_all = training != 0;
   L.film = lb.make(P.film_rows, 1, 1, (size_t)n_noise * P.film_rows * sizeof(float));
+  // arena of fused GroupNorm statistics: one [B][tiles][C/4][2] fp32 table per conv output that feeds a GroupNorm
+  // (conv_in output, and h / y / z of every block), sized for the smallest pixel tile
+  auto sums_sz = [&](int C, int h, int w) { return align_up((size_t)B * conv_max_tiles(h, w) * ceil_div(C, 4) * 2 * sizeof(float), 256); };
+  {
+    size_t need = sums_sz(P.conv_in.cout, H, W);
+    int h = H, w = W;
+    for (auto* v : {&P.enc, &P.dec})
+      for (const BlockP& b : *v) {
+        if (b.up) { h *= 2; w *= 2; } else if (b.down) { h /= 2; w /= 2; }
+        need += (size_t)(b.attn ? 3 : 2) * sums_sz(b.cout, h, w);
+      }
+    L.sums_bytes = need;
+    const int id = lb.make(1, 1, 1, need);
+    L.sums_base = L.t[id].off;
+  }
+  size_t sums_cur = L.sums_base;
+  auto give_sums = [&](int id) {
+    L.t[id].sums = sums_cur;
+    sums_cur += sums_sz(L.t[id].C, L.t[id].H, L.t[id].W);
+  };
   L.t0 = lb.act(P.conv_in.cout, H, W);
+  give_sums(L.t0);
   std::vector<int> skips;
   int cur = L.t0;
   lb.retain(cur);                 // chain reference
@@ -395,11 +416,13 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
     bl.coef0 = lb.coef(b.cin);
     if (training) bl.stats0 = lb.stats(b.norm0.groups);
     bl.h = lb.act(b.cout, bl.H, bl.W);
+    give_sums(bl.h);
     lb.drop(bl.coef0);
     bl.coef1 = lb.coef(b.cout);
     if (training) bl.stats1 = lb.stats(b.norm1.groups);
     if (b.skip_kernel == 1) bl.sk = lb.act(b.cout, bl.H, bl.W);
     bl.y = lb.act(b.cout, bl.H, bl.W);
+    give_sums(bl.y);
     lb.drop(bl.h); lb.drop(bl.coef1); lb.drop(bl.sk);
     bl.out = bl.y;
     if (b.attn) {
@@ -410,6 +433,7 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
       bl.a = lb.act(b.cout, bl.H, bl.W);
       lb.drop(bl.qkv);
       bl.z = lb.act(b.cout, bl.H, bl.W);
+      give_sums(bl.z);
       lb.drop(bl.a); lb.drop(bl.y);
       bl.out = bl.z;
     }
@@ -465,9 +489,11 @@ Header header_for(const mcedm_plan& P, int B, int H, int W) {
 // forward schedule (adm_blocks.py:364-404 and :159-181)
 // ------------------------------------------------------------------------------------------
 static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl, const Layout& L, void* act,
-                     const float* pk, int B, int n_noise, hipStream_t s) {
+                     const float* pk, int B, int n_noise, hipStream_t s, std::vector<int>& st) {
   auto T = [&](int id) -> float* { return id < 0 ? nullptr : at<float>(act, L.t[id].off); };
   auto CF = [&](int id) -> Coef* { return id < 0 ? nullptr : at<Coef>(act, L.t[id].off); };
+  auto SUMS = [&](int id) -> float* { return (id < 0 || L.t[id].sums == NONE) ? nullptr : at<float>(act, L.t[id].sums); };
+  auto TL = [&](int id) -> int { return id < 0 ? 0 : st[id]; };      // tiles per sample of that tensor's table
   const float* xa = T(bl.xa);
   const float* xb = T(bl.xb);
   const int Ca = L.t[bl.xa].C, Cb = bl.xb >= 0 ? L.t[bl.xb].C : 0;
@@ -475,8 +501,8 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   int rc;
   // norm0 -> transform table for conv0
   GnArgs g0{xa, xb, Ca, Cb, bl.Hin * bl.Win, B, b.norm0.groups, pk + b.norm0.gamma, pk + b.norm0.beta,
-            nullptr, 0, 0, eps, CF(bl.coef0), T(bl.stats0)};
-  if ((rc = launch_gn_coef(g0, s))) return rc;
+            nullptr, 0, 0, eps, CF(bl.coef0), T(bl.stats0), SUMS(bl.xa), SUMS(bl.xb), TL(bl.xa), TL(bl.xb)};
+  if ((rc = launch_gn_coef_from_sums(g0, s))) return rc;
   // h = conv0(resample(silu(norm0(x))))
   ConvArgs c0{};
   c0.xa = xa; c0.xb = xb; c0.Ca = Ca; c0.Cb = Cb;
@@ -484,13 +510,13 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   c0.resample = b.up ? RS_UP : (b.down ? RS_DOWN : RS_NONE);
   c0.Hs = bl.Hin; c0.Ws = bl.Win; c0.H = bl.H; c0.W = bl.W;
   c0.wpk = pk + b.conv0.wpk; c0.bias = pk + b.conv0.bias;
-  c0.out = T(bl.h); c0.Cout = b.cout; c0.B = B;
+  c0.out = T(bl.h); c0.Cout = b.cout; c0.B = B; c0.gsum = SUMS(bl.h); c0.gsum_tiles = &st[bl.h];
   if ((rc = launch_conv(c0, 9, s))) return rc;
   // norm1 + FiLM -> transform table for conv1
   const float* film = at<float>(act, L.t[L.film].off) + b.film_row0;
   GnArgs g1{T(bl.h), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm1.groups, pk + b.norm1.gamma, pk + b.norm1.beta,
-            film, n_noise > 1 ? 1 : 0, P.film_rows, eps, CF(bl.coef1), T(bl.stats1)};
-  if ((rc = launch_gn_coef(g1, s))) return rc;
+            film, n_noise > 1 ? 1 : 0, P.film_rows, eps, CF(bl.coef1), T(bl.stats1), SUMS(bl.h), nullptr, TL(bl.h), 0};
+  if ((rc = launch_gn_coef_from_sums(g1, s))) return rc;
   // skip path
   const float* res = xa;
   int res_mode = RS_NONE;
@@ -512,13 +538,13 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   c1.Hs = bl.H; c1.Ws = bl.W; c1.H = bl.H; c1.W = bl.W;
   c1.wpk = pk + b.conv1.wpk; c1.bias = pk + b.conv1.bias;
   c1.res = res; c1.res_mode = res_mode;
-  c1.out = T(bl.y); c1.Cout = b.cout; c1.B = B;
+  c1.out = T(bl.y); c1.Cout = b.cout; c1.B = B; c1.gsum = SUMS(bl.y); c1.gsum_tiles = &st[bl.y];
   if ((rc = launch_conv(c1, 9, s))) return rc;
   if (!b.attn) return MCEDM_OK;
   // attention: z = proj(attn(qkv(norm2(y)))) + y
   GnArgs g2{T(bl.y), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm2.groups, pk + b.norm2.gamma, pk + b.norm2.beta,
-            nullptr, 0, 0, eps, CF(bl.coef2), T(bl.stats2)};
-  if ((rc = launch_gn_coef(g2, s))) return rc;
+            nullptr, 0, 0, eps, CF(bl.coef2), T(bl.stats2), SUMS(bl.y), nullptr, TL(bl.y), 0};
+  if ((rc = launch_gn_coef_from_sums(g2, s))) return rc;
   ConvArgs cq{};
   cq.xa = T(bl.y); cq.Ca = b.cout;
   cq.coef = CF(bl.coef2); cq.coef_batch = 1; cq.act = 0;
@@ -532,7 +558,7 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   cp.Hs = bl.H; cp.Ws = bl.W; cp.H = bl.H; cp.W = bl.W;
   cp.wpk = pk + b.proj.wpk; cp.bias = pk + b.proj.bias;
   cp.res = T(bl.y); cp.res_mode = RS_NONE;
-  cp.out = T(bl.z); cp.Cout = b.cout; cp.B = B;
+  cp.out = T(bl.z); cp.Cout = b.cout; cp.B = B; cp.gsum = SUMS(bl.z); cp.gsum_tiles = &st[bl.z];
   return launch_conv(cp, 1, s);
 }
 
@@ -545,6 +571,7 @@ static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, c
   EmbArgs e{noise_labels, n_noise, ch, pk + P.freqs, pk + P.w0, pk + P.b0, pk + P.w1, pk + P.b1,
             pk + P.waff, pk + P.baff, P.film_rows, nullptr, at<float>(act, L.t[L.film].off)};
   if ((rc = launch_embedding(e, s))) return rc;
+  std::vector<int> st(L.t.size(), 0);     // tiles per sample of each tensor's fused-statistics table
   // conv_in on cat(cond, x)  (cond FIRST, adm_blocks.py:332)
   ConvArgs ci{};
   ci.xa = cond; ci.Ca = P.desc.cond_channels;
@@ -553,16 +580,18 @@ static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, c
   ci.Hs = H; ci.Ws = W; ci.H = H; ci.W = W;
   ci.wpk = pk + P.conv_in.wpk; ci.bias = pk + P.conv_in.bias;
   ci.out = at<float>(act, L.t[L.t0].off); ci.Cout = P.conv_in.cout; ci.B = B;
+  ci.gsum = at<float>(act, L.t[L.t0].sums); ci.gsum_tiles = &st[L.t0];
   if ((rc = launch_conv(ci, 9, s))) return rc;
   size_t bi = 0;
-  for (const BlockP& b : P.enc) if ((rc = run_block(P, b, L.blocks[bi++], L, act, pk, B, n_noise, s))) return rc;
-  for (const BlockP& b : P.dec) if ((rc = run_block(P, b, L.blocks[bi++], L, act, pk, B, n_noise, s))) return rc;
+  for (const BlockP& b : P.enc) if ((rc = run_block(P, b, L.blocks[bi++], L, act, pk, B, n_noise, s, st))) return rc;
+  for (const BlockP& b : P.dec) if ((rc = run_block(P, b, L.blocks[bi++], L, act, pk, B, n_noise, s, st))) return rc;
   // out = out_conv(silu(out_norm(x)))
   const TRef& last = L.t[L.last];
   GnArgs go{at<float>(act, last.off), nullptr, last.C, 0, H * W, B, P.out_norm.groups, pk + P.out_norm.gamma,
             pk + P.out_norm.beta, nullptr, 0, 0, 1e-5f, at<Coef>(act, L.t[L.coef_out].off),
-            L.stats_out >= 0 ? at<float>(act, L.t[L.stats_out].off) : nullptr};
-  if ((rc = launch_gn_coef(go, s))) return rc;
+            L.stats_out >= 0 ? at<float>(act, L.t[L.stats_out].off) : nullptr,
+            last.sums != NONE ? at<float>(act, last.sums) : nullptr, nullptr, st[L.last], 0};
+  if ((rc = launch_gn_coef_from_sums(go, s))) return rc;
   ConvArgs co{};
   co.xa = at<float>(act, last.off); co.Ca = last.C;
   co.coef = at<Coef>(act, L.t[L.coef_out].off); co.coef_batch = 1; co.act = 1;

@@ -48,6 +48,8 @@ struct TRef {
   size_t off = NONE;           // byte offset
   int C = 0, H = 0, W = 0;
   size_t bytes = 0;
+  size_t sums = NONE;          // byte offset of the fused GroupNorm per-tile (sum, sumsq) table of this tensor, if any
+  int sum_tiles = 0;           // tiles per sample the producing conv used (filled while the forward is scheduled)
   int ref = 0;                 // live references while the layout is being simulated
 };
 
@@ -63,6 +65,7 @@ struct Layout {
   std::vector<TRef> t;         // all tensors
   std::vector<BlockLayout> blocks;   // encoder blocks then decoder blocks
   int film = -1, t0 = -1, coef_out = -1, stats_out = -1, last = -1;
+  size_t sums_base = 0, sums_bytes = 0;   // arena of all fused-statistics tables
   size_t total_bytes = 0;
 };
 
