@@ -113,7 +113,8 @@ int mcedm_edm_denoise(const mcedm_plan* plan, const void* packed, const float* x
 
 /* PlMcedm.sample_edm (models/mcedm.py:570-638), guide_dx False / dx_cond False.
  *  cond       [B, cond_channels, H, W] fp32; its first in_channels channels are hu_known
- *  mask       [B, in_channels, H, W] fp32, 1 = missing
+ *  mask       [B, in_channels, H, W] fp32, 1 = missing; NULL = no mask: the unmasked single-task sampler of
+ *             PlCondEdm.sample_edm (models/ddim.py:1532-1601), where cond is pure conditioning (may be NULL)
  *  init_noise [B, in_channels, H, W] fp32  (the reference's randn_like(hu), mcedm.py:576)
  *  step_noise [timesteps, B, in_channels, H, W] fp64 or NULL (the per-step randn_like(x_cur) of
  *             mcedm.py:608, fp64 like x_cur; NULL is only legal when no step has gamma > 0)
@@ -130,11 +131,13 @@ int mcedm_edm_t_steps(const mcedm_sampler_desc* sp, double* t_steps);
 /* ---- training --------------------------------------------------------------------- */
 /* Masked, weighted EDM loss of training_step (models/mcedm.py:266-278, models/losses.py:48-59)
  * and its gradient w.r.t. D:  loss = mean_b sum_chw w_b (D*m - x*m)^2,  w_b = (s^2+sd^2)/(s*sd)^2.
- *  loss_out: 1 fp32 (device), accumulated from zero by this call;  dD_out [B,C,H,W] or NULL. */
+ *  loss_out: 1 fp32 (device), accumulated from zero by this call;  dD_out [B,C,H,W] or NULL.
+ *  mask == NULL: unmasked loss of PlCondEdm.training_step (models/ddim.py:1727). */
 int mcedm_edm_loss(const float* D, const float* x, const float* mask, const float* sigma, int B, int C,
                    int H, int W, double sigma_data, float* loss_out, float* dD_out, void* stream);
 
-/* x_noise = x + mask*noise*sigma (mcedm.py:216), sigma = exp(rnd_normal*P_std + P_mean) (mcedm.py:271). */
+/* x_noise = x + mask*noise*sigma (mcedm.py:216; mask == NULL: x + noise*sigma, :218), sigma = exp(rnd_normal*P_std + P_mean)
+ * (mcedm.py:271). */
 int mcedm_edm_noise_inputs(const float* x, const float* mask, const float* noise, const float* rnd_normal,
                            int B, int C, int H, int W, double P_mean, double P_std, float* x_noise,
                            float* sigma_out, void* stream);

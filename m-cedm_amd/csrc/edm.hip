@@ -77,8 +77,9 @@ __global__ void heun_init_kernel(const float* __restrict__ cond, int cond_ch, in
                                  size_t total, double* __restrict__ x, float* __restrict__ x32) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / (in_ch * hw), r = i % (in_ch * hw);
-    const float known = cond[b * cond_ch * hw + r];          // cond[:, 0:in_ch]
-    const float m = mask[i];
+    // mask == NULL: the unmasked sampler of PlCondEdm (models/ddim.py:1556): x0 = noise * t0 (0 + v and v * 1 are exact)
+    const float m = mask ? mask[i] : 1.0f;
+    const float known = mask ? cond[b * cond_ch * hw + r] : 0.0f;          // cond[:, 0:in_ch]
     const float keep = known * (1.0f - m);                   // fp32 product like the reference
     const double v = (double)keep + ((double)noise[i] * t0) * (double)m;
     x[i] = v;
@@ -90,7 +91,7 @@ __global__ void heun_init_kernel(const float* __restrict__ cond, int cond_ch, in
 __global__ void heun_churn_kernel(double* __restrict__ x, const double* __restrict__ eps, const float* __restrict__ mask,
                                   double c, size_t total, float* __restrict__ x32) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const double v = x[i] + (c * eps[i]) * (double)mask[i];
+    const double v = x[i] + (c * eps[i]) * (mask ? (double)mask[i] : 1.0);
     x[i] = v;
     x32[i] = (float)v;
   }
@@ -103,7 +104,7 @@ __global__ void heun_euler_kernel(const double* __restrict__ x_hat, const float*
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const double xh = x_hat[i];
     const double d = (xh - (double)D[i]) / t_hat;
-    const double v = xh + (dt * d) * (double)mask[i];
+    const double v = xh + (dt * d) * (mask ? (double)mask[i] : 1.0);
     d_cur[i] = d;
     x_next[i] = v;
     x32[i] = (float)v;
@@ -116,7 +117,7 @@ __global__ void heun_correct_kernel(const double* __restrict__ x_hat, const doub
                                     size_t total, double* __restrict__ x_next, float* __restrict__ x32) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const double dp = (x_next[i] - (double)D[i]) / t_next;
-    const double v = x_hat[i] + (dt * (0.5 * d_cur[i] + 0.5 * dp)) * (double)mask[i];
+    const double v = x_hat[i] + (dt * (0.5 * d_cur[i] + 0.5 * dp)) * (mask ? (double)mask[i] : 1.0);
     x_next[i] = v;
     x32[i] = (float)v;
   }
@@ -176,7 +177,7 @@ __global__ void noise_inputs_kernel(const float* __restrict__ x, const float* __
     const size_t b = i / per_sample;
     const float sigma = expf(rnd[b] * P_std + P_mean);
     if (i % per_sample == 0) sigma_out[b] = sigma;
-    x_noise[i] = x[i] + mask[i] * noise[i] * sigma;
+    x_noise[i] = mask ? x[i] + mask[i] * noise[i] * sigma : x[i] + noise[i] * sigma;      // mcedm.py:216-218
   }
 }
 
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__
   const size_t base = (size_t)b * per_sample;
   float acc = 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_sample; i += (size_t)gridDim.x * blockDim.x) {
-    const float m = mask[base + i];
+    const float m = mask ? mask[base + i] : 1.0f;
     const float diff = D[base + i] * m - x[base + i] * m;
     acc += wgt * (diff * diff);
     if (dD) dD[base + i] = (2.0f * wgt / (float)B) * diff * m;
@@ -257,7 +258,7 @@ using namespace mcedm;
 extern "C" int mcedm_edm_noise_inputs(const float* x, const float* mask, const float* noise, const float* rnd_normal,
                                       int B, int C, int H, int W, double P_mean, double P_std, float* x_noise,
                                       float* sigma_out, void* stream) {
-  MCEDM_REQUIRE(x && mask && noise && rnd_normal && x_noise && sigma_out, "noise_inputs: null pointer");
+  MCEDM_REQUIRE(x && noise && rnd_normal && x_noise && sigma_out, "noise_inputs: null pointer");
   MCEDM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "noise_inputs: empty shape");
   const size_t per = (size_t)C * H * W, total = per * B;
   hipLaunchKernelGGL(noise_inputs_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, mask, noise,
@@ -268,7 +269,7 @@ extern "C" int mcedm_edm_noise_inputs(const float* x, const float* mask, const f
 
 extern "C" int mcedm_edm_loss(const float* D, const float* x, const float* mask, const float* sigma, int B, int C, int H,
                               int W, double sigma_data, float* loss_out, float* dD_out, void* stream) {
-  MCEDM_REQUIRE(D && x && mask && sigma && loss_out, "edm_loss: null pointer");
+  MCEDM_REQUIRE(D && x && sigma && loss_out, "edm_loss: null pointer");
   MCEDM_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0, "edm_loss: bad shape");
   const size_t per = (size_t)C * H * W;
   MCEDM_HIP_TRY(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));

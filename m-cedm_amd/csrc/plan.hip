@@ -727,11 +727,11 @@ extern "C" int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, con
                                  const float* cond, const float* mask, const float* init_noise,
                                  const double* step_noise, double* out, int return_last, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, void* stream) {
-  MCEDM_REQUIRE(plan && packed && sp && cond && mask && init_noise && out && workspace, "heun_sample: null argument");
+  MCEDM_REQUIRE(plan && packed && sp && init_noise && out && workspace, "heun_sample: null argument");
   const mcedm_plan& P = *plan;
   MCEDM_REQUIRE(P.desc.in_channels == P.desc.out_channels, "heun_sample: in_channels != out_channels");
-  MCEDM_REQUIRE(P.desc.cond_channels >= P.desc.in_channels, "heun_sample: cond must carry hu_known in its first %d channels",
-                P.desc.in_channels);
+  MCEDM_REQUIRE(mask == nullptr || (cond != nullptr && P.desc.cond_channels >= P.desc.in_channels),
+                "heun_sample: with a mask, cond must carry hu_known in its first %d channels", P.desc.in_channels);
   MCEDM_REQUIRE(sp->timesteps >= 2 && sp->timesteps <= 4096, "heun_sample: timesteps=%d out of range", sp->timesteps);
   const int N = sp->timesteps;
   std::vector<double> t(N + 1);

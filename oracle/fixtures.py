@@ -140,3 +140,28 @@ def training_nchw(h, u, mask, cond_noise):
     x = torch.cat([(h - st[0]) / st[1], (u - st[2]) / st[3]], dim=-1)
     cond_in = orc.cond_input(x, mask, cond_noise).permute(0, 3, 1, 2).contiguous()
     return x.permute(0, 3, 1, 2).contiguous(), cond_in, mask.permute(0, 3, 1, 2).contiguous()
+
+
+# ---- single-task conditional EDM (PlCondEdm, configs/model/adm_edm_cond_h_res32.yaml): h -> u, 1 + 1 -> 1 channels
+CFG_C = orc.UNetConfig(in_channels=1, cond_channels=1, out_ch=1)
+COND_SAMPLER_CASES = {"det": 0.0, "churn": 15.0}
+
+
+def cond_sampler_inputs(tag: str, B: int = 3, H: int = 32, W: int = 32, n_steps: int = 18):
+    """h (conditioning) and u_noise in the reference's NHWC layout + per-step noise (NCHW, fp32-representable)."""
+    h = randn(f"cond/{tag}/h", B, H, W, 1)
+    u_noise = randn(f"cond/{tag}/u_noise", B, H, W, 1)
+    steps = [randn(f"cond/{tag}/step{i}", B, 1, H, W).double() for i in range(n_steps)]
+    return h, u_noise, steps
+
+
+COND_GRAD_NAMES = ["enc.128x128_conv.weight", "out_conv.weight", "dec.32x32_in0.qkv.weight", "map_layer1.weight",
+                   "dec.64x64_block1.conv1.bias", "enc.32x32_down.norm0.weight"]
+
+
+def cond_training_inputs(B: int = 3, T: int = 32, X: int = 32):
+    h = randn("cond/train/h", B, T, X, 1) * 0.2 + 1.4
+    u = randn("cond/train/u", B, T, X, 1) * 0.5
+    noise = randn("cond/train/noise", B, 1, T, X)
+    rnd_normal = randn("cond/train/rnd", B, 1, 1, 1)
+    return h, u, noise, rnd_normal

@@ -44,6 +44,7 @@ sys.modules["pytorch_lightning"] = _pl
 
 from models import adm_blocks as ref_blocks          # noqa: E402  (reference)
 from models.mcedm import PlMcedm                      # noqa: E402  (reference)
+from models.ddim import PlCondEdm                     # noqa: E402  (reference)
 
 from oracle import mcedm_oracle as orc                # noqa: E402
 from oracle import fixtures as fx                     # noqa: E402
@@ -346,10 +347,73 @@ def golden_training():
     save("training_P.npz", seed=7, **out)
 
 
+def make_cond_hparams(cfg: orc.UNetConfig, sampler: dict):
+    """Mirror of configs/model/adm_edm_cond_h_res32.yaml."""
+    hp = make_hparams(cfg, sampler)
+    hp["name"] = "adm_edm_cond_h"
+    hp.model.update(type="simple", var_type="fixedsmall", node_type=False)
+    hp["diffusion"] = _wrap(dict(beta_schedule="linear", beta_start=0.0001, beta_end=0.02, num_diffusion_timesteps=1000))
+    return hp
+
+
+def golden_cond_edm():
+    """Section 8(f2): single-task conditional EDM, models/ddim.py PlCondEdm (1608-1773) with the same DhariwalUNet
+    (in 1 + cond 1 -> out 1): unmasked Heun sampler (deterministic and churned) and the training step."""
+    cfg = fx.CFG_C
+    P = orc.make_params(cfg, 13)
+    out = {}
+    for tag, churn in fx.COND_SAMPLER_CASES.items():
+        sp = sampler_dict(S_churn=churn)
+        m = PlCondEdm(make_cond_hparams(cfg, sp))
+        assert [(n, tuple(p.shape)) for n, p in m.model.named_parameters()] == [(n, tuple(s)) for n, s in orc.param_shapes(cfg)]
+        with torch.no_grad():
+            for n, p in m.model.named_parameters():
+                p.copy_(P[n])
+            for n, p in m.ema_model.ma_model.named_parameters():
+                p.copy_(P[n])
+        h, u_noise, steps = fx.cond_sampler_inputs(tag)
+        with torch.no_grad(), _Inject(steps):
+            xs = m.sample_edm(h, u_noise, _wrap(sp), return_last=False)
+        xo = orc.sample_edm_cond(P, cfg, h.permute(0, 3, 1, 2), orc.SamplerParams(S_churn=churn), u_noise.permute(0, 3, 1, 2),
+                                 steps, return_last=False)
+        check(f"PlCondEdm.sample_edm {tag}", xo, xs, rtol=1e-3, atol=1e-4)
+        assert xs.dtype == torch.float64 and tuple(xs.shape) == (3, 19, 32, 32, 1)
+        out[f"{tag}_xs_last"] = xs[:, -1:].contiguous()
+        out[f"{tag}_xs_traj"] = xs[:, ::6].contiguous()
+    # training step
+    m = PlCondEdm(make_cond_hparams(cfg, sampler_dict()))
+    with torch.no_grad():
+        for n, p in m.model.named_parameters():
+            p.copy_(P[n])
+    h, u, noise, rnd_normal = fx.cond_training_inputs()
+    st = fx.TRAIN_NORM_STATS
+    m.normalizer_input.set_stats(torch.tensor(st[0]), torch.tensor(st[1]))
+    m.normalizer_target.set_stats(torch.tensor(st[2]), torch.tensor(st[3]))
+    with _Inject([noise], [rnd_normal]):
+        loss = m.training_step((h, None, None, u), 0)
+    loss.backward()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    hn, un = ((h - st[0]) / st[1]).permute(0, 3, 1, 2), ((u - st[2]) / st[3]).permute(0, 3, 1, 2)
+    lo = orc.training_loss_cond(Pg, cfg, un, hn, noise, rnd_normal)
+    lo.backward()
+    check("PlCondEdm.training_step loss", lo, loss, rtol=1e-5, atol=1e-6)
+    ref = {n: p.grad for n, p in m.model.named_parameters()}
+    for n in ref:
+        check(f"cond grad {n}", Pg[n].grad, ref[n], rtol=1e-3, rel_to_max=2e-6)
+    out["loss"] = loss.detach()
+    for n in fx.COND_GRAD_NAMES:
+        out[f"grad::{n}"] = ref[n]
+    out["grad_sqnorm_each"] = torch.tensor([float((g.double() ** 2).sum()) for g in ref.values()])
+    sd = m.state_dict()
+    out["betas"], out["logvar"] = sd["betas"], sd["logvar"]
+    save("cond_edm.npz", seed=13, **out)
+
+
 if __name__ == "__main__":
     golden_ops()
     golden_blocks()
     golden_unet()
     golden_sampler()
     golden_training()
+    golden_cond_edm()
     print("all golden vectors written; oracle pinned against the reference on every case")

@@ -346,6 +346,15 @@ def training_loss(P, cfg, x: Tensor, cond_in: Tensor, mask_c: Tensor, noise: Ten
     return loss_matrix.sum(dim=(1, 2, 3)).mean()
 
 
+def training_loss_cond(P, cfg, u: Tensor, cond_in: Tensor, noise: Tensor, rnd_normal: Tensor) -> Tensor:
+    """PlCondEdm.training_step (single-task conditional EDM), models/ddim.py:1700-1727 + forward :1661-1687
+    with cond_p = 1, dx_cond False, self_cond False: unmasked noising and loss."""
+    sigma = (rnd_normal * P_STD + P_MEAN).exp()
+    weight = loss_weight(sigma)
+    D_x = model_precond(P, cfg, u + noise * sigma, sigma.float(), cond_in)
+    return (weight * (D_x - u) ** 2).sum(dim=(1, 2, 3)).mean()
+
+
 def cond_input(x: Tensor, mask: Tensor, cond_noise: Tensor) -> Tensor:
     """get_cond_in, mcedm.py:247 (add_cond_mask False, add_xt False); any layout."""
     return x * (1 - mask) + cond_noise * mask
@@ -372,6 +381,31 @@ class SamplerParams:
     S_max: float = float("inf")
     S_noise: float = 1.0
     w: float = 0.0
+
+
+def sample_edm_cond(P, cfg, h: Tensor, sp: SamplerParams, init_noise: Tensor,
+                    step_noise: Optional[Sequence[Tensor]] = None, return_last: bool = True) -> Tensor:
+    """PlCondEdm.sample_edm, models/ddim.py:1532-1601 (guide_dx False, no self-conditioning): the unmasked Heun
+    sampler; ``h`` [B, cond_ch, H, W] is pure conditioning, ``init_noise`` [B, out_ch, H, W]."""
+    N = sp.timesteps
+    t_steps = edm_t_steps(N, sp.sigma_min, sp.sigma_max, sp.rho)
+    x_next = init_noise.to(torch.float64) * t_steps[0]
+    xs = [x_next]
+    for i in range(N):
+        t_cur, t_next = t_steps[i], t_steps[i + 1]
+        gamma = min(sp.S_churn / N, math.sqrt(2) - 1) if sp.S_min <= float(t_cur) <= float(sp.S_max) else 0
+        t_hat = t_cur + gamma * t_cur
+        eps_i = step_noise[i] if step_noise is not None else torch.zeros_like(x_next)
+        x_hat = x_next + (t_hat ** 2 - t_cur ** 2).sqrt() * sp.S_noise * eps_i
+        denoised = get_denoised(P, cfg, x_hat, t_hat, cond=h, w=sp.w)[0].to(torch.float64)
+        d_cur = (x_hat - denoised) / t_hat
+        x_next = x_hat + (t_next - t_hat) * d_cur
+        if i < N - 1:
+            denoised = get_denoised(P, cfg, x_next, t_next, cond=h, w=sp.w)[0].to(torch.float64)
+            d_prime = (x_next - denoised) / t_next
+            x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
+        xs = [x_next] if return_last else xs + [x_next]
+    return torch.stack(xs, dim=0).permute(1, 0, 3, 4, 2).contiguous()
 
 
 def sample_edm(P, cfg, cond: Tensor, hu_mask: Tensor, sp: SamplerParams, init_noise: Tensor,

@@ -142,3 +142,31 @@ def test_training_loss_grads_adam(golden):
         p1, _, _, e1 = orc.adam_ema_step(P[n], ref, torch.zeros_like(ref), torch.zeros_like(ref), P[n], 1, clip=coef)
         close(p1, g[f"adam::{n}"], rtol=1e-5, atol=1e-7)
         close(e1, g[f"ema::{n}"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", list(fx.COND_SAMPLER_CASES))
+def test_cond_edm_sampler(golden, tag):
+    """Section 8(f2): PlCondEdm.sample_edm (models/ddim.py:1532-1601), unmasked Heun sampler."""
+    g = golden("cond_edm.npz")
+    P = orc.make_params(fx.CFG_C, int(g["seed"]))
+    h, u_noise, steps = fx.cond_sampler_inputs(tag)
+    with torch.no_grad():
+        xs = orc.sample_edm_cond(P, fx.CFG_C, h.permute(0, 3, 1, 2), orc.SamplerParams(S_churn=fx.COND_SAMPLER_CASES[tag]),
+                                 u_noise.permute(0, 3, 1, 2), steps, return_last=False)
+    close(xs[:, -1:], g[f"{tag}_xs_last"], rtol=1e-3, atol=1e-4)
+    close(xs[:, ::6], g[f"{tag}_xs_traj"], rtol=1e-3, atol=1e-4)
+
+
+def test_cond_edm_training(golden):
+    g = golden("cond_edm.npz")
+    P = orc.make_params(fx.CFG_C, int(g["seed"]))
+    h, u, noise, rnd_normal = fx.cond_training_inputs()
+    st = fx.TRAIN_NORM_STATS
+    hn, un = ((h - st[0]) / st[1]).permute(0, 3, 1, 2), ((u - st[2]) / st[3]).permute(0, 3, 1, 2)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss = orc.training_loss_cond(Pg, fx.CFG_C, un, hn, noise, rnd_normal)
+    loss.backward()
+    close(loss.detach(), g["loss"], rtol=1e-5)
+    for n in fx.COND_GRAD_NAMES:
+        ref = torch.as_tensor(g[f"grad::{n}"])
+        close(Pg[n].grad, ref, rtol=1e-3, atol=2e-6 * float(ref.abs().max()))
