@@ -193,9 +193,9 @@ int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, const mcedm_
 int mcedm_op_attention(const float* qkv, float* out, int B, int heads, int T, void* stream);
 /* Backward building blocks.
  * conv weight / bias gradient: dw [Cout, Cin, k, k], db [Cout] (may be NULL) for the conv described as in mcedm_op_conv
- * (the input transform is recomputed on the fly); scratch holds mcedm_op_wgrad_scratch_floats() floats; qkv_heads > 0:
+ * (the transformed input is rebuilt into the scratch first); scratch holds mcedm_op_wgrad_scratch_floats() floats; qkv_heads > 0:
  * dy rows are in packed qkv order.  Data gradient = mcedm_op_conv on weights packed with dgrad = 1. */
-size_t mcedm_op_wgrad_scratch_floats(int Cout, int Cin, int k);
+size_t mcedm_op_wgrad_scratch_floats(int Cout, int Cin, int k, int B, int H, int W);
 int mcedm_op_conv_wgrad(const float* dy, const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef,
                         int coef_batch, int act, int resample, int Hs, int Ws, int H, int W, int Cout, int B, int k,
                         int qkv_heads, float* scratch, float* dw, float* db, void* stream);

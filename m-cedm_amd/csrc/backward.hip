@@ -78,7 +78,7 @@ __global__ void colsum_kernel(const float* __restrict__ A, int rows, int cols, i
 
 struct BwdScratch {
   std::vector<size_t> g;     // gradient buffer per forward tensor id (NONE when not an activation)
-  size_t dact, dskip, ab, wg, dfilm, lse, gF, pe, u1, u2, t1, t2, t3, total;
+  size_t dact, dskip, xact, ab, wg, dfilm, lse, gF, pe, u1, u2, t1, t2, t3, total;
 };
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
@@ -110,6 +110,7 @@ static BwdScratch make_scratch(const mcedm_plan& P, const Layout& L, int B, int 
   const int ch = P.desc.ch;
   S.dact = take(max_dact * 4);
   S.dskip = take(max_dact * 4);
+  S.xact = take(max_dact * 4);
   S.ab = take((size_t)B * max_c * 2 * 4);
   S.wg = take(max_wg * 4);
   S.dfilm = take((size_t)B * P.film_rows * 4);
@@ -172,12 +173,12 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
     const float* dz = c.G(bl.z);
     // z = proj(a) + y
     WgradArgs wp{dz, c.T(bl.a), nullptr, b.cout, 0, nullptr, 0, 0, RS_NONE, H, W, H, W, b.cout, B, wg, nullptr};
-    if ((rc = launch_wgrad(wp, 1, c.grads[b.proj.w], c.grads[b.proj.b], 0, c.s))) return rc;
+    if ((rc = launch_wgrad(wp, 1, c.grads[b.proj.w], c.grads[b.proj.b], 0, c.X(c.S.xact), c.s))) return rc;
     if ((rc = dgrad(c, b.proj, dz, H, W, c.G(bl.a)))) return rc;
     if ((rc = launch_attention_bwd(c.T(bl.qkv), c.T(bl.a), c.G(bl.a), c.G(bl.qkv), c.X(c.S.lse), B, b.heads, H * W, c.s))) return rc;
     // qkv = conv1x1(norm2(y))   (rows in packed order)
     WgradArgs wq{c.G(bl.qkv), c.T(bl.y), nullptr, b.cout, 0, c.CF(bl.coef2), 1, 0, RS_NONE, H, W, H, W, 3 * b.cout, B, wg, nullptr};
-    if ((rc = launch_wgrad(wq, 1, c.grads[b.qkv.w], c.grads[b.qkv.b], b.heads, c.s))) return rc;
+    if ((rc = launch_wgrad(wq, 1, c.grads[b.qkv.w], c.grads[b.qkv.b], b.heads, c.X(c.S.xact), c.s))) return rc;
     if ((rc = dgrad(c, b.qkv, c.G(bl.qkv), H, W, dact))) return rc;
     GnBwdArgs g2{dact, RS_NONE, c.T(bl.y), nullptr, b.cout, 0, H, W, B, b.norm2.groups, c.CF(bl.coef2), c.T(bl.stats2),
                  c.pk + b.norm2.gamma, nullptr, 0, 0, 0, c.G(bl.y), nullptr, 0, dz, 1, b.cout, c.X(c.S.ab)};
@@ -187,7 +188,7 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
   }
   // y = conv1(silu(film(norm1(h)))) + skip(x)
   WgradArgs w1{dy, c.T(bl.h), nullptr, b.cout, 0, c.CF(bl.coef1), 1, 1, RS_NONE, H, W, H, W, b.cout, B, wg, nullptr};
-  if ((rc = launch_wgrad(w1, 9, c.grads[b.conv1.w], c.grads[b.conv1.b], 0, c.s))) return rc;
+  if ((rc = launch_wgrad(w1, 9, c.grads[b.conv1.w], c.grads[b.conv1.b], 0, c.X(c.S.xact), c.s))) return rc;
   if ((rc = dgrad(c, b.conv1, dy, H, W, dact))) return rc;
   const float* film = reinterpret_cast<const float*>(c.act + c.L.t[c.L.film].off) + b.film_row0;
   GnBwdArgs g1{dact, RS_NONE, c.T(bl.h), nullptr, b.cout, 0, H, W, B, b.norm1.groups, c.CF(bl.coef1), c.T(bl.stats1),
@@ -201,7 +202,7 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
   if (b.skip_kernel == 1) {
     if (rs != RS_NONE) { set_error("backward: resampling 1x1 skip conv is outside the hot path (%s)", b.key.c_str()); return MCEDM_ERR_UNSUPPORTED; }
     WgradArgs wsk{dy, xa, xb, Ca, Cb, nullptr, 0, 0, RS_NONE, H, W, H, W, b.cout, B, wg, nullptr};
-    if ((rc = launch_wgrad(wsk, 1, c.grads[b.skip.w], c.grads[b.skip.b], 0, c.s))) return rc;
+    if ((rc = launch_wgrad(wsk, 1, c.grads[b.skip.w], c.grads[b.skip.b], 0, c.X(c.S.xact), c.s))) return rc;
     if ((rc = dgrad(c, b.skip, dy, H, W, c.X(c.S.dskip)))) return rc;
     add = c.X(c.S.dskip);
   } else if (b.skip_kernel == 0) {
@@ -209,7 +210,7 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
   }
   // h = conv0(resample(silu(norm0(x))))
   WgradArgs w0{c.G(bl.h), xa, xb, Ca, Cb, c.CF(bl.coef0), 1, 1, rs, bl.Hin, bl.Win, H, W, b.cout, B, wg, nullptr};
-  if ((rc = launch_wgrad(w0, 9, c.grads[b.conv0.w], c.grads[b.conv0.b], 0, c.s))) return rc;
+  if ((rc = launch_wgrad(w0, 9, c.grads[b.conv0.w], c.grads[b.conv0.b], 0, c.X(c.S.xact), c.s))) return rc;
   if ((rc = dgrad(c, b.conv0, c.G(bl.h), H, W, dact))) return rc;
   GnBwdArgs g0{dact, rs, xa, xb, Ca, Cb, bl.Hin, bl.Win, B, b.norm0.groups, c.CF(bl.coef0), c.T(bl.stats0),
                c.pk + b.norm0.gamma, nullptr, 0, 0, 1, c.G(bl.xa), c.G(bl.xb), 0, add, add_mode, b.cin, c.X(c.S.ab)};
@@ -267,7 +268,7 @@ extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* pa
   const TRef& last = L.t[L.last];
   WgradArgs wo{c.X(S.gF), c.T(L.last), nullptr, last.C, 0, c.CF(L.coef_out), 1, 1, RS_NONE, H, W, H, W,
                P.desc.out_channels, B, c.X(S.wg), nullptr};
-  if ((rc = launch_wgrad(wo, 9, grads[P.conv_out.w], grads[P.conv_out.b], 0, s))) return rc;
+  if ((rc = launch_wgrad(wo, 9, grads[P.conv_out.w], grads[P.conv_out.b], 0, c.X(c.S.xact), s))) return rc;
   if ((rc = dgrad(c, P.conv_out, c.X(S.gF), H, W, c.X(S.dact)))) return rc;
   GnBwdArgs go{c.X(S.dact), RS_NONE, c.T(L.last), nullptr, last.C, 0, H, W, B, P.out_norm.groups, c.CF(L.coef_out),
                c.T(L.stats_out), pk + P.out_norm.gamma, nullptr, 0, 0, 1, c.G(L.last), nullptr, 0, nullptr, 0, 0, c.X(S.ab)};
@@ -285,7 +286,7 @@ extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* pa
   // conv_in: weight / bias gradient only (its inputs carry no gradient)
   WgradArgs wi{c.G(L.t0), cond, x, P.desc.cond_channels, P.desc.in_channels, at<Coef>(workspace, hd.coef_in),
                n_sigma > 1 ? 1 : 0, 0, RS_NONE, H, W, H, W, P.conv_in.cout, B, c.X(S.wg), nullptr};
-  if ((rc = launch_wgrad(wi, 9, grads[P.conv_in.w], grads[P.conv_in.b], 0, s))) return rc;
+  if ((rc = launch_wgrad(wi, 9, grads[P.conv_in.w], grads[P.conv_in.b], 0, c.X(c.S.xact), s))) return rc;
 
   // embedding MLP + affine rows: film = emb Waff^T + baff, emb = silu(u2), u2 = W1 silu(u1) + b1, u1 = W0 pe + b0
   const int n = n_sigma, R = P.film_rows;

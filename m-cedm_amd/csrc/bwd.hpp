@@ -16,7 +16,8 @@ struct WgradArgs {
 };
 size_t wgrad_scratch_floats(int Cout, int Cin, int taps);
 // dw [Cout][Cin][kh][kw], db [Cout] (may be null).  qkv_heads > 0: dy rows are in packed qkv order.
-int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, hipStream_t s);
+// act_tmp: scratch of B * (Ca+Cb) * H * W floats for the materialised conv input
+int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s);
 
 // backward through  act(film(group_norm(cat(xa,xb))))  followed by an optional 2x resampling
 struct GnBwdArgs {

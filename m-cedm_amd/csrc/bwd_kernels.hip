@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
   const int HWc = a.resample == RS_UP ? HWs * 4 : (a.resample == RS_DOWN ? HWs / 4 : HWs);
   const float mean = a.stats[((size_t)n * a.groups + g) * 2], rstd = a.stats[((size_t)n * a.groups + g) * 2 + 1];
   const int tid = threadIdx.x;
+  const bool vec = a.resample == RS_NONE && (HWs & 3) == 0;      // all planes are then 16-byte aligned
   __shared__ double red[2][4];
   __shared__ float sA[GN_MAX_CPG], sB[GN_MAX_CPG], sM[2];
 
@@ -49,13 +50,28 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
     const float* dpl = a.dact + ((size_t)n * C + c) * HWc;
     const Coef cf = a.coef[(size_t)n * C + c];
     float pa = 0.f, pb = 0.f;
-    for (int p = tid; p < HWs; p += 256) {
-      const int ys = p / a.Ws, xs = p - ys * a.Ws;
-      const float xv = x[p];
-      float dt = fetch_resampled(dpl, a.resample, ys, xs, a.Ws);
-      if (a.act) dt *= dsilu((xv - cf.mean) * cf.scale + cf.offset);
-      pa += dt;
-      pb += dt * ((xv - mean) * rstd);
+    if (vec) {            // no resampling, HW % 4 == 0: 16-byte loads
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+      const f32x4* d4 = reinterpret_cast<const f32x4*>(dpl);
+      for (int p = tid; p < HWs / 4; p += 256) {
+        const f32x4 xv = x4[p], dv = d4[p];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float dt = dv[e];
+          if (a.act) dt *= dsilu((xv[e] - cf.mean) * cf.scale + cf.offset);
+          pa += dt;
+          pb += dt * ((xv[e] - mean) * rstd);
+        }
+      }
+    } else {
+      for (int p = tid; p < HWs; p += 256) {
+        const int ys = p / a.Ws, xs = p - ys * a.Ws;
+        const float xv = x[p];
+        float dt = fetch_resampled(dpl, a.resample, ys, xs, a.Ws);
+        if (a.act) dt *= dsilu((xv - cf.mean) * cf.scale + cf.offset);
+        pa += dt;
+        pb += dt * ((xv - mean) * rstd);
+      }
     }
     double da = pa, db = pb;
 #pragma unroll
@@ -94,6 +110,27 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
     const float* dpl = a.dact + ((size_t)n * C + c) * HWc;
     const float* addp = a.add ? a.add + ((size_t)n * C + c) * (a.add_mode == 2 ? HWc : HWs) : nullptr;
     const Coef cf = a.coef[(size_t)n * C + c];
+    if (vec) {
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+      const f32x4* d4 = reinterpret_cast<const f32x4*>(dpl);
+      const f32x4* a4 = reinterpret_cast<const f32x4*>(addp);
+      f32x4* o4 = reinterpret_cast<f32x4*>(dx);
+      for (int p = tid; p < HWs / 4; p += 256) {
+        const f32x4 xv = x4[p], dv = d4[p];
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (addp) o = a4[p];
+        if (a.accumulate) { const f32x4 old = o4[p]; o += old; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float dt = dv[e];
+          if (a.act) dt *= dsilu((xv[e] - cf.mean) * cf.scale + cf.offset);
+          const float xh = (xv[e] - mean) * rstd;
+          o[e] += cf.scale * dt - rstd * (m1 + xh * m2);
+        }
+        o4[p] = o;
+      }
+      continue;
+    }
     for (int p = tid; p < HWs; p += 256) {
       const int ys = p / a.Ws, xs = p - ys * a.Ws;
       const float xv = x[p];

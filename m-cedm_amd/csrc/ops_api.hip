@@ -60,9 +60,9 @@ extern "C" int mcedm_op_set_conv_tile(int mt, int ph, int pw) {
   return MCEDM_OK;
 }
 
-extern "C" size_t mcedm_op_wgrad_scratch_floats(int Cout, int Cin, int k) {
-  if (Cout <= 0 || Cin <= 0 || (k != 1 && k != 3)) return 0;
-  return wgrad_scratch_floats(Cout, Cin, k * k);
+extern "C" size_t mcedm_op_wgrad_scratch_floats(int Cout, int Cin, int k, int B, int H, int W) {
+  if (Cout <= 0 || Cin <= 0 || (k != 1 && k != 3) || B <= 0 || H <= 0 || W <= 0) return 0;
+  return align_up(wgrad_scratch_floats(Cout, Cin, k * k), 64) + (size_t)B * Cin * H * W;
 }
 
 extern "C" int mcedm_op_conv_wgrad(const float* dy, const float* xa, const float* xb, int Ca, int Cb,
@@ -73,7 +73,8 @@ extern "C" int mcedm_op_conv_wgrad(const float* dy, const float* xa, const float
   MCEDM_REQUIRE(dy && scratch && dw, "op_conv_wgrad: null pointer");
   WgradArgs a{dy, xa, xb, Ca, Cb, reinterpret_cast<const Coef*>(coef), coef_batch, act, resample, Hs, Ws, H, W, Cout, B,
               scratch, nullptr};
-  return launch_wgrad(a, k * k, dw, db, qkv_heads, (hipStream_t)stream);
+  float* act_tmp = scratch + align_up(wgrad_scratch_floats(Cout, Ca + Cb, k * k), 64);
+  return launch_wgrad(a, k * k, dw, db, qkv_heads, act_tmp, (hipStream_t)stream);
 }
 
 extern "C" int mcedm_op_gn_bwd(const float* dact, int resample, const float* xa, const float* xb, int Ca, int Cb, int Hs,

@@ -305,7 +305,7 @@ def _bind_ops():
     lib.mcedm_op_conv.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32,
                                   i32, i32, vp]
     lib.mcedm_op_attention.argtypes = [vp, vp, i32, i32, i32, vp]
-    lib.mcedm_op_wgrad_scratch_floats.argtypes = [i32, i32, i32]
+    lib.mcedm_op_wgrad_scratch_floats.argtypes = [i32, i32, i32, i32, i32, i32]
     lib.mcedm_op_wgrad_scratch_floats.restype = sz
     lib.mcedm_op_conv_wgrad.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                         vp, vp, vp, vp]
@@ -402,7 +402,7 @@ def op_conv_wgrad(dy, xa, xb, k, coef=None, coef_batch=1, act=0, resample=RS_NON
     Ca, Hs, Ws = xa.shape[1], xa.shape[2], xa.shape[3]
     Cb = xb.shape[1] if xb is not None else 0
     Cin = Ca + Cb
-    scratch = torch.empty(lib.mcedm_op_wgrad_scratch_floats(Cout, Cin, k), dtype=torch.float32, device=dy.device)
+    scratch = torch.empty(lib.mcedm_op_wgrad_scratch_floats(Cout, Cin, k, B, H, W), dtype=torch.float32, device=dy.device)
     dw = torch.empty((Cout, Cin, k, k), dtype=torch.float32, device=dy.device)
     db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
     check(lib.mcedm_op_conv_wgrad(_ptr(dy), _ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, resample, Hs, Ws, H,
