@@ -216,6 +216,9 @@ int mcedm_op_attention_bwd(const float* qkv, const float* a, const float* da, fl
 /* Test hook: force the conv tile (channel tile mt in {32,64,128}, pixel tile ph x pw in {8x32,16x16,8x8});
  * (0,0,0) restores the size heuristic.  Process-global, not thread-safe. */
 int mcedm_op_set_conv_tile(int mt, int ph, int pw);
+/* Diagnostics: when buf != NULL every conv workgroup writes 8 x u64 at buf[8*blockIdx]: timestamps (10 ns units) at
+ * start / first chunk / end of K loop / end of epilogue, and (XCC id << 32 | HW_ID).  NULL switches it off. */
+int mcedm_op_set_conv_debug(unsigned long long* buf);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * Per-launch timing with HIP event pairs recorded on the launch stream (bench.py's roofline leg).

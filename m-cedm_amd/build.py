@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libmcedm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}",
-          "-Wall", "-Wno-unused-function"]
+          "-Wall", "-Wno-unused-function"] + os.environ.get("MCEDM_EXTRA_HIPCC_FLAGS", "").split()
 # the fp64 sampler arithmetic must follow the reference's evaluation order: no fma contraction there
 PER_FILE = {"edm.hip": ["-ffp-contract=off"]}
 

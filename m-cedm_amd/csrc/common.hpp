@@ -76,11 +76,14 @@ struct ConvArgs {
                      // of the OUTPUT written by the epilogue (no atomics); feeds the next GroupNorm without a stats
                      // pass.  Must hold B * conv_max_tiles(H, W) * ceil(Cout/4) * 2 floats.
   int* gsum_tiles;   // host out: tiles per sample the launcher used (row count of gsum per sample)
+  int coef_rows;     // set by the launcher: 1 = coef holds Ca+Cb rows (per sample if coef_batch), 0 = a single identity row
+  unsigned long long* dbg;   // diagnostics only (mcedm_op_set_conv_debug): 4 timestamps (10 ns) + CU id per workgroup
 };
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t stream);
 static inline int conv_max_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 7) / 8); }   // smallest pixel tile is 8x8
-void set_conv_tile_override(int mt, int ph, int pw);   // test hook; (0,0,0) restores the heuristic
+void set_conv_tile_override(int mt, int ph, int pw);
+void set_conv_debug(unsigned long long* buf);   // test hook; (0,0,0) restores the heuristic
 // geometry the packer must use for a given (Cout, taps): tile height over Cout and K-chunk
 int conv_mt_for(int Cout);
 int conv_kc_for(int taps);

@@ -34,6 +34,9 @@ struct ConvCfg {
   static constexpr int XL = KC * PLANE;      // floats of the input tile
   static constexpr int WL = TAPS * KC * MT;  // floats of the weight slab
   static constexpr int NWAVE = WM * WN;       // waves that own accumulators (the rest only help staging)
+  // resident workgroups per CU the kernel is compiled for: <= 64 accumulator registers leave room for a third wave
+  // per SIMD (<= 168 VGPRs), which hides more of the staging phases (+5 % on the MT = 64 tiles)
+  static constexpr int OCC = (TM * TN <= 4) ? 3 : 2;
   static_assert(NWAVE >= 1 && NWAVE <= 4, "at most 4 compute waves per workgroup");
   static_assert(TM >= 1 && TN >= 1 && MT % (WM * 32) == 0 && NPIX % (WN * 32) == 0, "tile shape");
   static_assert(MT % 4 == 0 && KC % 2 == 0, "vector widths");
@@ -61,10 +64,16 @@ template <class C, int RS>
 struct TileGeom {
   static constexpr int NL = (RS == RS_DOWN) ? 4 : 1;
   static constexpr int SUB = (C::PLANE + 255) / 256;
-  int soff[SUB][NL];   // clamped source offsets inside one channel plane
-  bool inb[SUB];       // element lies inside the image (else it is conv zero padding)
-  bool inp[SUB];       // element index lies inside the LDS plane
+  unsigned boff[SUB][NL];   // clamped BYTE offsets inside one channel plane (the same for every channel)
+  unsigned keep[SUB];       // all-ones: element lies inside the image; 0: it is conv zero padding
 };
+
+// Weight slab: buffer addressing (one 128-bit descriptor in SGPRs + a 32-bit per-lane byte offset + a scalar
+// offset), so no per-load address VGPRs.  (The input planes keep scalar-base pointers + the 32-bit lane offsets
+// of TileGeom: a descriptor per channel costs more SGPRs than the kernel has, and spills.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
 
 template <class C, int RS>
 __device__ __forceinline__ void make_geom(const ConvArgs& p, TileGeom<C, RS>& G, int y0, int x0, int tid) {
@@ -75,19 +84,21 @@ __device__ __forceinline__ void make_geom(const ConvArgs& p, TileGeom<C, RS>& G,
     const int c = e - r * C::PITCH;
     const int y = y0 + r - C::HALO;
     const int x = x0 + c - C::HALO;
-    G.inp[sub] = e < C::PLANE;
-    G.inb[sub] = G.inp[sub] && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
-    const int yc = G.inb[sub] ? y : 0, xc = G.inb[sub] ? x : 0;
-    if (RS == RS_NONE) {
-      G.soff[sub][0] = yc * p.Ws + xc;
-    } else if (RS == RS_UP) {
-      G.soff[sub][0] = (yc >> 1) * p.Ws + (xc >> 1);
+    const bool inb = (e < C::PLANE) && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
+    G.keep[sub] = inb ? 0xffffffffu : 0u;
+    const int yc = inb ? y : 0, xc = inb ? x : 0;
+    if constexpr (RS == RS_NONE) {
+      G.boff[sub][0] = 4u * (unsigned)(yc * p.Ws + xc);
+    } else if constexpr (RS == RS_UP) {
+      G.boff[sub][0] = 4u * (unsigned)((yc >> 1) * p.Ws + (xc >> 1));
     } else {
-      const int o = (2 * yc) * p.Ws + 2 * xc;
-      G.soff[sub][0] = o; G.soff[sub][1] = o + 1; G.soff[sub][2] = o + p.Ws; G.soff[sub][3] = o + p.Ws + 1;
+      const unsigned o = 4u * (unsigned)((2 * yc) * p.Ws + 2 * xc);
+      G.boff[sub][0] = o; G.boff[sub][1] = o + 4u; G.boff[sub][2] = o + 4u * p.Ws; G.boff[sub][3] = o + 4u * p.Ws + 4u;
     }
   }
 }
+
+__device__ Coef k_identity_coef = {0.f, 1.f, 0.f, 0.f};   // the table of a conv without an input transform
 
 template <class C, int RS>
 struct InputRegs {
@@ -110,11 +121,13 @@ __device__ __forceinline__ void load_input(const ConvArgs& p, const TileGeom<C, 
     const int CC = in_a ? p.Ca : p.Cb;
     const bool chan_ok = (ci < Cin) && (src != nullptr);
     const float* plane = chan_ok ? src + ((size_t)n * CC + cc) * src_plane : safe;
-    R.cf[cil] = (chan_ok && p.coef) ? p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + ci] : Coef{0.f, 1.f, 0.f, 0.f};
+    // Unconditional load (a guarded one costs a vmcnt(0) round trip per channel): padded channels read a clamped row
+    // and are zeroed in store_input; without a table the launcher points coef at one identity row (coef_rows == 0).
+    R.cf[cil] = p.coef[((p.coef_batch ? (size_t)n * Cin : 0) + (ci < Cin ? ci : Cin - 1)) * p.coef_rows];
 #pragma unroll
     for (int sub = 0; sub < TileGeom<C, RS>::SUB; ++sub)
 #pragma unroll
-      for (int q = 0; q < TileGeom<C, RS>::NL; ++q) R.raw[cil][sub][q] = plane[G.soff[sub][q]];
+      for (int q = 0; q < TileGeom<C, RS>::NL; ++q) R.raw[cil][sub][q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + G.boff[sub][q]);
   }
 }
 
@@ -126,19 +139,25 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
   for (int cil = 0; cil < C::KC; ++cil) {
     const int ci = c0 + cil;
     const bool chan_ok = (ci < Cin) && ((ci < p.Ca ? p.xa : p.xb) != nullptr);
+    const unsigned ckeep = chan_ok ? 0xffffffffu : 0u;
 #pragma unroll
     for (int sub = 0; sub < TileGeom<C, RS>::SUB; ++sub) {
       float v;
-      if (RS == RS_DOWN) {
+      if constexpr (RS == RS_DOWN) {
         // 2x2 box filter of the ACTIVATED source (adm_blocks.py:75-77 runs after silu(norm(x)))
         v = 0.25f * ((apply_coef(R.raw[cil][sub][0], R.cf[cil], p.act) + apply_coef(R.raw[cil][sub][1], R.cf[cil], p.act)) +
                      (apply_coef(R.raw[cil][sub][2], R.cf[cil], p.act) + apply_coef(R.raw[cil][sub][3], R.cf[cil], p.act)));
       } else {
         v = apply_coef(R.raw[cil][sub][0], R.cf[cil], p.act);
       }
-      v = (chan_ok && G.inb[sub]) ? v : 0.f;
-      if (G.inp[sub]) xl[cil * C::PLANE + tid + sub * 256] = v;
+      // zero padding / padded channels as a bit mask: straight-line code (a select makes the compiler branch
+      // around the SiLU, ~30 tiny basic blocks per chunk)
+      v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (G.keep[sub] & ckeep));
+      if ((sub + 1) * 256 <= C::PLANE || tid + sub * 256 < C::PLANE) xl[cil * C::PLANE + tid + sub * 256] = v;
     }
+    // one channel at a time: left alone, the scheduler interleaves all KC SiLU chains of this straight-line code
+    // and pays for the extra live values with accumulator spills
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -150,17 +169,38 @@ struct WeightRegs {
   f32x4 v[IT];   // native vector type: HIP's float4 class defeats SROA here and lands in scratch
 };
 
+// 256 threads fetch 256 float4 per step = ROWS_IT whole rows of the slab; the per-lane byte offset is the same
+// for every step and chunk, the (chunk, step) part is a scalar offset.
 template <class C>
-__device__ __forceinline__ void load_weights(const float* wpk, WeightRegs<C>& R, int ch, int m0, int coutp, int tid) {
-  constexpr int V4_PER_ROW = C::MT / 4;
-  const float* wbase = wpk + (size_t)ch * (C::TAPS * C::KC) * coutp + m0;
+struct WeightGeom {
+  static constexpr int V4_PER_ROW = C::MT / 4;
+  static constexpr int ROWS_IT = 256 / V4_PER_ROW;
+  static_assert(256 % V4_PER_ROW == 0, "a staging step covers whole slab rows");
+  unsigned voff;        // byte offset of this lane's float4 inside a step
+  unsigned voff_last;   // the same for the last step, clamped into the slab when that step is partial
+  __amdgpu_buffer_rsrc_t rs;
+};
+
+template <class C>
+__device__ __forceinline__ void make_wgeom(const float* wpk, WeightGeom<C>& G, int m0, int coutp, int nchunks, int tid) {
+  constexpr int V4 = WeightGeom<C>::V4_PER_ROW, NV4 = WeightRegs<C>::NV4, IT = WeightRegs<C>::IT;
+  const int row = tid / V4, c4 = tid - row * V4;
+  G.voff = 4u * (unsigned)(row * coutp + c4 * 4);
+  int il = tid + (IT - 1) * 256;
+  if (il >= NV4) il = NV4 - 1;
+  const int rl = il / V4 - (IT - 1) * WeightGeom<C>::ROWS_IT, cl = il % V4;
+  G.voff_last = 4u * (unsigned)(rl * coutp + cl * 4);
+  G.rs = make_rsrc(wpk + m0, 4u * (unsigned)((size_t)nchunks * C::TAPS * C::KC * coutp - m0));
+}
+
+template <class C>
+__device__ __forceinline__ void load_weights(const WeightGeom<C>& G, WeightRegs<C>& R, int ch, int coutp) {
+  constexpr int IT = WeightRegs<C>::IT;
 #pragma unroll
-  for (int it = 0; it < WeightRegs<C>::IT; ++it) {
-    int i = tid + it * 256;
-    if (i >= WeightRegs<C>::NV4) i = WeightRegs<C>::NV4 - 1;     // clamp instead of branching; the store is guarded
-    const int row = i / V4_PER_ROW;
-    const int c4 = i - row * V4_PER_ROW;
-    R.v[it] = *reinterpret_cast<const f32x4*>(wbase + (size_t)row * coutp + c4 * 4);
+  for (int it = 0; it < IT; ++it) {
+    const unsigned soff = 4u * (unsigned)((ch * (C::TAPS * C::KC) + it * WeightGeom<C>::ROWS_IT) * coutp);
+    const unsigned voff = (it == IT - 1) ? G.voff_last : G.voff;
+    R.v[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(G.rs, voff, soff, 0));
   }
 }
 
@@ -173,21 +213,66 @@ __device__ __forceinline__ void store_weights(float* wl, const WeightRegs<C>& R,
   }
 }
 
-// FULL: every output channel of the tile exists (m0 + MT <= Cout); RM: -1 no residual, else its Resample mode.
-template <class C, bool FULL, int RM, bool STATS>
+// Accumulators start at bias (+ resampled residual): the residual is fetched once, up front, with every load of the
+// tile in flight together and overlapping the first chunk's staging.  (Added in the epilogue it costs one
+// load -> wait -> store round trip per accumulator tile, ~3x the time of a store-only epilogue when both resident
+// workgroups of a CU are busy.)  MODE: 0 bias only, 1 residual at the output or half resolution, 2 residual at
+// double resolution (2x2 box filter, adm_blocks.py:75-77).  Out-of-range channels / pixels read clamped
+// addresses; they are never stored.
+template <class C, int MODE, bool FULL>
+__device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[C::TM][C::TN], int n, int m0, int y0,
+                                              int x0, int wm, int wn, int lane) {
+  const int sh = (MODE == 1 && p.res_mode == RS_UP) ? 1 : 0;
+  const unsigned Wr = (MODE == 2) ? p.W * 2 : (p.W >> sh);
+  const unsigned HWr = (MODE == 2) ? (unsigned)p.H * p.W * 4u : (unsigned)(p.H >> sh) * Wr;
+  // one descriptor for this sample's residual planes; lane part of the address in voffset, the per-register
+  // channel step in the scalar offset (the launcher checks Cout * HWr * 4 < 4 GiB)
+  __amdgpu_buffer_rsrc_t rs;
+  if (MODE != 0) rs = make_rsrc(p.res + (size_t)n * p.Cout * HWr, 4u * (unsigned)p.Cout * HWr);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias ? 4u * (unsigned)p.Cout : 0u);   // no bias: zero records
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) {
+    const int cbase = m0 + (wm * C::TM + i) * 32 + 4 * (lane >> 5);     // + (r&3) + 8*(r>>2)
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)   // channels past Cout are out of the descriptor's range and read as 0
+      bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, 4u * (unsigned)(cbase + (r & 3) + 8 * (r >> 2)), 0, 0));
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j) {
+      const int pix = (wn * C::TN + j) * 32 + (lane & 31);
+      const unsigned y = min(y0 + pix / C::PW, p.H - 1);
+      const unsigned x = min(x0 + pix % C::PW, p.W - 1);
+      const unsigned pixoff = (MODE == 2) ? (2u * y) * Wr + 2u * x : (y >> sh) * Wr + (x >> sh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        unsigned voff, soff;
+        if (FULL) { voff = 4u * ((unsigned)cbase * HWr + pixoff); soff = 4u * (unsigned)dr * HWr; }
+        else { voff = 4u * ((unsigned)min(cbase + dr, p.Cout - 1) * HWr + pixoff); soff = 0u; }
+        if (MODE == 0) {
+          acc[i][j][r] = bv[r];
+        } else if (MODE == 1) {
+          acc[i][j][r] = bv[r] + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+        } else {
+          const float q00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+          const float q01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4u, soff, 0));
+          const float q10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4u * Wr, soff, 0));
+          const float q11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4u * Wr + 4u, soff, 0));
+          acc[i][j][r] = bv[r] + 0.25f * ((q00 + q01) + (q10 + q11));
+        }
+      }
+    }
+  }
+}
+
+// FULL: every output channel of the tile exists (m0 + MT <= Cout).  Store-only: nothing here waits on memory.
+template <class C, bool FULL, bool STATS>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C::TM][C::TN], int n, int m0, int y0,
                                               int x0, int wm, int wn, int lane, float* red) {
   const size_t HW = (size_t)p.H * p.W;
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) {
     const int cbase = m0 + (wm * C::TM + i) * 32 + 4 * (lane >> 5);     // + (r&3) + 8*(r>>2)
-    float bv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cbase + (r & 3) + 8 * (r >> 2);
-      const int cc = FULL ? co : (co < p.Cout ? co : p.Cout - 1);
-      bv[r] = p.bias ? p.bias[cc] : 0.f;
-    }
     float gs1[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
@@ -195,29 +280,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
       const int y = y0 + pix / C::PW;
       const int x = x0 + pix % C::PW;
       if (y < p.H && x < p.W) {
-        float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = cbase + (r & 3) + 8 * (r >> 2);
-          const int cc = FULL ? co : (co < p.Cout ? co : p.Cout - 1);
-          const size_t plane = (size_t)n * p.Cout + cc;
-          if (RM == -1) {
-            rv[r] = 0.f;
-          } else if (RM == RS_NONE) {
-            rv[r] = p.res[plane * HW + (size_t)y * p.W + x];
-          } else if (RM == RS_UP) {
-            rv[r] = p.res[plane * (HW >> 2) + (size_t)(y >> 1) * (p.W >> 1) + (x >> 1)];
-          } else {
-            const int Wr = p.W * 2;
-            const float* q0 = p.res + plane * (HW * 4) + (size_t)(2 * y) * Wr + 2 * x;
-            rv[r] = 0.25f * ((q0[0] + q0[1]) + (q0[Wr] + q0[Wr + 1]));
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = cbase + (r & 3) + 8 * (r >> 2);
-          float v = acc[i][j][r] + bv[r];
-          if (RM != -1) v += rv[r];
+          const float v = acc[i][j][r];
           if (FULL || co < p.Cout) {
             p.out[((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x] = v;
             if (STATS) { gs1[r >> 2] += v; gs2[r >> 2] += v * v; }
@@ -261,12 +327,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   const int m0 = mt * C::MT;
 
   f32x16 acc[C::TM][C::TN];
-#pragma unroll
-  for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   int boff[C::TN];
 #pragma unroll
@@ -276,21 +336,49 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   }
   const int aoff = (lane >> 5) * C::MT + wm * C::TM * 32 + (lane & 31);
 
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
   TileGeom<C, RS> geom;
   make_geom<C, RS>(p, geom, y0, x0, tid);
   InputRegs<C, RS> xin;
   WeightRegs<C> win;
-  load_weights<C>(p.wpk, win, 0, m0, coutp, tid);
+  WeightGeom<C> wgeom;
+  make_wgeom<C>(p.wpk, wgeom, m0, coutp, nchunks, tid);
+  load_weights<C>(wgeom, win, 0, coutp);
   load_input<C, RS>(p, geom, xin, n, 0);
+  // after the first chunk's loads are issued: the residual tile streams in behind them
+  if (wave < C::NWAVE) {
+    if (m0 + C::MT <= p.Cout) {
+      if (!p.res) conv_init_acc<C, 0, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
+      else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
+      else conv_init_acc<C, 1, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    } else {
+      if (!p.res) conv_init_acc<C, 0, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
+      else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
+      else conv_init_acc<C, 1, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    }
+  }
 
+  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
+#ifdef MCEDM_CONV_TIMELINE   // per-phase cycle counters of the chunk loop (tools/conv_timeline.py); costs registers
+  unsigned long long seg[5] = {0, 0, 0, 0, 0}, tprev = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define MCEDM_STAMP(k) if (p.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg[k] += now_ - tprev; tprev = now_; }
+#else
+#define MCEDM_STAMP(k)
+#endif
   for (int ch = 0; ch < nchunks; ++ch) {
     store_weights<C>(wl, win, tid);
     store_input<C, RS>(p, geom, xl, xin, ch * C::KC, tid);
+    MCEDM_STAMP(0)
     __syncthreads();
-    if (ch + 1 < nchunks) {   // next chunk's global loads fly while this chunk's MFMAs run
-      load_weights<C>(p.wpk, win, ch + 1, m0, coutp, tid);
-      load_input<C, RS>(p, geom, xin, n, (ch + 1) * C::KC);
+    MCEDM_STAMP(1)
+    {   // next chunk's global loads fly while this chunk's MFMAs run.  Unconditional (the last iteration re-reads
+        // its own chunk and drops it): a guarded prefetch makes the loaded registers phis, which the compiler
+        // resolves with a vmcnt(0) + register copies right here, in front of the MFMA loop.
+      const int chn = ch + 1 < nchunks ? ch + 1 : ch;
+      load_weights<C>(wgeom, win, chn, coutp);
+      load_input<C, RS>(p, geom, xin, n, chn * C::KC);
     }
+    MCEDM_STAMP(2)
     if (wave < C::NWAVE) {
       // Register double-buffered operand fragments: the LDS reads of k-step s+1 are issued before the MFMAs
       // of k-step s.  The tap loop stays rolled (a fully unrolled chunk pushes the prefetch registers into
@@ -333,38 +421,34 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
         }
       }
     }
+    MCEDM_STAMP(3)
     __syncthreads();
+    MCEDM_STAMP(4)
   }
-  // ---- epilogue: + bias, + (resampled) residual, store NCHW.  Dispatch on wave-uniform conditions once, so
-  // that inside a variant the 16 residual loads of an accumulator tile are issued back to back (one wait)
-  // instead of one load -> wait -> store round trip per element.
+#ifdef MCEDM_CONV_TIMELINE
+  if (p.dbg && tid == 0) { for (int k = 0; k < 5; ++k) p.dbg[blockIdx.x * 16 + 8 + k] = seg[k]; }
+#endif
+  // ---- epilogue: store NCHW (+ the fused GroupNorm partial sums); bias and residual are already in acc
+  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
   const bool full = (m0 + C::MT <= p.Cout);
-  const int rm = p.res ? p.res_mode : -1;
   float* red = xl;            // the input tile is dead after the last chunk's closing barrier
   if (wave < C::NWAVE) {
     if (p.gsum) {
-      if (full) {
-        if (rm == -1) conv_epilogue<C, true, -1, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-        else if (rm == RS_NONE) conv_epilogue<C, true, RS_NONE, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-        else if (rm == RS_UP) conv_epilogue<C, true, RS_UP, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-        else conv_epilogue<C, true, RS_DOWN, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      } else {
-        if (rm == -1) conv_epilogue<C, false, -1, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-        else if (rm == RS_NONE) conv_epilogue<C, false, RS_NONE, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-        else if (rm == RS_UP) conv_epilogue<C, false, RS_UP, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-        else conv_epilogue<C, false, RS_DOWN, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      }
-    } else if (full) {
-      if (rm == -1) conv_epilogue<C, true, -1, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else if (rm == RS_NONE) conv_epilogue<C, true, RS_NONE, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else if (rm == RS_UP) conv_epilogue<C, true, RS_UP, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else conv_epilogue<C, true, RS_DOWN, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      if (full) conv_epilogue<C, true, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else conv_epilogue<C, false, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
     } else {
-      if (rm == -1) conv_epilogue<C, false, -1, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else if (rm == RS_NONE) conv_epilogue<C, false, RS_NONE, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else if (rm == RS_UP) conv_epilogue<C, false, RS_UP, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else conv_epilogue<C, false, RS_DOWN, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      if (full) conv_epilogue<C, true, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else conv_epilogue<C, false, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
     }
+  }
+  if (p.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p.dbg[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memrealtime();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.dbg[blockIdx.x * 16 + 4] = ((unsigned long long)xcc << 32) | hwid;
   }
   if (p.gsum) {               // wave-uniform: every wave of the workgroup reaches this barrier
     __syncthreads();
@@ -384,7 +468,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
 // RESAMPLED = false is the hot instantiation (no up/down sampling): keeping it in a kernel of its own gives
 // it its own register allocation (the 2x2-mean variant prefetches 4 source pixels per tile element).
 template <class C, bool RESAMPLED>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles,
+__global__ __launch_bounds__(256, RESAMPLED ? 2 : C::OCC) void conv_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles,
                                                            int nchunks, int coutp) {
   __shared__ __attribute__((aligned(16))) float xl[C::XL];
   __shared__ __attribute__((aligned(16))) float wl[C::WL];
@@ -469,9 +553,22 @@ int launch_pack_bias(const float* b, float* dst, int Cout, int qkv_heads, hipStr
   return MCEDM_OK;
 }
 
+static unsigned long long* g_dbg = nullptr;
+void set_conv_debug(unsigned long long* buf) { g_dbg = buf; }
+
 template <class C>
 static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
-  const ConvArgs& a = a_in;
+  ConvArgs a = a_in;
+  a.dbg = g_dbg;
+  a.coef_rows = 1;
+  if (!a.coef) {      // no input transform: one identity row, indexed with stride 0
+    static const Coef* ident[64] = {};     // per device
+    int dev = 0;
+    MCEDM_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device index %d out of range", dev); return MCEDM_ERR_INVALID; }
+    if (!ident[dev]) MCEDM_HIP_TRY(hipGetSymbolAddress((void**)&ident[dev], HIP_SYMBOL(k_identity_coef)));
+    a.coef = ident[dev]; a.coef_batch = 0; a.coef_rows = 0;
+  }
   const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
   const int mtiles = ceil_div(a.Cout, C::MT);
   const int nchunks = ceil_div(a.Ca + a.Cb, C::KC);
@@ -490,8 +587,10 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
                               (double)a.Cout * (a.Ca + a.Cb) * C::TAPS);
   ProfScope ps(name, flops, bytes, stream);
+  static int extra_lds = -1;     // diagnostics: MCEDM_CONV_EXTRA_LDS bytes of unused dynamic LDS lower the occupancy
+  if (extra_lds < 0) { const char* e = getenv("MCEDM_CONV_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
   if (a.resample == RS_NONE)
-    hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
+    hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)blocks), dim3(256), extra_lds, stream, a, tiles_x, tiles_y,
                        mtiles, nchunks, cout_padded(a.Cout));
   else
     hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
@@ -507,6 +606,9 @@ void set_conv_tile_override(int mt, int ph, int pw) { g_force_mt = mt; g_force_p
 template <int TAPS, int KC>
 static int dispatch(const ConvArgs& a, hipStream_t stream) {
   const int coutp = cout_padded(a.Cout);
+#ifdef MCEDM_CONV_ONE   // compile-time probe builds: only the dominant configuration
+  return launch_cfg<ConvCfg<128, 8, 32, 1, 4, 9, 8>>(a, stream);
+#else
   if (g_force_mt) {
     const int id = g_force_mt * 10000 + g_force_ph * 100 + g_force_pw;
     MCEDM_REQUIRE(coutp % g_force_mt == 0, "conv: forced MT=%d does not divide padded Cout=%d", g_force_mt, coutp);
@@ -541,6 +643,7 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
   if (coutp % 128 == 0 && blocks_for(128, 16, 16) >= want) return launch_cfg<ConvCfg<128, 16, 16, 1, 4, TAPS, KC>>(a, stream);
   if (coutp % 64 == 0 && blocks_for(64, 16, 16) >= want) return launch_cfg<ConvCfg<64, 16, 16, 1, 4, TAPS, KC>>(a, stream);
   return launch_cfg<ConvCfg<32, 16, 16, 1, 4, TAPS, KC>>(a, stream);
+#endif
 }
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {
@@ -551,6 +654,15 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {
   else if (a.resample == RS_DOWN) MCEDM_REQUIRE(a.Hs == a.H * 2 && a.Ws == a.W * 2, "conv: down-resample needs Hs = 2*H");
   else MCEDM_REQUIRE(a.Hs == a.H && a.Ws == a.W, "conv: source size mismatch");
   if (a.res && a.res_mode == RS_UP) MCEDM_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0, "conv: up residual needs even size");
+  // 32-bit buffer offsets: one channel plane and the packed weight table must each stay below 4 GiB
+  MCEDM_REQUIRE((unsigned long long)a.Hs * a.Ws * 4ull < (1ull << 32) &&
+                (unsigned long long)cout_padded(a.Cout) * (a.Ca + a.Cb + 16) * taps * 4ull < (1ull << 32),
+                "conv: plane or weight table exceeds the 4 GiB buffer range");
+  if (a.res) {
+    const unsigned long long rpix = a.res_mode == RS_DOWN ? 4ull * a.H * a.W : a.res_mode == RS_UP ? (a.H / 2ull) * (a.W / 2ull)
+                                                                                                    : 1ull * a.H * a.W;
+    MCEDM_REQUIRE(rpix * a.Cout * 4ull < (1ull << 32), "conv: one sample of the residual exceeds the 4 GiB buffer range");
+  }
   return taps == 9 ? dispatch<9, 8>(a, stream) : dispatch<1, 16>(a, stream);
 }
 

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmcedm_hip.so")
+LIB_PATH = os.environ.get("MCEDM_LIB") or os.path.join(_HERE, "libmcedm_hip.so")   # MCEDM_LIB: A/B builds
 MAX_LEVELS = 8
 
 # every symbol include/mcedm_hip.h declares
@@ -321,7 +321,8 @@ def _bind_ops():
 
 OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv",
               "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report",
-              "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd"]
+              "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd",
+              "mcedm_op_set_conv_debug"]
 
 
 def prof_enable(on: bool) -> None:
