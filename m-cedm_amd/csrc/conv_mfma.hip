@@ -614,6 +614,9 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
     MCEDM_REQUIRE(coutp % g_force_mt == 0, "conv: forced MT=%d does not divide padded Cout=%d", g_force_mt, coutp);
     switch (id) {
       case 1280832: return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);
+      case 1280816: return launch_cfg<ConvCfg<128, 8, 16, 1, 4, TAPS, KC>>(a, stream);
+      case 640816: return launch_cfg<ConvCfg<64, 8, 16, 1, 4, TAPS, KC>>(a, stream);
+      case 1280808: return launch_cfg<ConvCfg<128, 8, 8, 2, 2, TAPS, KC>>(a, stream);
       case 640832: return launch_cfg<ConvCfg<64, 8, 32, 1, 4, TAPS, KC>>(a, stream);
       case 320832: return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);
       case 1281616: return launch_cfg<ConvCfg<128, 16, 16, 1, 4, TAPS, KC>>(a, stream);
@@ -634,6 +637,11 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
   if ((long long)a.H * a.W <= 256 || a.W < 12) {          // <= 16x16 images: 8x8-pixel tiles
     if (coutp % 64 == 0) return launch_cfg<ConvCfg<64, 8, 8, 2, 2, TAPS, KC>>(a, stream);
     return launch_cfg<ConvCfg<32, 8, 8, 1, 2, TAPS, KC>>(a, stream);
+  }
+  if (TAPS == 9 && a.W >= 24 && (long long)a.H * a.W <= 1024) {   // 3x3 on ~32x32 images: half-width tiles, 3 workgroups/CU
+    if (coutp % 128 == 0 && blocks_for(128, 8, 16) >= want) return launch_cfg<ConvCfg<128, 8, 16, 1, 4, TAPS, KC>>(a, stream);
+    if (coutp % 64 == 0) return launch_cfg<ConvCfg<64, 8, 16, 1, 4, TAPS, KC>>(a, stream);
+    return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);
   }
   if (a.W >= 24) {
     if (coutp % 128 == 0 && blocks_for(128, 8, 32) >= want) return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mcedm_amd  # noqa
 from mcedm_amd import lib
 
-TILES = [(128, 8, 32), (64, 8, 32), (32, 8, 32), (128, 16, 16), (64, 16, 16), (32, 16, 16), (64, 8, 8), (32, 8, 8)]
+TILES = [(128, 8, 32), (64, 8, 32), (32, 8, 32), (128, 16, 16), (64, 16, 16), (32, 16, 16), (128, 8, 16), (64, 8, 16), (128, 8, 8), (64, 8, 8), (32, 8, 8)]
 SHAPES = [  # B, cin, cout, hw, k
     (32, 128, 128, 64, 3), (32, 128, 128, 32, 3), (32, 256, 128, 32, 3), (32, 128, 128, 16, 3), (32, 256, 128, 16, 3),
     (32, 256, 128, 32, 1), (32, 128, 384, 16, 1), (32, 128, 128, 16, 1),
@@ -14,7 +14,7 @@ SHAPES = [  # B, cin, cout, hw, k
 if len(sys.argv) > 1 and sys.argv[1] == "big":
     SHAPES = [(32, 128, 128, 128, 3), (32, 256, 128, 128, 3), (32, 128, 128, 64, 3), (32, 256, 128, 64, 3), (32, 256, 128, 128, 1),
               (32, 64, 64, 128, 3), (32, 128, 64, 128, 3)]
-    TILES = [(128, 8, 32), (128, 16, 16), (64, 8, 32), (64, 16, 16)]
+    TILES = [(128, 8, 32), (128, 16, 16), (128, 8, 16), (64, 8, 32), (64, 16, 16), (64, 8, 16)]
 for B, cin, cout, hw, k in SHAPES:
     x = torch.randn(B, cin, hw, hw, device="cuda")
     w = torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5
