@@ -213,11 +213,18 @@ int mcedm_op_gn_bwd(const float* dact, int resample, const float* xa, const floa
  * lse_scratch holds B*heads*T*2 floats. */
 int mcedm_op_attention_bwd(const float* qkv, const float* a, const float* da, float* dqkv, float* lse_scratch, int B,
                            int heads, int T, void* stream);
-/* Test hook: force the conv tile (channel tile mt in {32,64,128}, pixel tile ph x pw in {8x32,16x16,8x8});
+/* Test hook: force the conv tile (channel tile mt in {32,64,128}, pixel tile ph x pw in {8x32,8x16,16x16,8x8};
+ * (128,16,32) = the 8-wave kernel, 3x3 only);
  * (0,0,0) restores the size heuristic.  Process-global, not thread-safe. */
 int mcedm_op_set_conv_tile(int mt, int ph, int pw);
-/* Diagnostics: when buf != NULL every conv workgroup writes 8 x u64 at buf[8*blockIdx]: timestamps (10 ns units) at
- * start / first chunk / end of K loop / end of epilogue, and (XCC id << 32 | HW_ID).  NULL switches it off. */
+/* Selects the experimental 8-wave conv kernel (one 512-thread workgroup per CU, double-buffered LDS slabs) for the
+ * 3x3 layers large enough to give every CU a workgroup: 1 on, 0 off, -1 back to the default (env MCEDM_CONV8, else
+ * off).  Results are bit-identical to the default kernel.  Process-global, not thread-safe. */
+int mcedm_op_set_conv8(int enable);
+/* Diagnostics: when buf != NULL every conv workgroup writes 16 x u64 at buf[16*blockIdx]: [0..3] timestamps (10 ns
+ * units) at start / first chunk / end of K loop / end of epilogue, [4] (XCC id << 32 | HW_ID), [5..6] shader-clock
+ * counter at the K loop's ends, [8..] per-phase cycle sums (MCEDM_CONV_TIMELINE builds) or per-wave HW_ID (8-wave
+ * kernel).  NULL switches it off. */
 int mcedm_op_set_conv_debug(unsigned long long* buf);
 
 /* ---- measurement ---------------------------------------------------------------------------

@@ -83,6 +83,7 @@ struct ConvArgs {
 int launch_conv(const ConvArgs& a, int taps, hipStream_t stream);
 static inline int conv_max_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 7) / 8); }   // smallest pixel tile is 8x8
 void set_conv_tile_override(int mt, int ph, int pw);
+void set_conv8(int enable);   // 1 / 0, -1: default (env MCEDM_CONV8, else off)
 void set_conv_debug(unsigned long long* buf);   // test hook; (0,0,0) restores the heuristic
 // geometry the packer must use for a given (Cout, taps): tile height over Cout and K-chunk
 int conv_mt_for(int Cout);

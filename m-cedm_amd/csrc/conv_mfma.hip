@@ -21,9 +21,10 @@
 
 namespace mcedm {
 
-template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_>
+template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_, int NT_ = 256>
 struct ConvCfg {
   static constexpr int MT = MT_, PH = PH_, PW = PW_, WM = WM_, WN = WN_, TAPS = TAPS_, KC = KC_;
+  static constexpr int NT = NT_;              // threads per workgroup
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
   static constexpr int PITCH = PW + 2 * HALO;
   static constexpr int ROWS = PH + 2 * HALO;
@@ -37,7 +38,7 @@ struct ConvCfg {
   // resident workgroups per CU the kernel is compiled for: <= 64 accumulator registers leave room for a third wave
   // per SIMD (<= 168 VGPRs), which hides more of the staging phases (+5 % on the MT = 64 tiles)
   static constexpr int OCC = (TM * TN <= 4) ? 3 : 2;
-  static_assert(NWAVE >= 1 && NWAVE <= 4, "at most 4 compute waves per workgroup");
+  static_assert(NWAVE >= 1 && NWAVE <= NT / 64, "more compute waves than the workgroup has");
   static_assert(TM >= 1 && TN >= 1 && MT % (WM * 32) == 0 && NPIX % (WN * 32) == 0, "tile shape");
   static_assert(MT % 4 == 0 && KC % 2 == 0, "vector widths");
 };
@@ -63,7 +64,7 @@ __device__ __forceinline__ float apply_coef(float v, const Coef& c, int act) {
 template <class C, int RS>
 struct TileGeom {
   static constexpr int NL = (RS == RS_DOWN) ? 4 : 1;
-  static constexpr int SUB = (C::PLANE + 255) / 256;
+  static constexpr int SUB = (C::PLANE + C::NT - 1) / C::NT;
   unsigned boff[SUB][NL];   // clamped BYTE offsets inside one channel plane (the same for every channel)
   unsigned keep[SUB];       // all-ones: element lies inside the image; 0: it is conv zero padding
 };
@@ -79,7 +80,7 @@ template <class C, int RS>
 __device__ __forceinline__ void make_geom(const ConvArgs& p, TileGeom<C, RS>& G, int y0, int x0, int tid) {
 #pragma unroll
   for (int sub = 0; sub < TileGeom<C, RS>::SUB; ++sub) {
-    const int e = tid + sub * 256;
+    const int e = tid + sub * C::NT;
     const int r = e / C::PITCH;
     const int c = e - r * C::PITCH;
     const int y = y0 + r - C::HALO;
@@ -103,10 +104,10 @@ __device__ Coef k_identity_coef = {0.f, 1.f, 0.f, 0.f};   // the table of a conv
 template <class C, int RS>
 struct InputRegs {
   float raw[C::KC][TileGeom<C, RS>::SUB][TileGeom<C, RS>::NL];
-  Coef cf[C::KC];
+  Coef cf[C::KC];      // unused (and optimised away) when the transform rows are read from LDS at commit
 };
 
-template <class C, int RS>
+template <class C, int RS, bool COEF_REGS = true>
 __device__ __forceinline__ void load_input(const ConvArgs& p, const TileGeom<C, RS>& G, InputRegs<C, RS>& R, int n,
                                            int c0) {
   const int Cin = p.Ca + p.Cb;
@@ -123,7 +124,7 @@ __device__ __forceinline__ void load_input(const ConvArgs& p, const TileGeom<C, 
     const float* plane = chan_ok ? src + ((size_t)n * CC + cc) * src_plane : safe;
     // Unconditional load (a guarded one costs a vmcnt(0) round trip per channel): padded channels read a clamped row
     // and are zeroed in store_input; without a table the launcher points coef at one identity row (coef_rows == 0).
-    R.cf[cil] = p.coef[((p.coef_batch ? (size_t)n * Cin : 0) + (ci < Cin ? ci : Cin - 1)) * p.coef_rows];
+    if (COEF_REGS) R.cf[cil] = p.coef[((p.coef_batch ? (size_t)n * Cin : 0) + (ci < Cin ? ci : Cin - 1)) * p.coef_rows];
 #pragma unroll
     for (int sub = 0; sub < TileGeom<C, RS>::SUB; ++sub)
 #pragma unroll
@@ -133,8 +134,13 @@ __device__ __forceinline__ void load_input(const ConvArgs& p, const TileGeom<C, 
 
 template <class C, int RS>
 __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C, RS>& G, float* xl,
-                                            const InputRegs<C, RS>& R, int c0, int tid) {
+                                            const InputRegs<C, RS>& R0, int c0, int tid, const Coef* cfl = nullptr) {
   const int Cin = p.Ca + p.Cb;
+  InputRegs<C, RS> R = R0;
+  if (cfl) {      // rows of this sample staged in LDS by the caller (wave-uniform broadcast reads)
+#pragma unroll
+    for (int cil = 0; cil < C::KC; ++cil) R.cf[cil] = cfl[c0 + cil < Cin ? c0 + cil : Cin - 1];
+  }
 #pragma unroll
   for (int cil = 0; cil < C::KC; ++cil) {
     const int ci = c0 + cil;
@@ -153,7 +159,7 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
       // zero padding / padded channels as a bit mask: straight-line code (a select makes the compiler branch
       // around the SiLU, ~30 tiny basic blocks per chunk)
       v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (G.keep[sub] & ckeep));
-      if ((sub + 1) * 256 <= C::PLANE || tid + sub * 256 < C::PLANE) xl[cil * C::PLANE + tid + sub * 256] = v;
+      if ((sub + 1) * C::NT <= C::PLANE || tid + sub * C::NT < C::PLANE) xl[cil * C::PLANE + tid + sub * C::NT] = v;
     }
     // one channel at a time: left alone, the scheduler interleaves all KC SiLU chains of this straight-line code
     // and pays for the extra live values with accumulator spills
@@ -165,17 +171,17 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
 template <class C>
 struct WeightRegs {
   static constexpr int NV4 = C::WL / 4;
-  static constexpr int IT = (NV4 + 255) / 256;
+  static constexpr int IT = (NV4 + C::NT - 1) / C::NT;
   f32x4 v[IT];   // native vector type: HIP's float4 class defeats SROA here and lands in scratch
 };
 
-// 256 threads fetch 256 float4 per step = ROWS_IT whole rows of the slab; the per-lane byte offset is the same
+// NT threads fetch NT float4 per step = ROWS_IT whole rows of the slab; the per-lane byte offset is the same
 // for every step and chunk, the (chunk, step) part is a scalar offset.
 template <class C>
 struct WeightGeom {
   static constexpr int V4_PER_ROW = C::MT / 4;
-  static constexpr int ROWS_IT = 256 / V4_PER_ROW;
-  static_assert(256 % V4_PER_ROW == 0, "a staging step covers whole slab rows");
+  static constexpr int ROWS_IT = C::NT / V4_PER_ROW;
+  static_assert(C::NT % V4_PER_ROW == 0, "a staging step covers whole slab rows");
   unsigned voff;        // byte offset of this lane's float4 inside a step
   unsigned voff_last;   // the same for the last step, clamped into the slab when that step is partial
   __amdgpu_buffer_rsrc_t rs;
@@ -186,7 +192,7 @@ __device__ __forceinline__ void make_wgeom(const float* wpk, WeightGeom<C>& G, i
   constexpr int V4 = WeightGeom<C>::V4_PER_ROW, NV4 = WeightRegs<C>::NV4, IT = WeightRegs<C>::IT;
   const int row = tid / V4, c4 = tid - row * V4;
   G.voff = 4u * (unsigned)(row * coutp + c4 * 4);
-  int il = tid + (IT - 1) * 256;
+  int il = tid + (IT - 1) * C::NT;
   if (il >= NV4) il = NV4 - 1;
   const int rl = il / V4 - (IT - 1) * WeightGeom<C>::ROWS_IT, cl = il % V4;
   G.voff_last = 4u * (unsigned)(rl * coutp + cl * 4);
@@ -208,7 +214,7 @@ template <class C>
 __device__ __forceinline__ void store_weights(float* wl, const WeightRegs<C>& R, int tid) {
 #pragma unroll
   for (int it = 0; it < WeightRegs<C>::IT; ++it) {
-    const int i = tid + it * 256;
+    const int i = tid + it * C::NT;
     if (i < WeightRegs<C>::NV4) reinterpret_cast<f32x4*>(wl)[i] = R.v[it];
   }
 }
@@ -309,6 +315,52 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
   }
 }
 
+// One K chunk (KC input channels x all taps) of the implicit GEMM out of the LDS slabs.
+template <class C>
+__device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32x16 (&acc)[C::TM][C::TN], int aoff,
+                                           const int (&boff)[C::TN]) {
+  // Register double-buffered operand fragments: the LDS reads of k-step s+1 are issued before the MFMAs
+  // of k-step s.  The tap loop stays rolled (a fully unrolled chunk pushes the prefetch registers into
+  // scratch); the fragment for the next tap's first k-step is fetched at the end of the current tap.
+  float fa[2][C::TM], fb[2][C::TN];
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i) fa[0][i] = wl[aoff + i * 32];
+#pragma unroll
+  for (int j = 0; j < C::TN; ++j) fb[0][j] = xl[boff[j]];
+#pragma unroll 1
+  for (int tap = 0; tap < C::TAPS; ++tap) {
+    const int toff = (C::TAPS == 9) ? (tap / 3) * C::PITCH + (tap % 3) : 0;
+    const int tn = (tap + 1 < C::TAPS) ? tap + 1 : tap;         // clamped: the last prefetch is discarded
+    const int toff_n = (C::TAPS == 9) ? (tn / 3) * C::PITCH + (tn % 3) : 0;
+    const float* wt = wl + aoff + tap * C::KC * C::MT;
+    const float* wt_n = wl + aoff + tn * C::KC * C::MT;
+#pragma unroll
+    for (int kk = 0; kk < C::KC / 2; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < C::KC / 2) {
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) fa[nxt][i] = wt[2 * (kk + 1) * C::MT + i * 32];
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) fb[nxt][j] = xl[boff[j] + toff + 2 * (kk + 1) * C::PLANE];
+      } else {
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) fa[nxt][i] = wt_n[i * 32];
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) fb[nxt][j] = xl[boff[j] + toff_n];
+      }
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      // pin the order: this step's LDS reads (next fragments) first, then this step's MFMAs, so the reads'
+      // latency hides under TM*TN * 64 cycles of matrix work and the wait before the MFMAs is a counted one
+      __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
+    }
+  }
+}
+
 template <class C, int RS>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* wl, int tiles_x, int tiles_y,
                                           int mtiles, int nchunks, int coutp) {
@@ -379,48 +431,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
       load_input<C, RS>(p, geom, xin, n, chn * C::KC);
     }
     MCEDM_STAMP(2)
-    if (wave < C::NWAVE) {
-      // Register double-buffered operand fragments: the LDS reads of k-step s+1 are issued before the MFMAs
-      // of k-step s.  The tap loop stays rolled (a fully unrolled chunk pushes the prefetch registers into
-      // scratch); the fragment for the next tap's first k-step is fetched at the end of the current tap.
-      float fa[2][C::TM], fb[2][C::TN];
-#pragma unroll
-      for (int i = 0; i < C::TM; ++i) fa[0][i] = wl[aoff + i * 32];
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) fb[0][j] = xl[boff[j]];
-#pragma unroll 1
-      for (int tap = 0; tap < C::TAPS; ++tap) {
-        const int toff = (C::TAPS == 9) ? (tap / 3) * C::PITCH + (tap % 3) : 0;
-        const int tn = (tap + 1 < C::TAPS) ? tap + 1 : tap;         // clamped: the last prefetch is discarded
-        const int toff_n = (C::TAPS == 9) ? (tn / 3) * C::PITCH + (tn % 3) : 0;
-        const float* wt = wl + aoff + tap * C::KC * C::MT;
-        const float* wt_n = wl + aoff + tn * C::KC * C::MT;
-#pragma unroll
-        for (int kk = 0; kk < C::KC / 2; ++kk) {
-          const int cur = kk & 1, nxt = cur ^ 1;
-          if (kk + 1 < C::KC / 2) {
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i) fa[nxt][i] = wt[2 * (kk + 1) * C::MT + i * 32];
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j) fb[nxt][j] = xl[boff[j] + toff + 2 * (kk + 1) * C::PLANE];
-          } else {
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i) fa[nxt][i] = wt_n[i * 32];
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j) fb[nxt][j] = xl[boff[j] + toff_n];
-          }
-#pragma unroll
-          for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < C::TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-          // pin the order: this step's LDS reads (next fragments) first, then this step's MFMAs, so the reads'
-          // latency hides under TM*TN * 64 cycles of matrix work and the wait before the MFMAs is a counted one
-          __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
-        }
-      }
-    }
+    if (wave < C::NWAVE) mfma_chunk<C>(xl, wl, acc, aoff, boff);
     MCEDM_STAMP(3)
     __syncthreads();
     MCEDM_STAMP(4)
@@ -475,6 +486,168 @@ __global__ __launch_bounds__(256, RESAMPLED ? 2 : C::OCC) void conv_mfma_kernel(
   if (!RESAMPLED) conv_body<C, RS_NONE>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
   else if (p.resample == RS_UP) conv_body<C, RS_UP>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
   else conv_body<C, RS_DOWN>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
+}
+
+// Weight slab global -> LDS without passing through VGPRs (LDS-DMA, 16 bytes per lane): the LDS image is the linear
+// [tap][ci_local][MT] slab, float4 number i written by thread i, i.e. lane-linear per wave as the instruction needs.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+template <class C>
+__device__ __forceinline__ void dma_weights(const float* wpk, float* wl, int ch, int m0, int coutp, int tid) {
+  constexpr int V4 = C::MT / 4, NV4 = C::WL / 4, IT = (NV4 + C::NT - 1) / C::NT;
+  static_assert(NV4 % 64 == 0, "whole waves in the last staging step");
+  const float* wbase = wpk + (size_t)ch * (C::TAPS * C::KC) * coutp + m0;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = tid + it * C::NT;
+    if (i < NV4) {      // wave-granular: a wave is either entirely inside the slab or issues nothing
+      const int row = i / V4, c4 = i - row * V4;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wbase + (size_t)row * coutp + c4 * 4), (lds_ptr_t)(wl + i * 4), 16, 0, 0);
+    }
+  }
+}
+
+// ---- 8-wave variant for the large layers ------------------------------------------------------------
+// One 512-thread workgroup per CU computes MT = 128 channels x (16 x 32) pixels: the work of two workgroups of the
+// kernel above, sharing one weight slab.  The LDS slabs are double-buffered, so a chunk needs ONE barrier, and the two
+// wave groups (waves 0-3 / 4-7, one of each per SIMD) run the chunk in opposite order:
+//     group 0:  MFMA(chunk c)  ->  commit(chunk c+1) + issue loads(chunk c+2)
+//     group 1:  commit(chunk c+1) + issue loads(chunk c+2)  ->  MFMA(chunk c)
+// so on every SIMD one wave has matrix work while the other stages, by construction instead of by the luck of two
+// independent workgroups drifting apart, and both groups meet at every barrier: no lag between them, no tail.
+// Arithmetic (accumulation order per output element) and the GroupNorm partial sums (emitted per 8 x 32 sub-tile,
+// reduced in the 4-wave order of the kernel above) are bit-identical to conv_mfma_kernel<128, 8, 32>, so choosing
+// between the two by batch size does not break exact batch shardability.
+template <class C>
+__global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles, int nchunks,
+                                                           int coutp) {
+  static_assert(C::NT == 512 && C::WM == 1 && C::WN == 8 && C::PH == 16, "8-wave tile shape");
+  extern __shared__ __attribute__((aligned(16))) float lds8[];
+  constexpr int BUF = C::WL + C::XL;          // floats per buffer: weight slab, then input tile
+  constexpr int NLOADS = C::KC * TileGeom<C, RS_NONE>::SUB;   // input loads a thread issues per chunk
+  Coef* cfl = reinterpret_cast<Coef*>(lds8 + 2 * BUF);      // this sample's Ca + Cb transform rows
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave;                        // WM == 1
+  const int group = wave >> 2;
+
+  int bid = blockIdx.x;
+  const int mt = bid % mtiles; bid /= mtiles;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * C::PH, x0 = tx * C::PW;
+  const int m0 = mt * C::MT;
+
+  f32x16 acc[C::TM][C::TN];
+  int boff[C::TN];
+#pragma unroll
+  for (int j = 0; j < C::TN; ++j) {
+    const int pix = (wn * C::TN + j) * 32 + (lane & 31);
+    boff[j] = (lane >> 5) * C::PLANE + (pix / C::PW) * C::PITCH + (pix % C::PW);
+  }
+  const int aoff = (lane >> 5) * C::MT + (lane & 31);
+
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
+  if (p.dbg && lane == 0) {     // which SIMD each wave landed on
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    p.dbg[blockIdx.x * 16 + 8 + wave] = hw;
+  }
+  TileGeom<C, RS_NONE> geom;
+  make_geom<C, RS_NONE>(p, geom, y0, x0, tid);
+  InputRegs<C, RS_NONE> xin;
+  dma_weights<C>(p.wpk, lds8, 0, m0, coutp, tid);             // chunk 0 weights -> buffer 0
+  load_input<C, RS_NONE, false>(p, geom, xin, n, 0);
+  {
+    const int Cin = p.Ca + p.Cb;
+    for (int i = tid; i < Cin; i += C::NT) cfl[i] = p.coef[((p.coef_batch ? (size_t)n * Cin : 0) + i) * p.coef_rows];
+  }
+  if (m0 + C::MT <= p.Cout) {
+    if (!p.res) conv_init_acc<C, 0, true>(p, acc, n, m0, y0, x0, 0, wn, lane);
+    else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, true>(p, acc, n, m0, y0, x0, 0, wn, lane);
+    else conv_init_acc<C, 1, true>(p, acc, n, m0, y0, x0, 0, wn, lane);
+  } else {
+    if (!p.res) conv_init_acc<C, 0, false>(p, acc, n, m0, y0, x0, 0, wn, lane);
+    else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, false>(p, acc, n, m0, y0, x0, 0, wn, lane);
+    else conv_init_acc<C, 1, false>(p, acc, n, m0, y0, x0, 0, wn, lane);
+  }
+  __syncthreads();            // transform rows visible (also drains the chunk-0 weight DMA)
+  // chunk 0 input -> buffer 0; chunk 1 input -> registers (clamped re-reads past the end are staged, never consumed)
+  store_input<C, RS_NONE>(p, geom, lds8 + C::WL, xin, 0, tid, cfl);
+  load_input<C, RS_NONE, false>(p, geom, xin, n, (1 < nchunks ? 1 : 0) * C::KC);
+  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    float* wl_c = lds8 + (ch & 1) * BUF;
+    float* wl_n = lds8 + ((ch & 1) ^ 1) * BUF;
+    const int c1 = ch + 1 < nchunks ? ch + 1 : ch;      // chunk held in the staging registers
+    const int c2 = ch + 2 < nchunks ? ch + 2 : c1;      // chunk to fetch next
+    // Per thread and iteration the VMEM order is: weight DMA (chunk c1 -> the other buffer), then NLOADS input loads
+    // (chunk c2 -> registers).  The closing wait retires the DMA and leaves the input loads in flight.
+    // (the MFMA code exists once; only the short staging block is duplicated around it: two full copies of the
+    // iteration in an if/else made the register allocator spill the staging registers inside the loop)
+    if (group == 0) {
+      dma_weights<C>(p.wpk, wl_n, c1, m0, coutp, tid);
+    } else {
+      store_input<C, RS_NONE>(p, geom, wl_n + C::WL, xin, c1 * C::KC, tid, cfl);
+      __builtin_amdgcn_sched_barrier(0);
+      dma_weights<C>(p.wpk, wl_n, c1, m0, coutp, tid);
+      __builtin_amdgcn_sched_barrier(0);
+      load_input<C, RS_NONE, false>(p, geom, xin, n, c2 * C::KC);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk<C>(wl_c + C::WL, wl_c, acc, aoff, boff);
+    __builtin_amdgcn_sched_barrier(0);
+    if (group == 0) {
+      store_input<C, RS_NONE>(p, geom, wl_n + C::WL, xin, c1 * C::KC, tid, cfl);
+      load_input<C, RS_NONE, false>(p, geom, xin, n, c2 * C::KC);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dropped tail prefetch must not land in reused registers
+
+  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
+  const bool full = (m0 + C::MT <= p.Cout);
+  float* red = lds8;          // every slab is dead after the last chunk's barrier
+  if (p.gsum) {
+    if (full) conv_epilogue<C, true, true>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
+    else conv_epilogue<C, false, true>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
+  } else {
+    if (full) conv_epilogue<C, true, false>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
+    else conv_epilogue<C, false, false>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
+  }
+  if (p.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p.dbg[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memrealtime();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.dbg[blockIdx.x * 16 + 4] = ((unsigned long long)xcc << 32) | hwid;
+  }
+  if (p.gsum) {
+    __syncthreads();
+    // two 8 x 32 sub-tile records (rows 0-7: waves 0-3, rows 8-15: waves 4-7), each the 4-wave sum of the 4-wave kernel
+    constexpr int NG2 = C::MT / 4 * 2;
+    if (tid < 2 * NG2) {
+      const int sub = tid / NG2, e = tid - sub * NG2;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += red[(sub * 4 + w) * NG2 + e];
+      const int g = m0 / 4 + e / 2;
+      const int ngroups = (p.Cout + 3) / 4;
+      const int tiles_y8 = (p.H + 7) / 8;
+      const int ty8 = 2 * ty + sub;
+      if (g < ngroups && ty8 < tiles_y8)
+        p.gsum[(((size_t)n * (tiles_x * tiles_y8) + ty8 * tiles_x + tx) * ngroups + g) * 2 + (e & 1)] = t;
+    }
+  }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -600,6 +773,53 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   return MCEDM_OK;
 }
 
+typedef ConvCfg<128, 16, 32, 1, 8, 9, 8, 512> Conv8Cfg;
+static int g_conv8 = -1;     // MCEDM_CONV8=1 selects the 8-wave kernel for the large layers (off: it only ties)
+
+static int launch_conv8(const ConvArgs& a_in, hipStream_t stream) {
+  typedef Conv8Cfg C;
+  ConvArgs a = a_in;
+  a.dbg = g_dbg;
+  a.coef_rows = 1;
+  if (!a.coef) {
+    static const Coef* ident[64] = {};
+    int dev = 0;
+    MCEDM_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device index %d out of range", dev); return MCEDM_ERR_INVALID; }
+    if (!ident[dev]) MCEDM_HIP_TRY(hipGetSymbolAddress((void**)&ident[dev], HIP_SYMBOL(k_identity_coef)));
+    a.coef = ident[dev]; a.coef_batch = 0; a.coef_rows = 0;
+  }
+  const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
+  const int mtiles = ceil_div(a.Cout, C::MT);
+  const int nchunks = ceil_div(a.Ca + a.Cb, C::KC);
+  const long long blocks = (long long)a.B * tiles_x * tiles_y * mtiles;
+  constexpr int lds_max = 160 * 1024;
+  const int lds_bytes = 2 * (C::WL + C::XL) * (int)sizeof(float) + (a.Ca + a.Cb) * (int)sizeof(Coef);
+  static bool attr_set[64] = {};
+  {
+    int dev = 0;
+    MCEDM_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+      MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv8_mfma_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+      attr_set[dev] = true;
+    }
+  }
+  static char name[96];
+  if (prof_enabled()) snprintf(name, sizeof(name), "conv8_mfma_kernel<ConvCfg<128, 16, 32, 1, 8, 9, 8, 512>>");
+  const double px = (double)a.B * a.H * a.W;
+  const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
+  const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
+                              (double)a.Cout * (a.Ca + a.Cb) * C::TAPS);
+  ProfScope ps(name, flops, bytes, stream);
+  hipLaunchKernelGGL((conv8_mfma_kernel<C>), dim3((unsigned)blocks), dim3(512), lds_bytes, stream, a, tiles_x, tiles_y, mtiles,
+                     nchunks, cout_padded(a.Cout));
+  MCEDM_LAUNCH_CHECK("conv8_mfma_kernel");
+  if (a.gsum_tiles) *a.gsum_tiles = tiles_x * ceil_div(a.H, 8);     // records are per 8 x 32 sub-tile
+  return MCEDM_OK;
+}
+
+void set_conv8(int enable) { g_conv8 = enable; }
+
 static int g_force_mt = 0, g_force_ph = 0, g_force_pw = 0;   // test hook (mcedm_op_set_conv_tile); 0 = heuristic
 void set_conv_tile_override(int mt, int ph, int pw) { g_force_mt = mt; g_force_ph = ph; g_force_pw = pw; }
 
@@ -613,6 +833,9 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
     const int id = g_force_mt * 10000 + g_force_ph * 100 + g_force_pw;
     MCEDM_REQUIRE(coutp % g_force_mt == 0, "conv: forced MT=%d does not divide padded Cout=%d", g_force_mt, coutp);
     switch (id) {
+      case 1281632:
+        MCEDM_REQUIRE(TAPS == 9 && a.resample == RS_NONE && a.Ca + a.Cb <= 2048, "conv: the 8-wave kernel is 3x3, not resampled");
+        return launch_conv8(a, stream);
       case 1280832: return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);
       case 1280816: return launch_cfg<ConvCfg<128, 8, 16, 1, 4, TAPS, KC>>(a, stream);
       case 640816: return launch_cfg<ConvCfg<64, 8, 16, 1, 4, TAPS, KC>>(a, stream);
@@ -644,6 +867,11 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
     return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);
   }
   if (a.W >= 24) {
+    if (g_conv8 < 0) { const char* e = getenv("MCEDM_CONV8"); g_conv8 = e ? atoi(e) : 0; }
+    // experimental 8-wave kernel (needs about one workgroup per CU); results are bit-identical to <128, 8, 32>
+    if (g_conv8 && TAPS == 9 && a.resample == RS_NONE && coutp % 128 == 0 && a.Ca + a.Cb <= 2048 &&
+        blocks_for(128, 16, 32) >= 224)
+      return launch_conv8(a, stream);
     if (coutp % 128 == 0 && blocks_for(128, 8, 32) >= want) return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);
     if (coutp % 64 == 0 && blocks_for(64, 8, 32) >= want) return launch_cfg<ConvCfg<64, 8, 32, 1, 4, TAPS, KC>>(a, stream);
     return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);

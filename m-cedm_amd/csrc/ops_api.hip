@@ -98,6 +98,11 @@ extern "C" int mcedm_op_attention_bwd(const float* qkv, const float* a, const fl
   return launch_attention_bwd(qkv, a, da, dqkv, lse_scratch, B, heads, T, (hipStream_t)stream);
 }
 
+extern "C" int mcedm_op_set_conv8(int enable) {
+  set_conv8(enable);
+  return MCEDM_OK;
+}
+
 extern "C" int mcedm_op_set_conv_debug(unsigned long long* buf) {
   set_conv_debug(buf);
   return MCEDM_OK;

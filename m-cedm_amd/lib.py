@@ -322,7 +322,7 @@ def _bind_ops():
 OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv",
               "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report",
               "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd",
-              "mcedm_op_set_conv_debug"]
+              "mcedm_op_set_conv_debug", "mcedm_op_set_conv8"]
 
 
 def prof_enable(on: bool) -> None:
@@ -346,6 +346,13 @@ def set_conv_tile(mt: int = 0, ph: int = 0, pw: int = 0) -> None:
     lib = _bind_ops()
     lib.mcedm_op_set_conv_tile.argtypes = [C.c_int, C.c_int, C.c_int]
     check(lib.mcedm_op_set_conv_tile(mt, ph, pw), "set_conv_tile")
+def set_conv8(enable: int = -1) -> None:
+    """Select the experimental 8-wave conv kernel (1 / 0; -1 = default)."""
+    lib = _bind_ops()
+    lib.mcedm_op_set_conv8.argtypes = [C.c_int]
+    check(lib.mcedm_op_set_conv8(int(enable)), "set_conv8")
+
+
 RS_NONE, RS_UP, RS_DOWN = 0, 1, 2
 
 

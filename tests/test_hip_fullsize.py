@@ -59,6 +59,21 @@ def test_sampler_batch_shard_invariance_determinism_and_observed_entries(net):
     assert float(full[:, 0].cpu()[~obs].std()) > 1e-3, "sampled entries must not be degenerate"
 
 
+def test_eight_wave_conv_kernel_is_bit_identical(net):
+    # the experimental 8-wave kernel (fused GroupNorm partial sums included) must not change a single bit
+    lib, plan, packed, _ = net
+    B = 8
+    cond, m, init = inputs(B, seed=3)
+    sd = lib.sampler_desc(orc.SamplerParams(timesteps=2))
+    base = plan.sample(packed, sd, cond.cuda(), m.cuda(), init.cuda(), None)
+    lib.set_conv8(1)
+    try:
+        eight = plan.sample(packed, sd, cond.cuda(), m.cuda(), init.cuda(), None)
+    finally:
+        lib.set_conv8(-1)
+    assert torch.equal(base, eight)
+
+
 def test_conv_linearity_full_size(net):
     lib, *_ = net
     g = torch.Generator().manual_seed(1)

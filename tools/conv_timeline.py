@@ -19,6 +19,7 @@ for _ in range(12):   # steady state (clocks, caches): every launch overwrites t
 torch.cuda.synchronize()
 l.mcedm_op_set_conv_debug(None)
 d = dbg.cpu().numpy().reshape(nb, 16)
+d = d[d[:, 0] != 0]; nb = len(d)   # the 8-wave kernel launches fewer, larger workgroups
 if os.path.isdir("gpurun_out"): np.save("gpurun_out/timeline.npy", d)
 t0 = d[:, 0].min()
 st, pro, loop, end = [(d[:, i] - t0) / 100.0 for i in range(4)]   # microseconds
@@ -30,6 +31,9 @@ clk = (d[:, 6] - d[:, 5]) / ((d[:, 2] - d[:, 1]) * 10e-9) / 1e9
 print(f"shader clock inside the K loop: median {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f}); MFMA-bound K loop at that clock: {2 * (cin // 8) * 18432 / np.median(clk) / 1e3:.1f} us")
 nch = cin // 8
 print("per-chunk cycles (wave 0 of each WG): " + "  ".join(f"{nm} {np.mean(d[:, 8 + k]) / nch:.0f}" for k, nm in enumerate(["commit", "barrier1", "load-issue", "mfma-loop", "barrier2"])))
+if d[:, 8:16].max() < (1 << 32) and d[0, 15] != 0:
+    for i in (0, 1, 2):
+        print("wave -> (simd, wave slot):", [((int(h) >> 4) & 3, int(h) & 15) for h in d[i, 8:16]])
 order = np.argsort(st)
 for k in (0, 255, 511, 512, 767, 1023, 1535, 2047):
     i = order[k]; print(f"  wg#{k:4d} by start: start {st[i]:7.1f} loop_begin {pro[i]:7.1f} loop_end {loop[i]:7.1f} end {end[i]:7.1f}  cu {d[i,4] & 0xffffffff:#x} xcc {d[i,4] >> 32}")

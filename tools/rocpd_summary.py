@@ -60,8 +60,22 @@ def traffic(fdb, wdb, out):
               f"  write {v['write_bytes'] / 1e6:8.1f} MB")
 
 
+def counters(dbs):
+    """print the per-launch average of every counter in the given PMC result databases, per kernel"""
+    for db in dbs:
+        c = sqlite3.connect(db)
+        agg = collections.defaultdict(list)
+        for k, name, v in c.execute("select kernel_name, counter_name, value from counters_collection"):
+            agg[(k.split("(")[0][-60:], name)].append(v)
+        for (k, name), v in sorted(agg.items()):
+            if len(v) >= 3 and "conv" in k:
+                print(f"{k:60s} {name:32s} n={len(v):4d} avg {sum(v) / len(v):16.1f}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        counters(sys.argv[2:])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])
