@@ -650,6 +650,57 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
   }
 }
 
+// ---- output convolution (Cout <= 4) -------------------------------------------------------------------
+// The network's last 3x3 conv maps ch -> out_channels (2): on the matrix path it would fill 2 of the 32 rows of an MFMA
+// tile.  Here each thread owns one pixel of a 16 x 16 tile and CO accumulators; the staged (transformed) halo tile is
+// the B operand as above, the weights are wave-uniform scalar loads (s_load -> SGPR operands of v_fmac).  The kernel
+// is bound by reading its input once from HBM.  fmaf chain over (channel, tap): deterministic, batch independent.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(ConvArgs p, const float* __restrict__ wpk,
+                                                              const float* __restrict__ bias, int tiles_x, int tiles_y,
+                                                              int nchunks, int coutp) {
+  typedef ConvCfg<32, 16, 16, 1, 4, 9, 8> C;      // geometry only (16 x 16 pixels + halo, 8 channels per chunk)
+  __shared__ __attribute__((aligned(16))) float xl[C::XL];
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * C::PH, x0 = tx * C::PW;
+  const int py = tid / C::PW, px = tid % C::PW;
+
+  TileGeom<C, RS_NONE> geom;
+  make_geom<C, RS_NONE>(p, geom, y0, x0, tid);
+  InputRegs<C, RS_NONE> xin;
+  load_input<C, RS_NONE>(p, geom, xin, n, 0);
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = (bias && co < p.Cout) ? bias[co] : 0.f;
+  const float* xp = xl + py * C::PITCH + px;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    store_input<C, RS_NONE>(p, geom, xl, xin, ch * C::KC, tid);
+    __syncthreads();
+    load_input<C, RS_NONE>(p, geom, xin, n, (ch + 1 < nchunks ? ch + 1 : ch) * C::KC);
+    const float* wc = wpk + (size_t)ch * (9 * C::KC) * coutp;      // [tap][ci_local][coutp]
+#pragma unroll
+    for (int cil = 0; cil < C::KC; ++cil) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float x = xp[cil * C::PLANE + (tap / 3) * C::PITCH + (tap % 3)];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(x, wc[(tap * C::KC + cil) * coutp + co], acc[co]);
+      }
+    }
+    __syncthreads();
+  }
+  const int y = y0 + py, x = x0 + px;
+  if (y < p.H && x < p.W) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+      if (co < p.Cout) p.out[((size_t)n * p.Cout + co) * ((size_t)p.H * p.W) + (size_t)y * p.W + x] = acc[co];
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 // host side
 int conv_kc_for(int taps) { return taps == 9 ? 8 : 16; }
@@ -820,6 +871,36 @@ static int launch_conv8(const ConvArgs& a_in, hipStream_t stream) {
 
 void set_conv8(int enable) { g_conv8 = enable; }
 
+static int launch_small_cout(const ConvArgs& a_in, hipStream_t stream) {
+  typedef ConvCfg<32, 16, 16, 1, 4, 9, 8> C;
+  ConvArgs a = a_in;
+  a.dbg = nullptr;
+  a.coef_rows = 1;
+  if (!a.coef) {
+    static const Coef* ident[64] = {};
+    int dev = 0;
+    MCEDM_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device index %d out of range", dev); return MCEDM_ERR_INVALID; }
+    if (!ident[dev]) MCEDM_HIP_TRY(hipGetSymbolAddress((void**)&ident[dev], HIP_SYMBOL(k_identity_coef)));
+    a.coef = ident[dev]; a.coef_batch = 0; a.coef_rows = 0;
+  }
+  const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
+  const int nchunks = ceil_div(a.Ca + a.Cb, C::KC);
+  const long long blocks = (long long)a.B * tiles_x * tiles_y;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv grid out of range (%lld blocks)", blocks); return MCEDM_ERR_INVALID; }
+  const double px = (double)a.B * a.H * a.W;
+  ProfScope ps("conv_small_cout_kernel", 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * 9,
+               4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout), stream);
+  if (a.Cout <= 2)
+    hipLaunchKernelGGL(conv_small_cout_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, a.wpk, a.bias, tiles_x, tiles_y,
+                       nchunks, cout_padded(a.Cout));
+  else
+    hipLaunchKernelGGL(conv_small_cout_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a, a.wpk, a.bias, tiles_x, tiles_y,
+                       nchunks, cout_padded(a.Cout));
+  MCEDM_LAUNCH_CHECK("conv_small_cout_kernel");
+  return MCEDM_OK;
+}
+
 static int g_force_mt = 0, g_force_ph = 0, g_force_pw = 0;   // test hook (mcedm_op_set_conv_tile); 0 = heuristic
 void set_conv_tile_override(int mt, int ph, int pw) { g_force_mt = mt; g_force_ph = ph; g_force_pw = pw; }
 
@@ -899,6 +980,10 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {
                                                                                                     : 1ull * a.H * a.W;
     MCEDM_REQUIRE(rpix * a.Cout * 4ull < (1ull << 32), "conv: one sample of the residual exceeds the 4 GiB buffer range");
   }
+  // the output conv (ch -> 2): direct kernel, unless a tile is being forced by a test
+  // (at <= 32 x 32 the padded matrix kernel is still faster: 43 vs 60 us at B = 64)
+  if (taps == 9 && a.Cout <= 4 && a.resample == RS_NONE && !a.res && !a.gsum && !g_force_mt && (long long)a.H * a.W >= 4096)
+    return launch_small_cout(a, stream);
   return taps == 9 ? dispatch<9, 8>(a, stream) : dispatch<1, 16>(a, stream);
 }
 

@@ -95,44 +95,53 @@ int launch_gn_coef(const GnArgs& a, hipStream_t stream) {
 }
 
 // K1': the same table from the (sum, sum of squares) per 4 channels that the PRODUCING conv's epilogue
-// wrote per output tile (ConvArgs::gsum): no pass over the tensor at all.  One thread per (sample, channel).
-__global__ void gn_coef_from_sums_kernel(GnArgs a) {
+// wrote per output tile (ConvArgs::gsum): no pass over the tensor at all.  One wave per (sample, group): lanes
+// stride over the producer's tiles (fp64 partial sums), a fixed-order butterfly combines them (bitwise reproducible,
+// independent of the batch size), lanes 0..cpg-1 then write the group's channel rows.
+__global__ __launch_bounds__(256) void gn_coef_from_sums_kernel(GnArgs a) {
   const int C = a.Ca + a.Cb;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.B * C) return;
-  const int n = i / C, c = i - n * C;
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);       // (sample, group)
+  if (pair >= a.B * a.groups) return;
+  const int n = pair / a.groups, g = pair - n * a.groups;
   const int cpg = C / a.groups;
-  const int g = c / cpg, c0 = g * cpg;
+  const int c0 = g * cpg;
   const bool in_a = c0 < a.Ca;
   const float* sums = in_a ? a.suma : a.sumb;
   const int tiles = in_a ? a.tiles_a : a.tiles_b;
   const int Cs = in_a ? a.Ca : a.Cb;
   const int q4 = (Cs + 3) / 4;                       // 4-channel groups of the source tensor
   const int q0 = (in_a ? c0 : c0 - a.Ca) / 4;
+  const int nq = cpg / 4;
   double s1 = 0, s2 = 0;
-  for (int t = 0; t < tiles; ++t) {                  // fixed order over the producer's tiles: bitwise reproducible
+  for (int t = lane; t < tiles; t += 64) {
     const float* row = sums + (((size_t)n * tiles + t) * q4 + q0) * 2;
-    for (int q = 0; q < cpg / 4; ++q) { s1 += (double)row[2 * q]; s2 += (double)row[2 * q + 1]; }
+    for (int q = 0; q < nq; ++q) { s1 += (double)row[2 * q]; s2 += (double)row[2 * q + 1]; }
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
   const double N = (double)cpg * a.HW;
   const double m = s1 / N;
   double var = s2 / N - m * m;
   if (var < 0) var = 0;
   const float mean = (float)m;
   const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-  if (a.stats && c == c0) { a.stats[((size_t)n * a.groups + g) * 2] = mean; a.stats[((size_t)n * a.groups + g) * 2 + 1] = rstd; }
-  float sc = 1.f, sh = 0.f;
-  if (a.film) {
-    const float* f = a.film + (size_t)(a.film_batch ? n : 0) * a.film_stride;
-    sc = f[c] + 1.f;
-    sh = f[C + c];
+  if (a.stats && lane == 0) { a.stats[((size_t)n * a.groups + g) * 2] = mean; a.stats[((size_t)n * a.groups + g) * 2 + 1] = rstd; }
+  for (int k = lane; k < cpg; k += 64) {
+    const int c = c0 + k;
+    float sc = 1.f, sh = 0.f;
+    if (a.film) {
+      const float* f = a.film + (size_t)(a.film_batch ? n : 0) * a.film_stride;
+      sc = f[c] + 1.f;
+      sh = f[C + c];
+    }
+    Coef o;
+    o.mean = mean;
+    o.scale = a.gamma[c] * rstd * sc;
+    o.offset = a.beta[c] * sc + sh;
+    o.pad = 0.f;
+    a.coef[(size_t)n * C + c] = o;
   }
-  Coef o;
-  o.mean = mean;
-  o.scale = a.gamma[c] * rstd * sc;
-  o.offset = a.beta[c] * sc + sh;
-  o.pad = 0.f;
-  a.coef[i] = o;
 }
 
 int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream) {
@@ -141,7 +150,7 @@ int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream) {
   const int cpg = C / a.groups;
   if (cpg % 4 != 0 || a.Ca % cpg != 0 || a.suma == nullptr || (a.Cb > 0 && a.sumb == nullptr))
     return launch_gn_coef(a, stream);            // no fused statistics for this shape: one pass over the tensor
-  hipLaunchKernelGGL(gn_coef_from_sums_kernel, dim3(ceil_div(a.B * C, 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(gn_coef_from_sums_kernel, dim3(ceil_div(a.B * a.groups, 4)), dim3(256), 0, stream, a);
   MCEDM_LAUNCH_CHECK("gn_coef_from_sums_kernel");
   return MCEDM_OK;
 }
