@@ -653,14 +653,16 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
 // ---- output convolution (Cout <= 4) -------------------------------------------------------------------
 // The network's last 3x3 conv maps ch -> out_channels (2): on the matrix path it would fill 2 of the 32 rows of an MFMA
 // tile.  Here each thread owns one pixel of a 16 x 16 tile and CO accumulators; the staged (transformed) halo tile is
-// the B operand as above, the weights are wave-uniform scalar loads (s_load -> SGPR operands of v_fmac).  The kernel
-// is bound by reading its input once from HBM.  fmaf chain over (channel, tap): deterministic, batch independent.
+// the B operand as above, the chunk's weights sit in LDS and are read as wave-uniform broadcasts (scalar loads
+// interleaved with the LDS reads forced an lgkmcnt(0) every few instructions: 4x slower).  fmaf chain over (channel, tap): deterministic, batch independent.
 template <int CO>
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(ConvArgs p, const float* __restrict__ wpk,
                                                               const float* __restrict__ bias, int tiles_x, int tiles_y,
                                                               int nchunks, int coutp) {
   typedef ConvCfg<32, 16, 16, 1, 4, 9, 8> C;      // geometry only (16 x 16 pixels + halo, 8 channels per chunk)
+  constexpr int NW = 9 * C::KC;                    // (tap, channel) pairs per chunk
   __shared__ __attribute__((aligned(16))) float xl[C::XL];
+  __shared__ __attribute__((aligned(16))) float wl[NW * CO];    // chunk weights [tap][ci_local][CO]: broadcast reads
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   const int tx = bid % tiles_x; bid /= tiles_x;
@@ -673,22 +675,32 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(ConvArgs p, const 
   make_geom<C, RS_NONE>(p, geom, y0, x0, tid);
   InputRegs<C, RS_NONE> xin;
   load_input<C, RS_NONE>(p, geom, xin, n, 0);
+  const int wrow = tid < NW ? tid : NW - 1;        // threads 0..71 carry one (tap, channel) row of CO weights
+  float wreg[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) wreg[co] = wpk[(size_t)wrow * coutp + co];
   float acc[CO];
 #pragma unroll
   for (int co = 0; co < CO; ++co) acc[co] = (bias && co < p.Cout) ? bias[co] : 0.f;
   const float* xp = xl + py * C::PITCH + px;
   for (int ch = 0; ch < nchunks; ++ch) {
     store_input<C, RS_NONE>(p, geom, xl, xin, ch * C::KC, tid);
+    if (tid < NW) {
+#pragma unroll
+      for (int co = 0; co < CO; ++co) wl[tid * CO + co] = wreg[co];
+    }
     __syncthreads();
-    load_input<C, RS_NONE>(p, geom, xin, n, (ch + 1 < nchunks ? ch + 1 : ch) * C::KC);
-    const float* wc = wpk + (size_t)ch * (9 * C::KC) * coutp;      // [tap][ci_local][coutp]
+    const int chn = ch + 1 < nchunks ? ch + 1 : ch;
+    load_input<C, RS_NONE>(p, geom, xin, n, chn * C::KC);
+#pragma unroll
+    for (int co = 0; co < CO; ++co) wreg[co] = wpk[((size_t)chn * NW + wrow) * coutp + co];
 #pragma unroll
     for (int cil = 0; cil < C::KC; ++cil) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const float x = xp[cil * C::PLANE + (tap / 3) * C::PITCH + (tap % 3)];
 #pragma unroll
-        for (int co = 0; co < CO; ++co) acc[co] = fmaf(x, wc[(tap * C::KC + cil) * coutp + co], acc[co]);
+        for (int co = 0; co < CO; ++co) acc[co] = fmaf(x, wl[(tap * C::KC + cil) * CO + co], acc[co]);
       }
     }
     __syncthreads();

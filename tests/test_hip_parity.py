@@ -168,6 +168,27 @@ def test_conv_every_tile_configuration(lib, tile, k):
         assert torch.equal(y, y4)
 
 
+@pytest.mark.parametrize("Cout", [1, 2, 3, 4])
+def test_output_conv_direct_kernel(lib, Cout):
+    # ch -> out_channels 3x3 conv on a large image takes the direct (non-MFMA) kernel: ragged 72 x 88 image,
+    # 44 input channels (zero-padded last chunk), GroupNorm/SiLU transform rows, bias, no residual
+    B, Cin, H, W = 2, 44, 72, 88
+    tag = f"t/outconv/{Cout}"
+    x = fx.randn(tag + "/x", B, Cin, H, W)
+    w, b = fx.param(tag, "conv.weight", (Cout, Cin, 3, 3)), fx.param(tag, "conv.bias", (Cout,))
+    coef = torch.stack([fx.randn(tag + "/mean", B, Cin) * 0.3, 1 + 0.3 * fx.randn(tag + "/scale", B, Cin),
+                        0.2 * fx.randn(tag + "/off", B, Cin), torch.zeros(B, Cin)], dim=-1)
+    wpk, bpk = lib.op_pack_conv(dev(w), dev(b))
+    y = lib.op_conv(dev(x), None, wpk, bpk, Cout, 3, coef=dev(coef), act=1)
+    close(y, orc.conv2d(apply_coef(x, coef, True), w, b), what=f"output conv Cout={Cout}")
+    lib.set_conv_tile(32, 8, 32)      # the matrix path on the same problem
+    try:
+        y2 = lib.op_conv(dev(x), None, wpk, bpk, Cout, 3, coef=dev(coef), act=1)
+    finally:
+        lib.set_conv_tile()
+    close(y, y2.cpu(), what="direct vs MFMA")
+
+
 def test_conv_null_source_is_zero(lib):
     # cond=None => the cond half of cat(cond, x) reads as zeros (adm_blocks.py:328-331)
     x = fx.randn("t/null/x", 2, 2, 16, 16)
