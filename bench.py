@@ -204,10 +204,9 @@ def main():
                 "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
                 "share_of_kernel_time": dom["total_ms"] / total_ms,
                 "hbm_frac_on_algorithmic_bytes": dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
-    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.py), per launch
+    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (tools/rocpd_summary.py traffic), per launch
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-        key = dom["name"].replace("ConvCfg", "mcedm::ConvCfg").replace(">>", "> >") if False else None
         for k, v in tr.items():
             norm = k.replace("mcedm::", "").replace(" ", "")
             if norm == dom["name"].replace(" ", ""):

@@ -816,8 +816,8 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   // algorithmic cost of this launch: 2*MAC flops; bytes = input read once + output written once + weights + residual
   static char name[96];
   if (prof_enabled())
-    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d>, %s>", C::MT, C::PH, C::PW,
-             C::WM, C::WN, C::TAPS, C::KC, a.resample == RS_NONE ? "false" : "true");
+    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d>, %s>", C::MT, C::PH, C::PW,
+             C::WM, C::WN, C::TAPS, C::KC, C::NT, a.resample == RS_NONE ? "false" : "true");   // = rocprofv3's name
   const double px = (double)a.B * a.H * a.W;
   const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
   const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
@@ -868,7 +868,7 @@ static int launch_conv8(const ConvArgs& a_in, hipStream_t stream) {
     }
   }
   static char name[96];
-  if (prof_enabled()) snprintf(name, sizeof(name), "conv8_mfma_kernel<ConvCfg<128, 16, 32, 1, 8, 9, 8, 512>>");
+  if (prof_enabled()) snprintf(name, sizeof(name), "conv8_mfma_kernel<ConvCfg<128, 16, 32, 1, 8, 9, 8, 512> >");
   const double px = (double)a.B * a.H * a.W;
   const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
   const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
