@@ -316,18 +316,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
 }
 
 // One K chunk (KC input channels x all taps) of the implicit GEMM out of the LDS slabs.
-template <class C>
+// UNROLL_TAPS: the tap loop fully unrolled (all LDS offsets immediates, no loop-carried address arithmetic; VALU
+// and bubbles in this loop are paid in matrix time): +6...18 % on the small tiles, +0.6 % on <128, 8, 32>.
+template <class C, bool UNROLL_TAPS = true>
 __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32x16 (&acc)[C::TM][C::TN], int aoff,
                                            const int (&boff)[C::TN]) {
   // Register double-buffered operand fragments: the LDS reads of k-step s+1 are issued before the MFMAs
-  // of k-step s.  The tap loop stays rolled (a fully unrolled chunk pushes the prefetch registers into
-  // scratch); the fragment for the next tap's first k-step is fetched at the end of the current tap.
+  // of k-step s; the fragment for the next tap's first k-step is fetched at the end of the current tap.
   float fa[2][C::TM], fb[2][C::TN];
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) fa[0][i] = wl[aoff + i * 32];
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) fb[0][j] = xl[boff[j]];
-#pragma unroll 1
+#pragma unroll(UNROLL_TAPS ? C::TAPS : 1)
   for (int tap = 0; tap < C::TAPS; ++tap) {
     const int toff = (C::TAPS == 9) ? (tap / 3) * C::PITCH + (tap % 3) : 0;
     const int tn = (tap + 1 < C::TAPS) ? tap + 1 : tap;         // clamped: the last prefetch is discarded
@@ -418,6 +419,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
 #define MCEDM_STAMP(k)
 #endif
   for (int ch = 0; ch < nchunks; ++ch) {
+    // Staging runs at raised wave priority: fp32 VALU and MFMA share one issue path (no co-execution on gfx950), and
+    // at equal priority the co-resident wave's ready MFMAs starve these short VALU bursts until its whole MFMA
+    // phase is over, which serialises the two waves of a SIMD instead of interleaving them.
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     store_weights<C>(wl, win, tid);
     store_input<C, RS>(p, geom, xl, xin, ch * C::KC, tid);
     MCEDM_STAMP(0)
@@ -431,6 +436,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
       load_input<C, RS>(p, geom, xin, n, chn * C::KC);
     }
     MCEDM_STAMP(2)
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
     if (wave < C::NWAVE) mfma_chunk<C>(xl, wl, acc, aoff, boff);
     MCEDM_STAMP(3)
     __syncthreads();
@@ -550,11 +556,13 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
   const int aoff = (lane >> 5) * C::MT + (lane & 31);
 
   if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
+#ifndef MCEDM_CONV_TIMELINE
   if (p.dbg && lane == 0) {     // which SIMD each wave landed on
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     p.dbg[blockIdx.x * 16 + 8 + wave] = hw;
   }
+#endif
   TileGeom<C, RS_NONE> geom;
   make_geom<C, RS_NONE>(p, geom, y0, x0, tid);
   InputRegs<C, RS_NONE> xin;
@@ -580,6 +588,12 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
   __syncthreads();
 
+#ifdef MCEDM_CONV_TIMELINE   // per-phase cycle sums of wave 0 (group 0) and wave 4 (group 1): pre / MFMA / post / barrier
+  unsigned long long seg8[4] = {0, 0, 0, 0}, tprev8 = __builtin_amdgcn_s_memtime();
+#define MCEDM_STAMP8(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg8[k] += now_ - tprev8; tprev8 = now_; }
+#else
+#define MCEDM_STAMP8(k)
+#endif
   for (int ch = 0; ch < nchunks; ++ch) {
     float* wl_c = lds8 + (ch & 1) * BUF;
     float* wl_n = lds8 + ((ch & 1) ^ 1) * BUF;
@@ -592,6 +606,7 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
     if (group == 0) {
       dma_weights<C>(p.wpk, wl_n, c1, m0, coutp, tid);
     } else {
+      if (p.prio) __builtin_amdgcn_s_setprio(3);
       store_input<C, RS_NONE>(p, geom, wl_n + C::WL, xin, c1 * C::KC, tid, cfl);
       __builtin_amdgcn_sched_barrier(0);
       dma_weights<C>(p.wpk, wl_n, c1, m0, coutp, tid);
@@ -599,17 +614,26 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
       load_input<C, RS_NONE, false>(p, geom, xin, n, c2 * C::KC);
     }
     __builtin_amdgcn_sched_barrier(0);
+    MCEDM_STAMP8(0)
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
     mfma_chunk<C>(wl_c + C::WL, wl_c, acc, aoff, boff);
     __builtin_amdgcn_sched_barrier(0);
+    MCEDM_STAMP8(1)
     if (group == 0) {
+      if (p.prio) __builtin_amdgcn_s_setprio(3);
       store_input<C, RS_NONE>(p, geom, wl_n + C::WL, xin, c1 * C::KC, tid, cfl);
       load_input<C, RS_NONE, false>(p, geom, xin, n, c2 * C::KC);
     }
     __builtin_amdgcn_sched_barrier(0);
+    MCEDM_STAMP8(2)
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NLOADS) : "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    MCEDM_STAMP8(3)
   }
+#ifdef MCEDM_CONV_TIMELINE
+  if (p.dbg && lane == 0 && (wave == 0 || wave == 4)) { for (int k = 0; k < 4; ++k) p.dbg[blockIdx.x * 16 + 8 + group * 4 + k] = seg8[k]; }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the dropped tail prefetch must not land in reused registers
 
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
@@ -796,6 +820,7 @@ template <class C>
 static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   ConvArgs a = a_in;
   a.dbg = g_dbg;
+  { static int pr = -1; if (pr < 0) { const char* e = getenv("MCEDM_CONV_PRIO"); pr = e ? atoi(e) : 1; } a.prio = pr; }
   a.coef_rows = 1;
   if (!a.coef) {      // no input transform: one identity row, indexed with stride 0
     static const Coef* ident[64] = {};     // per device
@@ -843,6 +868,7 @@ static int launch_conv8(const ConvArgs& a_in, hipStream_t stream) {
   typedef Conv8Cfg C;
   ConvArgs a = a_in;
   a.dbg = g_dbg;
+  { static int pr = -1; if (pr < 0) { const char* e = getenv("MCEDM_CONV_PRIO"); pr = e ? atoi(e) : 1; } a.prio = pr; }
   a.coef_rows = 1;
   if (!a.coef) {
     static const Coef* ident[64] = {};

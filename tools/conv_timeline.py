@@ -31,7 +31,9 @@ clk = (d[:, 6] - d[:, 5]) / ((d[:, 2] - d[:, 1]) * 10e-9) / 1e9
 print(f"shader clock inside the K loop: median {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f}); MFMA-bound K loop at that clock: {2 * (cin // 8) * 18432 / np.median(clk) / 1e3:.1f} us")
 nch = cin // 8
 print("per-chunk cycles (wave 0 of each WG): " + "  ".join(f"{nm} {np.mean(d[:, 8 + k]) / nch:.0f}" for k, nm in enumerate(["commit", "barrier1", "load-issue", "mfma-loop", "barrier2"])))
-if d[:, 8:16].max() < (1 << 32) and d[0, 15] != 0:
+if os.environ.get("MCEDM_CONV8_SEG"):
+    print("8-wave per-chunk cycles  group0 (MFMA first): " + "  ".join(f"{nm} {np.mean(d[:, 8 + k]) / nch:.0f}" for k, nm in enumerate(["pre", "mfma", "post", "barrier"])) + "   group1 (commit first): " + "  ".join(f"{nm} {np.mean(d[:, 12 + k]) / nch:.0f}" for k, nm in enumerate(["pre", "mfma", "post", "barrier"])))
+elif d[:, 8:16].max() < (1 << 32) and d[0, 15] != 0:
     for i in (0, 1, 2):
         print("wave -> (simd, wave slot):", [((int(h) >> 4) & 3, int(h) & 15) for h in d[i, 8:16]])
 order = np.argsort(st)
