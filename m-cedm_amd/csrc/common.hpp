@@ -76,7 +76,6 @@ struct ConvArgs {
                      // of the OUTPUT written by the epilogue (no atomics); feeds the next GroupNorm without a stats
                      // pass.  Must hold B * conv_max_tiles(H, W) * ceil(Cout/4) * 2 floats.
   int* gsum_tiles;   // host out: tiles per sample the launcher used (row count of gsum per sample)
-  int prio;          // set by the launcher: raise the wave priority while staging (env MCEDM_CONV_PRIO, default 1)
   int coef_rows;     // set by the launcher: 1 = coef holds Ca+Cb rows (per sample if coef_batch), 0 = a single identity row
   unsigned long long* dbg;   // diagnostics only (mcedm_op_set_conv_debug): 4 timestamps (10 ns) + CU id per workgroup
 };
