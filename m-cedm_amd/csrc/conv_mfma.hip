@@ -328,7 +328,8 @@ __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32
   for (int i = 0; i < C::TM; ++i) fa[0][i] = wl[aoff + i * 32];
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) fb[0][j] = xl[boff[j]];
-#pragma unroll(UNROLL_TAPS ? C::TAPS : 1)
+  constexpr int TAP_UNROLL = UNROLL_TAPS ? C::TAPS : 1;
+#pragma unroll TAP_UNROLL
   for (int tap = 0; tap < C::TAPS; ++tap) {
     const int toff = (C::TAPS == 9) ? (tap / 3) * C::PITCH + (tap % 3) : 0;
     const int tn = (tap + 1 < C::TAPS) ? tap + 1 : tap;         // clamped: the last prefetch is discarded
