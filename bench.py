@@ -229,7 +229,8 @@ def main():
         "train_samples_per_sec": (B * world / (train_ms * 1e-3)) if train_ms else None,
         "roofline": roofline, "kernels": kernels[:8],
     }
-    if not args.no_cpu_baseline:
+    line["cpu_baseline"] = None          # timed on rank 0 of the 1-GPU run only
+    if not args.no_cpu_baseline and world == 1:
         n_cpu = args.cpu_states or (2 if H * W * wl["ch"] >= 128 * 128 * 64 else 8)
         line["cpu_baseline"] = cpu_baseline(cfg, wl, n_cpu)
         line["gpu_over_cpu"] = value / world / line["cpu_baseline"]["value"]
