@@ -227,6 +227,20 @@ int mcedm_op_set_conv8(int enable);
  * kernel).  NULL switches it off. */
 int mcedm_op_set_conv_debug(unsigned long long* buf);
 
+/* ---- PDE residuals (forward) ----------------------------------------------
+ * Replace the tensor-op bodies of models/pde_loss.py; results are bit-identical to the PyTorch CPU path.
+ * All tensors are fp32, channel-last (b, t, x, 2) = (h, u) for SWE and (b, s, s, 2) = (a, u) for Darcy.
+ *   half_dt = (float)(0.5 * Tn / n_times), dx = x[1] - x[0] of SweFvLoss.gen_x (models/pde_loss.py:102-118, fp32).
+ * mcedm_swe_fv_step      SweFvLoss.f_t_swp1d      models/pde_loss.py:131-165   out (b, t, x, 2)
+ * mcedm_swe_fv_residual  SweFvLoss.calculate_loss models/pde_loss.py:211-225 (+ clamp of forward, :245-247)
+ *                        scale2_* = normalizer.divide ** 2 (get_scaling, :197-209); out (b, t, x, 2)
+ * mcedm_darcy_residual   DarcyLoss.calculate_loss models/pde_loss.py:30-54 and the division / clamp of forward
+ *                        (:80-86): two_dx = (float)(2 * D / s), denom = (s-4)^2; out (b, s-4, s-4) */
+int mcedm_swe_fv_step(const float* s, float* out, int B, int T, int X, float half_dt, float dx, void* stream);
+int mcedm_swe_fv_residual(const float* pred, const float* gt, float* out, int B, int T, int X, float half_dt, float dx,
+                          float scale2_h, float scale2_u, int clamp, void* stream);
+int mcedm_darcy_residual(const float* pred, float* out, int B, int S, float two_dx, float denom, int clamp, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * Per-launch timing with HIP event pairs recorded on the launch stream (bench.py's roofline leg).
  * mcedm_prof_report waits for the events, then writes a JSON array

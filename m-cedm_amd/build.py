@@ -21,7 +21,7 @@ ARCH = "gfx950"
 COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}",
           "-Wall", "-Wno-unused-function"] + os.environ.get("MCEDM_EXTRA_HIPCC_FLAGS", "").split()
 # the fp64 sampler arithmetic must follow the reference's evaluation order: no fma contraction there
-PER_FILE = {"edm.hip": ["-ffp-contract=off"]}
+PER_FILE = {"edm.hip": ["-ffp-contract=off"], "pde.hip": ["-ffp-contract=off"]}
 
 
 def _digest(paths, extra):

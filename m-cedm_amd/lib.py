@@ -22,6 +22,7 @@ EXPORTS = [
     "mcedm_unet_workspace_bytes", "mcedm_unet_forward", "mcedm_edm_denoise", "mcedm_sampler_workspace_bytes",
     "mcedm_heun_sample", "mcedm_edm_t_steps", "mcedm_edm_loss", "mcedm_edm_noise_inputs",
     "mcedm_edm_denoise_backward", "mcedm_sqnorm", "mcedm_adam_ema_step",
+    "mcedm_swe_fv_step", "mcedm_swe_fv_residual", "mcedm_darcy_residual",
 ]
 
 
@@ -78,6 +79,10 @@ def load() -> C.CDLL:
     lib.mcedm_sqnorm.argtypes = [f32p, sz, f64p, vp]
     lib.mcedm_adam_ema_step.argtypes = [f32p, f32p, f32p, f32p, f32p, sz, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_double, f64p, C.c_double, C.c_double, C.c_double, C.c_int64, vp]
+    lib.mcedm_swe_fv_step.argtypes = [f32p, f32p, i32, i32, i32, C.c_float, C.c_float, vp]
+    lib.mcedm_swe_fv_residual.argtypes = [f32p, f32p, f32p, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          i32, vp]
+    lib.mcedm_darcy_residual.argtypes = [f32p, f32p, i32, i32, C.c_float, C.c_float, i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)          # AttributeError here == header/library drift
         if name not in ("mcedm_last_error", "mcedm_unet_plan_destroy"):
@@ -272,6 +277,30 @@ def edm_loss(D, x, mask, sigma, sigma_data=1.0, want_grad=True):
     check(load().mcedm_edm_loss(_ptr(D), _ptr(x), _ptr(mask), _ptr(sigma), B, Cc, H, W, float(sigma_data), _ptr(loss),
                                 _ptr(dD), _stream()), "edm_loss")
     return loss, dD
+
+
+# ---- PDE residuals (models/pde_loss.py) -------------------------------------------------------
+def swe_fv_step(s_t: torch.Tensor, half_dt: float, dx: float) -> torch.Tensor:
+    """SweFvLoss.f_t_swp1d on (b, t, x, 2) fp32 states."""
+    B, T, X, _ = s_t.shape
+    out = torch.empty_like(s_t)
+    check(load().mcedm_swe_fv_step(_ptr(s_t), _ptr(out), B, T, X, half_dt, dx, _stream()), "swe_fv_step")
+    return out
+
+
+def swe_fv_residual(pred, gt, half_dt: float, dx: float, scale2_h: float, scale2_u: float, clamp: bool) -> torch.Tensor:
+    B, T, X, _ = pred.shape
+    out = torch.empty_like(pred)
+    check(load().mcedm_swe_fv_residual(_ptr(pred), _ptr(gt), _ptr(out), B, T, X, half_dt, dx, scale2_h, scale2_u, int(clamp),
+                                       _stream()), "swe_fv_residual")
+    return out
+
+
+def darcy_residual(pred, two_dx: float, denom: float, clamp: bool) -> torch.Tensor:
+    B, S = pred.shape[0], pred.shape[1]
+    out = torch.empty((B, S - 4, S - 4), dtype=torch.float32, device=pred.device)
+    check(load().mcedm_darcy_residual(_ptr(pred), _ptr(out), B, S, two_dx, denom, int(clamp), _stream()), "darcy_residual")
+    return out
 
 
 def sqnorm(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

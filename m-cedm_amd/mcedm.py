@@ -134,8 +134,8 @@ class PlMcedm(_Base):
         self.pde_loss_lambda = getattr(o, "pde_loss_lambda", 0.0) if hasattr(o, "pde_loss_lambda") else 0.0
         if self.pde_loss_lambda:
             raise NotImplementedError("pde_loss_lambda != 0 is outside the hot path")
-        self.pde_loss = None
-        self.pde_loss_simulator = None
+        from .pde_loss import get_pde_loss_function
+        self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system="swe", flip_xy=False)   # mcedm.py:82-84
         self.sparams = self.get_sampler_params(hparams)
         self.test_sparams = self.sparams
         self.h_ch = self.u_ch = n_state
@@ -155,13 +155,10 @@ class PlMcedm(_Base):
         self.test_sparams = params
 
     def set_pde_loss_function(self, system, flip_xy):
-        """The PDE residual is a host-side metric of the reference (models/pde_loss.py); when this module is used
-        inside the reference tree its own implementation is picked up, otherwise the metric is skipped."""
-        try:
-            from models.loss_helper import get_pde_loss_function      # the host repository's, if importable
-            self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system, flip_xy)
-        except Exception:
-            self.pde_loss = self.pde_loss_simulator = None
+        """models/mcedm.py:100-104.  The residual metric runs on the device (m-cedm_amd/pde_loss.py ->
+        csrc/pde.hip, bit-identical to models/pde_loss.py); its guidance gradient is not built."""
+        from .pde_loss import get_pde_loss_function
+        self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system, flip_xy)
 
     def setup(self, stage: str = None) -> None:
         if stage == "fit":

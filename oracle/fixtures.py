@@ -165,3 +165,28 @@ def cond_training_inputs(B: int = 3, T: int = 32, X: int = 32):
     noise = randn("cond/train/noise", B, 1, T, X)
     rnd_normal = randn("cond/train/rnd", B, 1, 1, 1)
     return h, u, noise, rnd_normal
+
+
+# ---- PDE residuals: (b, t, x) sizes, Tn, x range -----------------------------------
+PDE_SWE_CASES = {"per32": (3, 32, 32, 0.128, -0.5, 0.5), "dam128": (2, 128, 128, 1.28, -2.5, 2.5), "ragged": (2, 5, 37, 0.128, -0.5, 0.5)}
+PDE_DARCY_CASES = {"d32": (3, 32), "d128": (2, 128), "d7": (2, 7)}
+
+
+def pde_swe_inputs(name):
+    """Physical-looking SWE states: h in ~[1, 2], u in ~[-0.5, 0.5]; gt = pred + small noise; normaliser scales."""
+    B, T, X, _, _, _ = PDE_SWE_CASES[name]
+    h = 1.5 + 0.25 * randn(f"pde/swe/{name}/h", B, T, X).clamp(-1.9, 1.9)
+    u = 0.2 * randn(f"pde/swe/{name}/u", B, T, X)
+    pred = torch.stack((h, u), dim=-1)
+    gt = pred + 0.01 * randn(f"pde/swe/{name}/gt", B, T, X, 2)
+    if name == "ragged":            # a dry cell and a NaN: the reference zeroes NaNs of the stepped state (pde_loss.py:219)
+        pred[0, 1, 3, 0] = 0.0
+        pred[1, 2, 5, 1] = float("nan")
+    return pred, gt, torch.tensor(0.37), torch.tensor(0.21)
+
+
+def pde_darcy_inputs(name):
+    B, S = PDE_DARCY_CASES[name]
+    a = 1.0 + 0.5 * torch.from_numpy(uniform(f"pde/darcy/{name}/a", B, S, S).astype(np.float32))
+    u = 0.1 * randn(f"pde/darcy/{name}/u", B, S, S)
+    return torch.stack((a, u), dim=-1)
