@@ -18,6 +18,8 @@ size_t wgrad_scratch_floats(int Cout, int Cin, int taps);
 // dw [Cout][Cin][kh][kw], db [Cout] (may be null).  qkv_heads > 0: dy rows are in packed qkv order.
 // act_tmp: scratch of B * (Ca+Cb) * H * W floats for the materialised conv input
 int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s);
+// the materialisation step alone: out[B, Ca+Cb, H, W] = resample(act(coef(cat(xa, xb)))); dy / Cout / dwp are not read
+int launch_act_materialize(const WgradArgs& a, float* out, hipStream_t s);
 
 // backward through  act(film(group_norm(cat(xa,xb))))  followed by an optional 2x resampling
 struct GnBwdArgs {

@@ -478,16 +478,15 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   }
 }
 
-// RESAMPLED = false is the hot instantiation (no up/down sampling): keeping it in a kernel of its own gives
-// it its own register allocation (the 2x2-mean variant prefetches 4 source pixels per tile element).
-template <class C, bool RESAMPLED>
-__global__ __launch_bounds__(256, RESAMPLED ? 2 : C::OCC) void conv_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles,
-                                                           int nchunks, int coutp) {
+// One kernel per resampling mode (0 none, 1 nearest 2x up, 2 2x2-mean down), each with its own register allocation:
+// the down variant prefetches 4 source pixels per tile element and would otherwise set the budget (and the
+// spills) of the other two.
+template <class C, int RSK>
+__global__ __launch_bounds__(256, RSK == RS_DOWN ? 2 : C::OCC) void conv_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y,
+                                                                                    int mtiles, int nchunks, int coutp) {
   __shared__ __attribute__((aligned(16))) float xl[C::XL];
   __shared__ __attribute__((aligned(16))) float wl[C::WL];
-  if (!RESAMPLED) conv_body<C, RS_NONE>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
-  else if (p.resample == RS_UP) conv_body<C, RS_UP>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
-  else conv_body<C, RS_DOWN>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
+  conv_body<C, RSK>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
 }
 
 // Weight slab global -> LDS without passing through VGPRs (LDS-DMA, 16 bytes per lane): the LDS image is the linear
@@ -833,8 +832,8 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   // algorithmic cost of this launch: 2*MAC flops; bytes = input read once + output written once + weights + residual
   static char name[96];
   if (prof_enabled())
-    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d>, %s>", C::MT, C::PH, C::PW,
-             C::WM, C::WN, C::TAPS, C::KC, C::NT, a.resample == RS_NONE ? "false" : "true");   // = rocprofv3's name
+    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d>, %d>", C::MT, C::PH, C::PW,
+             C::WM, C::WN, C::TAPS, C::KC, C::NT, (int)a.resample);   // = rocprofv3's name
   const double px = (double)a.B * a.H * a.W;
   const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
   const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
@@ -843,10 +842,13 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   static int extra_lds = -1;     // diagnostics: MCEDM_CONV_EXTRA_LDS bytes of unused dynamic LDS lower the occupancy
   if (extra_lds < 0) { const char* e = getenv("MCEDM_CONV_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
   if (a.resample == RS_NONE)
-    hipLaunchKernelGGL((conv_mfma_kernel<C, false>), dim3((unsigned)blocks), dim3(256), extra_lds, stream, a, tiles_x, tiles_y,
+    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_NONE>), dim3((unsigned)blocks), dim3(256), extra_lds, stream, a, tiles_x, tiles_y,
+                       mtiles, nchunks, cout_padded(a.Cout));
+  else if (a.resample == RS_UP)
+    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_UP>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
                        mtiles, nchunks, cout_padded(a.Cout));
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<C, true>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
+    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_DOWN>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
                        mtiles, nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_mfma_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = tiles_x * tiles_y;

@@ -8,6 +8,7 @@
 
 #include "edm.hpp"
 #include "plan.hpp"
+#include "bwd.hpp"
 
 namespace mcedm {
 
@@ -415,9 +416,12 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
     bl.W = b.up ? bl.Win * 2 : (b.down ? bl.Win / 2 : bl.Win);
     bl.coef0 = lb.coef(b.cin);
     if (training) bl.stats0 = lb.stats(b.norm0.groups);
+    // a down block's conv0 reads avgpool2x2(silu(norm(x))): four SiLUs per staged element is paid in matrix time
+    // inside the fused kernel (62 vs 120 TFLOP/s), so that one input is materialised by an HBM-speed pass instead
+    if (b.down) bl.xd = lb.act(b.cin, bl.H, bl.W);
     bl.h = lb.act(b.cout, bl.H, bl.W);
     give_sums(bl.h);
-    lb.drop(bl.coef0);
+    lb.drop(bl.coef0); lb.drop(bl.xd);
     bl.coef1 = lb.coef(b.cout);
     if (training) bl.stats1 = lb.stats(b.norm1.groups);
     if (b.skip_kernel == 1) bl.sk = lb.act(b.cout, bl.H, bl.W);
@@ -507,10 +511,19 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   ConvArgs c0{};
   c0.xa = xa; c0.xb = xb; c0.Ca = Ca; c0.Cb = Cb;
   c0.coef = CF(bl.coef0); c0.coef_batch = 1; c0.act = 1;
-  c0.resample = b.up ? RS_UP : (b.down ? RS_DOWN : RS_NONE);
+  const int rs = b.up ? RS_UP : (b.down ? RS_DOWN : RS_NONE);
+  c0.resample = rs;
   c0.Hs = bl.Hin; c0.Ws = bl.Win; c0.H = bl.H; c0.W = bl.W;
   c0.wpk = pk + b.conv0.wpk; c0.bias = pk + b.conv0.bias;
   c0.out = T(bl.h); c0.Cout = b.cout; c0.B = B; c0.gsum = SUMS(bl.h); c0.gsum_tiles = &st[bl.h];
+  if (bl.xd >= 0) {
+    WgradArgs m{};
+    m.xa = xa; m.xb = xb; m.Ca = Ca; m.Cb = Cb; m.coef = c0.coef; m.coef_batch = 1; m.act = 1; m.resample = RS_DOWN;
+    m.Hs = bl.Hin; m.Ws = bl.Win; m.H = bl.H; m.W = bl.W; m.B = B;
+    if ((rc = launch_act_materialize(m, T(bl.xd), s))) return rc;
+    c0.xa = T(bl.xd); c0.xb = nullptr; c0.Ca = Ca + Cb; c0.Cb = 0;
+    c0.coef = nullptr; c0.act = 0; c0.resample = RS_NONE; c0.Hs = bl.H; c0.Ws = bl.W;
+  }
   if ((rc = launch_conv(c0, 9, s))) return rc;
   // norm1 + FiLM -> transform table for conv1
   const float* film = at<float>(act, L.t[L.film].off) + b.film_row0;
@@ -523,13 +536,13 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   if (b.skip_kernel == 1) {
     ConvArgs cs{};
     cs.xa = xa; cs.xb = xb; cs.Ca = Ca; cs.Cb = Cb;
-    cs.resample = c0.resample; cs.Hs = bl.Hin; cs.Ws = bl.Win; cs.H = bl.H; cs.W = bl.W;
+    cs.resample = rs; cs.Hs = bl.Hin; cs.Ws = bl.Win; cs.H = bl.H; cs.W = bl.W;
     cs.wpk = pk + b.skip.wpk; cs.bias = pk + b.skip.bias;
     cs.out = T(bl.sk); cs.Cout = b.cout; cs.B = B;
     if ((rc = launch_conv(cs, 1, s))) return rc;
     res = T(bl.sk);
   } else if (b.skip_kernel == 0) {
-    res_mode = c0.resample;
+    res_mode = rs;
   }
   // y = conv1(silu(film(norm1(h)))) + skip
   ConvArgs c1{};

@@ -57,6 +57,7 @@ struct BlockLayout {
   int xa = -1, xb = -1;        // input tensor ids (xb = popped skip for concat blocks)
   int coef0 = -1, h = -1, coef1 = -1, sk = -1, y = -1, coef2 = -1, qkv = -1, a = -1, z = -1;
   int stats0 = -1, stats1 = -1, stats2 = -1;
+  int xd = -1;                 // down blocks: the activated, 2x2-averaged input of conv0 (temporary)
   int out = -1;                // y or z
   int Hin = 0, Win = 0, H = 0, W = 0;
 };

@@ -260,6 +260,19 @@ static int launch_wg(const WgradArgs& a, const float* xact, hipStream_t s) {
   return MCEDM_OK;
 }
 
+// out: B * Cin * H * W floats = resample(act(coef(cat(xa, xb)))) at the conv resolution
+int launch_act_materialize(const WgradArgs& a, float* out, hipStream_t s) {
+  const int Cin = a.Ca + a.Cb;
+  const size_t total = (size_t)a.B * Cin * a.H * a.W;
+  const int vec = (a.W % 4 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0) ? 4 : 1;
+  const size_t n4 = total / vec;
+  const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  ProfScope ps("act_materialize_kernel", 10.0 * total, 4.0 * ((double)a.B * Cin * a.Hs * a.Ws + (double)total), s);
+  hipLaunchKernelGGL(act_materialize_kernel, dim3(blocks), dim3(256), 0, s, a, out, n4, vec);
+  MCEDM_LAUNCH_CHECK("act_materialize_kernel");
+  return MCEDM_OK;
+}
+
 // act_tmp: B * Cin * H * W floats (the materialised conv input)
 int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s) {
   MCEDM_REQUIRE(taps == 9 || taps == 1, "wgrad: taps must be 9 or 1");
@@ -269,16 +282,8 @@ int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_hea
   WgradArgs b = a;
   b.dbp = a.dwp + taps * cop * cip;
   MCEDM_HIP_TRY(hipMemsetAsync(a.dwp, 0, wgrad_scratch_floats(a.Cout, Cin, taps) * sizeof(float), s));
-  {
-    const size_t total = (size_t)a.B * Cin * a.H * a.W;
-    const int vec = (a.W % 4 == 0 && (reinterpret_cast<size_t>(act_tmp) & 15) == 0) ? 4 : 1;
-    const size_t n4 = total / vec;
-    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    ProfScope ps("act_materialize_kernel", 10.0 * total, 4.0 * ((double)a.B * Cin * a.Hs * a.Ws + (double)total), s);
-    hipLaunchKernelGGL(act_materialize_kernel, dim3(blocks), dim3(256), 0, s, a, act_tmp, n4, vec);
-    MCEDM_LAUNCH_CHECK("act_materialize_kernel");
-  }
   int rc;
+  if ((rc = launch_act_materialize(a, act_tmp, s))) return rc;
   if (taps == 9) {
     if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 9>>(b, act_tmp, s);
     else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 9>>(b, act_tmp, s);
