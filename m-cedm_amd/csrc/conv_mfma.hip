@@ -14,6 +14,12 @@
 // A workgroup = 4 waves = MT output channels x (PH x PW) pixels of one sample.  HBM layout
 // stays NCHW: lanes run along W, so both the staging loads and the epilogue stores are
 // contiguous 128-byte row segments.
+//
+// Kernels in this file: conv_mfma_kernel (the product path: one instantiation per tile configuration and
+// resampling mode), conv8_mfma_kernel (experimental 8-wave variant of the largest tile, off by default,
+// bit-identical), conv_small_cout_kernel (the ch -> out_channels output conv), pack_conv / pack_bias.
+// What bounds them and what was tried is written up in DESIGN.md section 3; the short version: fp32 VALU work
+// does not overlap fp32 MFMA work on gfx950, so every vector instruction here is paid in matrix time.
 #include <cstdlib>
 
 #include "common.hpp"
@@ -45,8 +51,6 @@ struct ConvCfg {
 
 // SiLU with the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each); relative error ~1e-6, far inside the
 // 1e-4 parity bar, and a third of the VALU work of expf() + IEEE division in the staging path.
-// SiLU with the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each); relative error ~1e-6, far inside the
-// 1e-4 parity bar, and a third of the VALU work of expf() + IEEE division in the staging path.
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ float apply_coef(float v, const Coef& c, int act) {
@@ -57,10 +61,10 @@ __device__ __forceinline__ float apply_coef(float v, const Coef& c, int act) {
 // ---- staging -----------------------------------------------------------------------------------------
 // Split into an issue half (global loads -> registers) and a commit half (transform + LDS writes) so the
 // loads of chunk c+1 are in flight while the MFMAs of chunk c run.  Everything that does not depend on the
-// channel (tile coordinates, bounds, clamped source offsets) is computed once per workgroup; the loads are
-// unconditional from clamped addresses (no exec-masked branches) and out-of-image / padded-channel elements
-// are zeroed at commit.  The per-(sample, channel) transform rows are wave-uniform (scalar loads) and are
-// prefetched together with the inputs.
+// channel (tile coordinates, bounds, clamped source offsets) is computed once per workgroup; every load is
+// unconditional from a clamped address (a guarded load costs a vmcnt(0) round trip in front of the MFMA loop)
+// and out-of-image / padded-channel elements are masked to zero at commit.  The per-(sample, channel) transform
+// rows are prefetched with the inputs.
 template <class C, int RS>
 struct TileGeom {
   static constexpr int NL = (RS == RS_DOWN) ? 4 : 1;
