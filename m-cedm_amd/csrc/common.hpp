@@ -55,6 +55,25 @@ struct __attribute__((aligned(16))) Coef {
 enum Resample { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
 
 // Arguments of the implicit-GEMM convolution (3x3 pad 1, or 1x1).
+// GroupNorm (+FiLM) -> per-(sample, channel) transform rows (K1)
+struct GnArgs {
+  const float* xa; const float* xb; int Ca, Cb;
+  int HW, B, groups;
+  const float* gamma; const float* beta;     // [C]
+  const float* film;  // row n: film[n*film_stride + (0..C) = scale | (C..2C) = shift], or null
+  int film_batch;     // 1: one row per sample, 0: row 0 broadcast over the batch
+  int film_stride;
+  float eps;
+  Coef* coef;        // out [B][C]
+  float* stats;      // out [B][groups][2] (mean, rstd) or null (kept for backward)
+  const float* suma; const float* sumb;     // launch_gn_coef_from_sums: per-tile (sum, sumsq) tables of xa / xb
+  int tiles_a, tiles_b;                     // tiles per sample in those tables
+};
+int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream);
+int launch_gn_coef(const GnArgs& a, hipStream_t stream);
+// true when the (sum, sumsq) tables in `a` can replace a pass over the tensor (4-channel groups tile the GroupNorm groups)
+bool gn_sums_usable(const GnArgs& a);
+
 struct ConvArgs {
   const float* xa;   // first source of the virtual channel concat [B, Ca, Hs, Ws] (may be null => zeros)
   const float* xb;   // second source [B, Cb, Hs, Ws] (null iff Cb == 0)
@@ -76,6 +95,9 @@ struct ConvArgs {
                      // of the OUTPUT written by the epilogue (no atomics); feeds the next GroupNorm without a stats
                      // pass.  Must hold B * conv_max_tiles(H, W) * ceil(Cout/4) * 2 floats.
   int* gsum_tiles;   // host out: tiles per sample the launcher used (row count of gsum per sample)
+  // gn_on: the kernel derives this sample's transform rows itself from the producers' per-tile (sum, sumsq) tables
+  // (gn.suma / gn.sumb ...; gn.coef / gn.stats / gn.xa / gn.xb are not used), so no GroupNorm kernel runs at all
+  GnArgs gn; int gn_on;
   int coef_rows;     // set by the launcher: 1 = coef holds Ca+Cb rows (per sample if coef_batch), 0 = a single identity row
   unsigned long long* dbg;   // diagnostics only (mcedm_op_set_conv_debug): 4 timestamps (10 ns) + CU id per workgroup
 };
@@ -96,21 +118,7 @@ int launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int taps, in
 int launch_pack_bias(const float* b, float* dst, int Cout, int qkv_heads, hipStream_t stream);
 
 // GroupNorm statistics + coefficient table (K1).  x = virtual concat of xa[B,Ca,HW], xb[B,Cb,HW].
-struct GnArgs {
-  const float* xa; const float* xb; int Ca, Cb;
-  int HW, B, groups;
-  const float* gamma; const float* beta;     // [C]
-  const float* film;  // row n: film[n*film_stride + (0..C) = scale | (C..2C) = shift], or null
-  int film_batch;     // 1: one row per sample, 0: row 0 broadcast over the batch
-  int film_stride;
-  float eps;
-  Coef* coef;        // out [B][C]
-  float* stats;      // out [B][groups][2] (mean, rstd) or null (kept for backward)
-  const float* suma; const float* sumb;     // launch_gn_coef_from_sums: per-tile (sum, sumsq) tables of xa / xb
-  int tiles_a, tiles_b;                     // tiles per sample in those tables
-};
-int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream);
-int launch_gn_coef(const GnArgs& a, hipStream_t stream);
+
 
 // sigma-embedding MLP + all FiLM affine rows (K6)
 struct EmbArgs {

@@ -105,6 +105,68 @@ __device__ __forceinline__ void make_geom(const ConvArgs& p, TileGeom<C, RS>& G,
 
 __device__ Coef k_identity_coef = {0.f, 1.f, 0.f, 0.f};   // the table of a conv without an input transform
 
+// This sample's Ca + Cb transform rows -> LDS, once per workgroup; the commit phase reads them as wave-uniform
+// broadcasts (24 fewer VGPRs and 8 fewer loads per chunk than carrying the rows of the next chunk in registers).
+// gn_on: the rows are derived right here from the per-tile (sum, sumsq) tables that the PRODUCING convs' epilogues
+// wrote (GroupNorm statistics in fp64, fixed-order butterfly over the lanes that share a group; + FiLM), so the
+// inference path runs no GroupNorm kernel at all: the input is normalised by the conv that consumes it.
+// Otherwise they are copied from the table p.coef (the launcher points a missing table at one identity row).
+template <int NT>
+__device__ __forceinline__ void stage_coef_rows(const ConvArgs& p, int n, Coef* cfl, int tid) {
+  const int C = p.Ca + p.Cb;
+  if (!p.gn_on) {
+    for (int i = tid; i < C; i += NT) cfl[i] = p.coef[((p.coef_batch ? (size_t)n * C : 0) + i) * p.coef_rows];
+    return;
+  }
+  const GnArgs& g = p.gn;
+  const int G = g.groups, cpg = C / G;
+  int lpg = NT / G;                                    // lanes per group: a power of two <= 64
+  lpg = lpg >= 64 ? 64 : lpg >= 32 ? 32 : lpg >= 16 ? 16 : lpg >= 8 ? 8 : lpg >= 4 ? 4 : lpg >= 2 ? 2 : 1;
+  const int gpr = NT / lpg;                            // groups per round
+  const int sub = tid % lpg;
+  for (int g0 = 0; g0 < G; g0 += gpr) {
+    const int gi = g0 + tid / lpg;
+    const bool live = gi < G;
+    const int c0 = live ? gi * cpg : 0;
+    const bool in_a = c0 < g.Ca;
+    const float* sums = in_a ? g.suma : g.sumb;
+    const int tiles = live ? (in_a ? g.tiles_a : g.tiles_b) : 0;
+    const int Cs = in_a ? g.Ca : g.Cb;
+    const int q4 = (Cs + 3) / 4;
+    const int q0 = (in_a ? c0 : c0 - g.Ca) / 4;
+    const int nq = cpg / 4;
+    double s1 = 0, s2 = 0;
+    for (int t = sub; t < tiles; t += lpg) {
+      const float* row = sums + (((size_t)n * tiles + t) * q4 + q0) * 2;
+      for (int q = 0; q < nq; ++q) { s1 += (double)row[2 * q]; s2 += (double)row[2 * q + 1]; }
+    }
+    for (int off = lpg >> 1; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if (live) {
+      const double N = (double)cpg * g.HW;
+      const double m = s1 / N;
+      double var = s2 / N - m * m;
+      if (var < 0) var = 0;
+      const float mean = (float)m;
+      const float rstd = (float)(1.0 / sqrt(var + (double)g.eps));
+      for (int k = sub; k < cpg; k += lpg) {
+        const int c = c0 + k;
+        float sc = 1.f, sh = 0.f;
+        if (g.film) {
+          const float* f = g.film + (size_t)(g.film_batch ? n : 0) * g.film_stride;
+          sc = f[c] + 1.f;
+          sh = f[C + c];
+        }
+        Coef o;
+        o.mean = mean;
+        o.scale = g.gamma[c] * rstd * sc;
+        o.offset = g.beta[c] * sc + sh;
+        o.pad = 0.f;
+        cfl[c] = o;
+      }
+    }
+  }
+}
+
 template <class C, int RS>
 struct InputRegs {
   float raw[C::KC][TileGeom<C, RS>::SUB][TileGeom<C, RS>::NL];
@@ -368,7 +430,7 @@ __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32
 }
 
 template <class C, int RS>
-__device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* wl, int tiles_x, int tiles_y,
+__device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* wl, Coef* cfl, int tiles_x, int tiles_y,
                                           int mtiles, int nchunks, int coutp) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -402,7 +464,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   WeightGeom<C> wgeom;
   make_wgeom<C>(p.wpk, wgeom, m0, coutp, nchunks, tid);
   load_weights<C>(wgeom, win, 0, coutp);
-  load_input<C, RS>(p, geom, xin, n, 0);
+  load_input<C, RS, false>(p, geom, xin, n, 0);
+  stage_coef_rows<C::NT>(p, n, cfl, tid);
   // after the first chunk's loads are issued: the residual tile streams in behind them
   if (wave < C::NWAVE) {
     if (m0 + C::MT <= p.Cout) {
@@ -423,9 +486,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
 #else
 #define MCEDM_STAMP(k)
 #endif
+  __syncthreads();            // transform rows visible to every wave
   for (int ch = 0; ch < nchunks; ++ch) {
     store_weights<C>(wl, win, tid);
-    store_input<C, RS>(p, geom, xl, xin, ch * C::KC, tid);
+    store_input<C, RS>(p, geom, xl, xin, ch * C::KC, tid, cfl);
     MCEDM_STAMP(0)
     __syncthreads();
     MCEDM_STAMP(1)
@@ -434,7 +498,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
         // resolves with a vmcnt(0) + register copies right here, in front of the MFMA loop.
       const int chn = ch + 1 < nchunks ? ch + 1 : ch;
       load_weights<C>(wgeom, win, chn, coutp);
-      load_input<C, RS>(p, geom, xin, n, chn * C::KC);
+      load_input<C, RS, false>(p, geom, xin, n, chn * C::KC);
     }
     MCEDM_STAMP(2)
     if (wave < C::NWAVE) mfma_chunk<C>(xl, wl, acc, aoff, boff);
@@ -490,7 +554,8 @@ __global__ __launch_bounds__(256, RSK == RS_DOWN ? 2 : C::OCC) void conv_mfma_ke
                                                                                     int mtiles, int nchunks, int coutp) {
   __shared__ __attribute__((aligned(16))) float xl[C::XL];
   __shared__ __attribute__((aligned(16))) float wl[C::WL];
-  conv_body<C, RSK>(p, xl, wl, tiles_x, tiles_y, mtiles, nchunks, coutp);
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];      // (Ca + Cb) transform rows
+  conv_body<C, RSK>(p, xl, wl, reinterpret_cast<Coef*>(dyn_lds), tiles_x, tiles_y, mtiles, nchunks, coutp);
 }
 
 // Weight slab global -> LDS without passing through VGPRs (LDS-DMA, 16 bytes per lane): the LDS image is the linear
@@ -567,10 +632,7 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
   InputRegs<C, RS_NONE> xin;
   dma_weights<C>(p.wpk, lds8, 0, m0, coutp, tid);             // chunk 0 weights -> buffer 0
   load_input<C, RS_NONE, false>(p, geom, xin, n, 0);
-  {
-    const int Cin = p.Ca + p.Cb;
-    for (int i = tid; i < Cin; i += C::NT) cfl[i] = p.coef[((p.coef_batch ? (size_t)n * Cin : 0) + i) * p.coef_rows];
-  }
+  stage_coef_rows<C::NT>(p, n, cfl, tid);
   if (m0 + C::MT <= p.Cout) {
     if (!p.res) conv_init_acc<C, 0, true>(p, acc, n, m0, y0, x0, 0, wn, lane);
     else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, true>(p, acc, n, m0, y0, x0, 0, wn, lane);
@@ -691,10 +753,14 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(ConvArgs p, const 
   const int y0 = ty * C::PH, x0 = tx * C::PW;
   const int py = tid / C::PW, px = tid % C::PW;
 
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  Coef* cfl = reinterpret_cast<Coef*>(dyn_lds);
   TileGeom<C, RS_NONE> geom;
   make_geom<C, RS_NONE>(p, geom, y0, x0, tid);
   InputRegs<C, RS_NONE> xin;
-  load_input<C, RS_NONE>(p, geom, xin, n, 0);
+  load_input<C, RS_NONE, false>(p, geom, xin, n, 0);
+  stage_coef_rows<256>(p, n, cfl, tid);
+  __syncthreads();
   const int wrow = tid < NW ? tid : NW - 1;        // threads 0..71 carry one (tap, channel) row of CO weights
   float wreg[CO];
 #pragma unroll
@@ -704,14 +770,14 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(ConvArgs p, const 
   for (int co = 0; co < CO; ++co) acc[co] = (bias && co < p.Cout) ? bias[co] : 0.f;
   const float* xp = xl + py * C::PITCH + px;
   for (int ch = 0; ch < nchunks; ++ch) {
-    store_input<C, RS_NONE>(p, geom, xl, xin, ch * C::KC, tid);
+    store_input<C, RS_NONE>(p, geom, xl, xin, ch * C::KC, tid, cfl);
     if (tid < NW) {
 #pragma unroll
       for (int co = 0; co < CO; ++co) wl[tid * CO + co] = wreg[co];
     }
     __syncthreads();
     const int chn = ch + 1 < nchunks ? ch + 1 : ch;
-    load_input<C, RS_NONE>(p, geom, xin, n, chn * C::KC);
+    load_input<C, RS_NONE, false>(p, geom, xin, n, chn * C::KC);
 #pragma unroll
     for (int co = 0; co < CO; ++co) wreg[co] = wpk[((size_t)chn * NW + wrow) * coutp + co];
 #pragma unroll
@@ -845,14 +911,17 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   ProfScope ps(name, flops, bytes, stream);
   static int extra_lds = -1;     // diagnostics: MCEDM_CONV_EXTRA_LDS bytes of unused dynamic LDS lower the occupancy
   if (extra_lds < 0) { const char* e = getenv("MCEDM_CONV_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
+  const unsigned rows_bytes = (unsigned)(a.Ca + a.Cb) * (unsigned)sizeof(Coef);      // transform rows in dynamic LDS
+  MCEDM_REQUIRE((C::XL + C::WL) * sizeof(float) + rows_bytes <= 64 * 1024, "conv: %d input channels exceed the LDS row table",
+                a.Ca + a.Cb);
   if (a.resample == RS_NONE)
-    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_NONE>), dim3((unsigned)blocks), dim3(256), extra_lds, stream, a, tiles_x, tiles_y,
-                       mtiles, nchunks, cout_padded(a.Cout));
+    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_NONE>), dim3((unsigned)blocks), dim3(256), rows_bytes + extra_lds, stream, a,
+                       tiles_x, tiles_y, mtiles, nchunks, cout_padded(a.Cout));
   else if (a.resample == RS_UP)
-    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_UP>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
+    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_UP>), dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, tiles_x, tiles_y,
                        mtiles, nchunks, cout_padded(a.Cout));
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_DOWN>), dim3((unsigned)blocks), dim3(256), 0, stream, a, tiles_x, tiles_y,
+    hipLaunchKernelGGL((conv_mfma_kernel<C, RS_DOWN>), dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, tiles_x, tiles_y,
                        mtiles, nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_mfma_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = tiles_x * tiles_y;
@@ -926,12 +995,14 @@ static int launch_small_cout(const ConvArgs& a_in, hipStream_t stream) {
   const double px = (double)a.B * a.H * a.W;
   ProfScope ps("conv_small_cout_kernel", 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * 9,
                4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout), stream);
+  const unsigned rows_bytes = (unsigned)(a.Ca + a.Cb) * (unsigned)sizeof(Coef);
+  MCEDM_REQUIRE(rows_bytes <= 48 * 1024, "conv: %d input channels exceed the LDS row table", a.Ca + a.Cb);
   if (a.Cout <= 2)
-    hipLaunchKernelGGL(conv_small_cout_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a, a.wpk, a.bias, tiles_x, tiles_y,
-                       nchunks, cout_padded(a.Cout));
+    hipLaunchKernelGGL(conv_small_cout_kernel<2>, dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, a.wpk, a.bias,
+                       tiles_x, tiles_y, nchunks, cout_padded(a.Cout));
   else
-    hipLaunchKernelGGL(conv_small_cout_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, a, a.wpk, a.bias, tiles_x, tiles_y,
-                       nchunks, cout_padded(a.Cout));
+    hipLaunchKernelGGL(conv_small_cout_kernel<4>, dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, a.wpk, a.bias,
+                       tiles_x, tiles_y, nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_small_cout_kernel");
   return MCEDM_OK;
 }

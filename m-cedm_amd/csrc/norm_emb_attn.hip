@@ -144,11 +144,17 @@ __global__ __launch_bounds__(256) void gn_coef_from_sums_kernel(GnArgs a) {
   }
 }
 
+bool gn_sums_usable(const GnArgs& a) {
+  const int C = a.Ca + a.Cb;
+  if (a.groups <= 0 || C % a.groups != 0) return false;
+  const int cpg = C / a.groups;
+  return cpg % 4 == 0 && a.Ca % cpg == 0 && a.suma != nullptr && (a.Cb == 0 || a.sumb != nullptr);
+}
+
 int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream) {
   const int C = a.Ca + a.Cb;
   MCEDM_REQUIRE(a.groups > 0 && C % a.groups == 0, "group_norm: C=%d not divisible by groups=%d", C, a.groups);
-  const int cpg = C / a.groups;
-  if (cpg % 4 != 0 || a.Ca % cpg != 0 || a.suma == nullptr || (a.Cb > 0 && a.sumb == nullptr))
+  if (!gn_sums_usable(a))
     return launch_gn_coef(a, stream);            // no fused statistics for this shape: one pass over the tensor
   hipLaunchKernelGGL(gn_coef_from_sums_kernel, dim3(ceil_div(a.B * a.groups, 4)), dim3(256), 0, stream, a);
   MCEDM_LAUNCH_CHECK("gn_coef_from_sums_kernel");

@@ -492,6 +492,18 @@ Header header_for(const mcedm_plan& P, int B, int H, int W) {
 // ------------------------------------------------------------------------------------------
 // forward schedule (adm_blocks.py:364-404 and :159-181)
 // ------------------------------------------------------------------------------------------
+// Inference: the consuming conv derives the GroupNorm(+FiLM) rows itself from the producers' partial sums
+// (ConvArgs::gn_on), so no GroupNorm kernel is launched.  Training keeps the table (wgrad / GN backward read it and
+// the saved statistics), as does any consumer that needs the table in memory (need_table) or a shape without
+// usable partial sums.
+static int gn_for_conv(const GnArgs& g, ConvArgs& c, bool need_table, hipStream_t s) {
+  if (!need_table && g.stats == nullptr && gn_sums_usable(g)) {
+    c.gn = g; c.gn_on = 1; c.coef = nullptr;
+    return MCEDM_OK;
+  }
+  return launch_gn_coef_from_sums(g, s);
+}
+
 static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl, const Layout& L, void* act,
                      const float* pk, int B, int n_noise, hipStream_t s, std::vector<int>& st) {
   auto T = [&](int id) -> float* { return id < 0 ? nullptr : at<float>(act, L.t[id].off); };
@@ -506,7 +518,6 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   // norm0 -> transform table for conv0
   GnArgs g0{xa, xb, Ca, Cb, bl.Hin * bl.Win, B, b.norm0.groups, pk + b.norm0.gamma, pk + b.norm0.beta,
             nullptr, 0, 0, eps, CF(bl.coef0), T(bl.stats0), SUMS(bl.xa), SUMS(bl.xb), TL(bl.xa), TL(bl.xb)};
-  if ((rc = launch_gn_coef_from_sums(g0, s))) return rc;
   // h = conv0(resample(silu(norm0(x))))
   ConvArgs c0{};
   c0.xa = xa; c0.xb = xb; c0.Ca = Ca; c0.Cb = Cb;
@@ -516,6 +527,7 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   c0.Hs = bl.Hin; c0.Ws = bl.Win; c0.H = bl.H; c0.W = bl.W;
   c0.wpk = pk + b.conv0.wpk; c0.bias = pk + b.conv0.bias;
   c0.out = T(bl.h); c0.Cout = b.cout; c0.B = B; c0.gsum = SUMS(bl.h); c0.gsum_tiles = &st[bl.h];
+  if ((rc = gn_for_conv(g0, c0, /*need_table=*/bl.xd >= 0, s))) return rc;
   if (bl.xd >= 0) {
     WgradArgs m{};
     m.xa = xa; m.xb = xb; m.Ca = Ca; m.Cb = Cb; m.coef = c0.coef; m.coef_batch = 1; m.act = 1; m.resample = RS_DOWN;
@@ -529,7 +541,6 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   const float* film = at<float>(act, L.t[L.film].off) + b.film_row0;
   GnArgs g1{T(bl.h), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm1.groups, pk + b.norm1.gamma, pk + b.norm1.beta,
             film, n_noise > 1 ? 1 : 0, P.film_rows, eps, CF(bl.coef1), T(bl.stats1), SUMS(bl.h), nullptr, TL(bl.h), 0};
-  if ((rc = launch_gn_coef_from_sums(g1, s))) return rc;
   // skip path
   const float* res = xa;
   int res_mode = RS_NONE;
@@ -552,18 +563,19 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   c1.wpk = pk + b.conv1.wpk; c1.bias = pk + b.conv1.bias;
   c1.res = res; c1.res_mode = res_mode;
   c1.out = T(bl.y); c1.Cout = b.cout; c1.B = B; c1.gsum = SUMS(bl.y); c1.gsum_tiles = &st[bl.y];
+  if ((rc = gn_for_conv(g1, c1, false, s))) return rc;
   if ((rc = launch_conv(c1, 9, s))) return rc;
   if (!b.attn) return MCEDM_OK;
   // attention: z = proj(attn(qkv(norm2(y)))) + y
   GnArgs g2{T(bl.y), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm2.groups, pk + b.norm2.gamma, pk + b.norm2.beta,
             nullptr, 0, 0, eps, CF(bl.coef2), T(bl.stats2), SUMS(bl.y), nullptr, TL(bl.y), 0};
-  if ((rc = launch_gn_coef_from_sums(g2, s))) return rc;
   ConvArgs cq{};
   cq.xa = T(bl.y); cq.Ca = b.cout;
   cq.coef = CF(bl.coef2); cq.coef_batch = 1; cq.act = 0;
   cq.Hs = bl.H; cq.Ws = bl.W; cq.H = bl.H; cq.W = bl.W;
   cq.wpk = pk + b.qkv.wpk; cq.bias = pk + b.qkv.bias;
   cq.out = T(bl.qkv); cq.Cout = 3 * b.cout; cq.B = B;
+  if ((rc = gn_for_conv(g2, cq, false, s))) return rc;
   if ((rc = launch_conv(cq, 1, s))) return rc;
   if ((rc = launch_attention(T(bl.qkv), T(bl.a), B, b.heads, bl.H * bl.W, s))) return rc;
   ConvArgs cp{};
@@ -604,13 +616,13 @@ static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, c
             pk + P.out_norm.beta, nullptr, 0, 0, 1e-5f, at<Coef>(act, L.t[L.coef_out].off),
             L.stats_out >= 0 ? at<float>(act, L.t[L.stats_out].off) : nullptr,
             last.sums != NONE ? at<float>(act, last.sums) : nullptr, nullptr, st[L.last], 0};
-  if ((rc = launch_gn_coef_from_sums(go, s))) return rc;
   ConvArgs co{};
   co.xa = at<float>(act, last.off); co.Ca = last.C;
   co.coef = at<Coef>(act, L.t[L.coef_out].off); co.coef_batch = 1; co.act = 1;
   co.Hs = H; co.Ws = W; co.H = H; co.W = W;
   co.wpk = pk + P.conv_out.wpk; co.bias = pk + P.conv_out.bias;
   co.out = out; co.Cout = P.desc.out_channels; co.B = B;
+  if ((rc = gn_for_conv(go, co, false, s))) return rc;
   return launch_conv(co, 9, s);
 }
 
