@@ -148,7 +148,6 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
 int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
   const int C = a.Ca + a.Cb;
   MCEDM_REQUIRE(a.groups > 0 && C % a.groups == 0 && C / a.groups <= GN_MAX_CPG, "gn_bwd: bad groups (C=%d groups=%d)", C, a.groups);
-  MCEDM_REQUIRE(a.Cb == 0 || a.Ca % (C / a.groups) == 0, "gn_bwd: a group straddles the concat boundary");
   MCEDM_REQUIRE(a.dact && a.xa && a.coef && a.stats && a.gamma && a.dxa && a.ab && (a.Cb == 0 || (a.xb && a.dxb)), "gn_bwd: null pointer");
   MCEDM_REQUIRE(a.resample != RS_DOWN || (a.Hs % 2 == 0 && a.Ws % 2 == 0), "gn_bwd: odd source size for a 2x2 mean");
   ProfScope ps("gn_bwd_kernel", 20.0 * a.B * (double)C * a.Hs * a.Ws, 4.0 * 3 * a.B * (double)C * a.Hs * a.Ws, s);

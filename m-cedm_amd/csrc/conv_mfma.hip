@@ -128,17 +128,19 @@ __device__ __forceinline__ void stage_coef_rows(const ConvArgs& p, int n, Coef* 
     const int gi = g0 + tid / lpg;
     const bool live = gi < G;
     const int c0 = live ? gi * cpg : 0;
-    const bool in_a = c0 < g.Ca;
-    const float* sums = in_a ? g.suma : g.sumb;
-    const int tiles = live ? (in_a ? g.tiles_a : g.tiles_b) : 0;
-    const int Cs = in_a ? g.Ca : g.Cb;
-    const int q4 = (Cs + 3) / 4;
-    const int q0 = (in_a ? c0 : c0 - g.Ca) / 4;
-    const int nq = cpg / 4;
+    const int nq = cpg / 4;          // the group = nq 4-channel blocks, each in xa's or xb's table (may straddle)
     double s1 = 0, s2 = 0;
-    for (int t = sub; t < tiles; t += lpg) {
-      const float* row = sums + (((size_t)n * tiles + t) * q4 + q0) * 2;
-      for (int q = 0; q < nq; ++q) { s1 += (double)row[2 * q]; s2 += (double)row[2 * q + 1]; }
+    for (int q = 0; q < (live ? nq : 0); ++q) {
+      const int cb = c0 + 4 * q;
+      const bool in_a = cb < g.Ca;
+      const float* sums = in_a ? g.suma : g.sumb;
+      const int tiles = in_a ? g.tiles_a : g.tiles_b;
+      const int q4 = ((in_a ? g.Ca : g.Cb) + 3) / 4;
+      const int qi = (in_a ? cb : cb - g.Ca) / 4;
+      for (int t = sub; t < tiles; t += lpg) {
+        const float* row = sums + (((size_t)n * tiles + t) * q4 + qi) * 2;
+        s1 += (double)row[0]; s2 += (double)row[1];
+      }
     }
     for (int off = lpg >> 1; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
     if (live) {

@@ -19,25 +19,30 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(GnArgs a) {
   const int n = blockIdx.x / a.groups;
   const int g = blockIdx.x % a.groups;
   const int c0 = g * cpg;
-  const float* src = (c0 < a.Ca) ? a.xa + ((size_t)n * a.Ca + c0) * a.HW
-                                 : a.xb + ((size_t)n * a.Cb + (c0 - a.Ca)) * a.HW;
+  // a group of the virtual concat cat(xa, xb) may straddle the boundary: the source is chosen per channel
+  auto plane = [&](int c) {
+    return (c < a.Ca) ? a.xa + ((size_t)n * a.Ca + c) * a.HW : a.xb + ((size_t)n * a.Cb + (c - a.Ca)) * a.HW;
+  };
   const int N = cpg * a.HW;
-  const float shift = src[0];
+  const float shift = plane(c0)[0];
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const int tid = threadIdx.x;
-  if ((N & 3) == 0) {
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-    const int N4 = N >> 2;
-    for (int i = tid; i < N4; i += 256) {
-      const float4 v = s4[i];
-      const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
-      s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
-      s2[0] += d0 * d0; s2[1] += d1 * d1; s2[2] += d2 * d2; s2[3] += d3 * d3;
-    }
-  } else {
-    for (int i = tid; i < N; i += 256) {
-      const float d = src[i] - shift;
-      s1[0] += d; s2[0] += d * d;
+  for (int cl = 0; cl < cpg; ++cl) {
+    const float* src = plane(c0 + cl);
+    if ((a.HW & 3) == 0) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      const int N4 = a.HW >> 2;
+      for (int i = tid; i < N4; i += 256) {
+        const float4 v = s4[i];
+        const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+        s1[0] += d0; s1[1] += d1; s1[2] += d2; s1[3] += d3;
+        s2[0] += d0 * d0; s2[1] += d1 * d1; s2[2] += d2 * d2; s2[3] += d3 * d3;
+      }
+    } else {
+      for (int i = tid; i < a.HW; i += 256) {
+        const float d = src[i] - shift;
+        s1[0] += d; s2[0] += d * d;
+      }
     }
   }
   double t1 = ((double)s1[0] + (double)s1[1]) + ((double)s1[2] + (double)s1[3]);
@@ -85,7 +90,6 @@ int launch_gn_coef(const GnArgs& a, hipStream_t stream) {
   const int C = a.Ca + a.Cb;
   MCEDM_REQUIRE(a.groups > 0 && C % a.groups == 0, "group_norm: C=%d not divisible by groups=%d", C, a.groups);
   const int cpg = C / a.groups;
-  MCEDM_REQUIRE(a.Cb == 0 || a.Ca % cpg == 0, "group_norm: a group straddles the concat boundary (Ca=%d cpg=%d)", a.Ca, cpg);
   MCEDM_REQUIRE(cpg <= 256, "group_norm: too many channels per group (%d)", cpg);
   MCEDM_REQUIRE(a.xa != nullptr && (a.Cb == 0 || a.xb != nullptr), "group_norm: null input");
   ProfScope ps("gn_coef_kernel", 3.0 * a.B * (double)C * a.HW, 4.0 * a.B * (double)C * a.HW, stream);
@@ -106,17 +110,21 @@ __global__ __launch_bounds__(256) void gn_coef_from_sums_kernel(GnArgs a) {
   const int n = pair / a.groups, g = pair - n * a.groups;
   const int cpg = C / a.groups;
   const int c0 = g * cpg;
-  const bool in_a = c0 < a.Ca;
-  const float* sums = in_a ? a.suma : a.sumb;
-  const int tiles = in_a ? a.tiles_a : a.tiles_b;
-  const int Cs = in_a ? a.Ca : a.Cb;
-  const int q4 = (Cs + 3) / 4;                       // 4-channel groups of the source tensor
-  const int q0 = (in_a ? c0 : c0 - a.Ca) / 4;
+  // the group is a run of 4-channel blocks; each block lives in xa's or xb's table (a group may straddle the
+  // concat boundary: Ca is a multiple of 4, see gn_sums_usable)
   const int nq = cpg / 4;
   double s1 = 0, s2 = 0;
-  for (int t = lane; t < tiles; t += 64) {
-    const float* row = sums + (((size_t)n * tiles + t) * q4 + q0) * 2;
-    for (int q = 0; q < nq; ++q) { s1 += (double)row[2 * q]; s2 += (double)row[2 * q + 1]; }
+  for (int q = 0; q < nq; ++q) {
+    const int cb = c0 + 4 * q;
+    const bool in_a = cb < a.Ca;
+    const float* sums = in_a ? a.suma : a.sumb;
+    const int tiles = in_a ? a.tiles_a : a.tiles_b;
+    const int q4 = ((in_a ? a.Ca : a.Cb) + 3) / 4;
+    const int qi = (in_a ? cb : cb - a.Ca) / 4;
+    for (int t = lane; t < tiles; t += 64) {
+      const float* row = sums + (((size_t)n * tiles + t) * q4 + qi) * 2;
+      s1 += (double)row[0]; s2 += (double)row[1];
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
@@ -148,7 +156,7 @@ bool gn_sums_usable(const GnArgs& a) {
   const int C = a.Ca + a.Cb;
   if (a.groups <= 0 || C % a.groups != 0) return false;
   const int cpg = C / a.groups;
-  return cpg % 4 == 0 && a.Ca % cpg == 0 && a.suma != nullptr && (a.Cb == 0 || a.sumb != nullptr);
+  return cpg % 4 == 0 && a.Ca % 4 == 0 && a.suma != nullptr && (a.Cb == 0 || a.sumb != nullptr);
 }
 
 int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream) {

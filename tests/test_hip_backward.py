@@ -213,11 +213,16 @@ def test_training_step_golden(lib, golden):
     np.testing.assert_allclose(each, g["grad_sqnorm_each"], rtol=5e-3)
 
 
-@pytest.mark.parametrize("cfg_name", ["P", "W"])
+CFG_M = orc.UNetConfig(ch=64, ch_mult=(1, 2, 4), attn_resolutions=(8,))
+
+
+@pytest.mark.parametrize("cfg_name", ["P", "W", "M"])
 def test_training_step_all_grads_vs_oracle(lib, cfg_name):
-    """every parameter gradient vs autograd through the oracle (P: ch=64 3 levels; W: ch=128, 4 levels, 2-head attention)"""
-    cfg = fx.CFG_P if cfg_name == "P" else fx.CFG_W
-    B, H, W = (2, 32, 32) if cfg_name == "P" else (2, 16, 16)
+    """every parameter gradient vs autograd through the oracle (P: ch=64 3 levels; W: ch=128, 4 levels, 2-head attention;
+    M: channel multipliers (1, 2, 4): decoder concats 256+128 / 128+64 whose GroupNorm groups (12 / 6 channels)
+    straddle the concat boundary, 4-head attention at 8x8)"""
+    cfg = {"P": fx.CFG_P, "W": fx.CFG_W, "M": CFG_M}[cfg_name]
+    B, H, W = (2, 16, 16) if cfg_name == "W" else (2, 32, 32)
     tag = f"t/bwd/train/{cfg_name}"
     P = orc.make_params(cfg, 3)
     xc = fx.randn(tag + "/x", B, 2, H, W)
@@ -235,3 +240,19 @@ def test_training_step_all_grads_vs_oracle(lib, cfg_name):
     close(loss, ref_loss.detach().reshape(1), what="loss")
     for n in plan.param_names:
         close(grads[n], Pg[n].grad, rtol=1e-3, rel_atol=1e-4, what=f"grad {n}")
+
+
+def test_inference_forward_wide_multipliers_vs_oracle(lib):
+    """config M through the inference path (GroupNorm rows derived inside the consuming conv, groups straddling the
+    concat boundary) against the oracle's preconditioned forward"""
+    P = orc.make_params(CFG_M, 5)
+    plan = make_plan(lib, CFG_M)
+    packed = plan.pack({k: dev(v) for k, v in P.items()})
+    B, H, W = 3, 32, 32
+    x = fx.randn("t/fwd/M/x", B, 2, H, W) * 2.0
+    cond = fx.randn("t/fwd/M/c", B, 2, H, W)
+    sigma = torch.tensor([0.7, 2.0, 11.0])
+    D = plan.denoise(packed, dev(x), dev(sigma), cond=dev(cond))
+    with torch.no_grad():
+        ref = orc.model_precond(P, CFG_M, x, sigma, cond)
+    close(D, ref, what="denoised (config M)")
