@@ -105,9 +105,15 @@ class DhariwalUNet(nn.Module):
         cond_channels = _get(m, "cond_channels", 0)
         if cond_channels > 0 and not _get(m, "cat_cond", False):
             unsupported.append("cond_enc (cat_cond=False)")
+        ch, mult = m.ch, tuple(m.ch_mult)
+        # attention widths: the bottleneck 'in0' block always, plus every level named in attn_resolutions; the
+        # kernels are built for head_dim 64, the reference's head_dim is C / (C // 64) (adm_blocks.py:135,175)
+        attn_widths = {ch * mult[-1]} | {ch * mu for lv, mu in enumerate(mult) if (m.resolution >> lv) in m.attn_resolutions}
+        bad = sorted(c for c in attn_widths if c >= 64 and c % 64)
+        if bad:
+            unsupported.append(f"attention over {bad} channels (head_dim != 64)")
         if unsupported:
             raise NotImplementedError("outside the MI355X hot path (SURVEY.md section 8a): " + ", ".join(unsupported))
-        ch, mult = m.ch, tuple(m.ch_mult)
         self.resolution = m.resolution
         self.in_channels = m.in_channels + cond_channels
         self.cond_channels = cond_channels

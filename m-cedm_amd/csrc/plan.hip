@@ -167,6 +167,16 @@ extern "C" int mcedm_unet_plan_create(const mcedm_unet_desc* d, mcedm_plan** out
   }
   P.out_norm = make_norm(P, "out_norm", cout);
   P.conv_out = make_conv(P, "out_conv", cout, d->out_channels, 3);
+  // the attention kernels are built for head_dim == 64; the reference's head_dim is cout / (cout // 64)
+  // (adm_blocks.py:135,175), which differs as soon as cout is not a multiple of 64 (e.g. 96 -> one head of 96)
+  for (auto* v : {&P.enc, &P.dec})
+    for (const BlockP& b : *v)
+      if (b.attn && b.cout % d->channels_per_head != 0) {
+        set_error("plan_create: block %s has attention with %d channels, not a multiple of channels_per_head=%d "
+                  "(head_dim %d is not built)", b.key.c_str(), b.cout, d->channels_per_head, b.cout / b.heads);
+        delete Pp;
+        return MCEDM_ERR_UNSUPPORTED;
+      }
 
   // packed-buffer layout
   Taker t;

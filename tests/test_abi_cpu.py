@@ -1,0 +1,80 @@
+"""CPU-only checks of the C ABI (no compute calls): libmcedm_hip.so loads without a GPU, exports exactly the symbols
+include/mcedm_hip.h declares, and its host-side entry points (plan construction, parameter table, sizes, the sigma
+schedule, argument validation) behave as documented."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+import mcedm_amd  # noqa: F401
+from mcedm_amd import lib as L
+from oracle import mcedm_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mcedm_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcedm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    names = declared_symbols()
+    assert len(names) >= 36
+    for n in names:
+        getattr(lib, n)                                  # AttributeError == header / library drift
+    nm = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\bT (mcedm_[a-z0-9_]+)$", nm, flags=re.M)))
+    assert exported == names, (set(exported) ^ set(names))
+    assert sorted(set(L.EXPORTS + L.OP_EXPORTS)) == names, set(L.EXPORTS + L.OP_EXPORTS) ^ set(names)
+    assert lib.mcedm_version() == 1
+
+
+def test_plan_parameter_table_matches_state_dict_order():
+    for cfg in (orc.UNetConfig(), orc.UNetConfig(ch=128, ch_mult=(1, 1, 1, 1), attn_resolutions=(16,))):
+        plan = L.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks,
+                      cfg.attn_resolutions, cfg.resolution)
+        ref = orc.param_shapes(cfg)
+        assert plan.param_names == [n for n, _ in ref]
+        assert plan.param_shapes == [tuple(s) for _, s in ref]
+        assert plan.packed_bytes > 4 * sum(int(torch.tensor(s).prod()) for _, s in ref)
+        assert plan.workspace_bytes(2, 32, 32) < plan.workspace_bytes(2, 32, 32, training=True)
+        assert plan.sampler_workspace_bytes(2, 32, 32) > plan.workspace_bytes(2, 32, 32)
+
+
+def test_t_steps_host_helper_matches_oracle():
+    sd = L.sampler_desc(orc.SamplerParams(timesteps=18))
+    t = torch.tensor(L.edm_t_steps(sd), dtype=torch.float64)
+    torch.testing.assert_close(t, orc.edm_t_steps(18, 0.002, 80.0, 7.0), rtol=1e-14, atol=0)
+    assert t[-1] == 0 and t[0] == 80.0
+
+
+@pytest.mark.parametrize("ch,mult,attn", [(96, (1, 1), ()), (32, (1, 5), ()), (64, (1, 1, 1), (64,)), (160, (1,), ())])
+def test_attention_width_not_a_multiple_of_64_is_rejected(ch, mult, attn):
+    """head_dim = C / (C // 64) in the reference (adm_blocks.py:135,175); only head_dim 64 is built, so a
+    width like 96 or 160 at an attention block must be refused, not computed with 64-wide heads."""
+    width_bad = any((ch * m) % 64 and ch * m >= 64 for lv, m in enumerate(mult) if lv == len(mult) - 1 or (128 >> lv) in attn)
+    if width_bad:
+        with pytest.raises(RuntimeError, match="channels_per_head"):
+            L.Plan(2, 2, 2, ch, mult, 1, attn, 128)
+    else:
+        L.Plan(2, 2, 2, ch, mult, 1, attn, 128)
+
+
+def test_host_side_argument_validation():
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        L.Plan(2, 2, 2, 12, (1,), 1, (), 128)
+    plan = L.Plan(2, 2, 2, 64, (1, 1, 1), 1, (32,), 128)
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        plan.workspace_bytes(1, 30, 32)
+    sd = L.sampler_desc(orc.SamplerParams(timesteps=1))
+    with pytest.raises(RuntimeError, match="timesteps"):
+        L.edm_t_steps(sd)
+    with pytest.raises(RuntimeError, match="CPU tensor"):
+        plan.forward(torch.zeros(8), torch.zeros(1, 2, 32, 32), torch.zeros(1))
