@@ -1,27 +1,43 @@
 #!/usr/bin/env python
 """bench.py -- denoised states/sec of the 18-step EDM Heun sampler (35 U-Net evaluations per state).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s128|s32|ref128] [--batch B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W          # N > 1: one rank per GPU
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload s128|s32|ref128|s128l3] [--batch B]
 
-A "step" is one pass of the hot path over one batch: ``sample_edm`` (models/mcedm.py:570-638) on B states per
-GPU, inputs already resident in HBM.  The batch axis is sharded across ranks with no data-path collective
-(SURVEY.md section 8e), so scaling is weak: per-GPU batch is fixed.  Rank 0 prints ONE JSON line.
+`--gpus N` (N > 1) works as typed: before anything touches the GPU the process starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`
+as a child (one rank per GPU over RCCL) and exits with its status.  Launched by torch.distributed.run directly
+(RANK / WORLD_SIZE in the environment) it is a rank.
+
+A "step" is one pass of the hot path over one batch: ``sample_edm`` (models/mcedm.py:570-638) on B states per GPU,
+inputs already resident in HBM.  The batch axis is sharded across ranks with no data-path collective, so
+scaling is weak: per-GPU batch is fixed.  Rank 0 prints ONE JSON line.
+
+What is timed, and how:
+  * headline `value`: K sampler calls between barrier + synchronize brackets, profiler OFF, the whole call replayed
+    from one HIP graph (mcedm_amd.lib.GraphedSampler; `--no-graph` launches the ~4000 kernels eagerly instead);
+  * `roofline` / `kernels`: a SEPARATE pass of `--profile-steps` eager calls with HIP event pairs around every launch
+    on the launch stream (mcedm_prof_enable): per-kernel average duration against algorithmic flops / bytes;
+  * `cpu_baseline`: the oracle (CPU restatement of the reference) on a bounded sample, 1 warm-up + median of 3, on all
+    physical cores and on one thread.
 
 Workloads (BASELINE.json `configs`):
   s128    SWE-periodic 128x128, EDM U-Net ch=128, ch_mult [1,1,1,1], attention at 16^2, 32 states / GPU  (config 3; default,
           the configuration the metric is quoted on)
+  s128l3  the same with the literal ch_mult [1,1,1] (attention only in the bottleneck block, SURVEY.md 8d "both ways")
   s32     SWE-periodic 32x32, ch=64, ch_mult [1,1,1], 64 states / GPU                                    (config 2)
   ref128  the reference's own adm_edm_mcedm_res32 network (ch=64) on 128x128 fields, 32 states / GPU
+The default run also reports s32 / ref128 / s128l3 as `secondary` entries (a few seconds each).
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,6 +45,8 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     "s128": dict(ch=128, ch_mult=(1, 1, 1, 1), attn=(16,), H=128, W=128, batch=32,
                  name="SWE-periodic 128x128, EDM U-Net ch=128 ch_mult=[1,1,1,1] attn@16^2 (BASELINE config 3)"),
+    "s128l3": dict(ch=128, ch_mult=(1, 1, 1), attn=(16,), H=128, W=128, batch=32,
+                   name="SWE-periodic 128x128, EDM U-Net ch=128 ch_mult=[1,1,1] (config 3 read literally: 3 levels)"),
     "s32": dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=32, W=32, batch=64,
                 name="SWE-periodic 32x32, EDM U-Net ch=64 ch_mult=[1,1,1] (BASELINE config 2)"),
     "ref128": dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32,
@@ -36,11 +54,58 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
+STEPS = 18                      # Heun steps -> 2*18 - 1 = 35 U-Net evaluations per state
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="s128", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="states per GPU (default: the workload's)")
+    ap.add_argument("--no-graph", action="store_true", help="launch the sampler's kernels eagerly instead of one HIP graph")
+    ap.add_argument("--profile-steps", type=int, default=1, help="sampler calls in the separate event-timed pass")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the (untimed) training-step measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other workloads")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """N > 1 typed directly: this process never initialises HIP; N fresh ranks do the work."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def synth_params(plan, seed, device):
+    """Random-init weights of the architecture, keyed like DhariwalUNet.state_dict(): conv / linear weights
+    U(-1,1)/sqrt(fan_in), GroupNorm gains 1 + 0.2 U, everything else 0.1 U (the reference's own init zeroes conv1 / proj /
+    out_conv, adm_blocks.py:145,157,317, which would make every output identically zero)."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    P = {}
+    for name, shape in zip(plan.param_names, plan.param_shapes):
+        u = torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1
+        if name.endswith(".weight") and len(shape) >= 2:
+            v = u / math.sqrt(math.prod(shape[1:]))
+        elif ".norm" in name or name.startswith("out_norm"):
+            v = 1 + 0.2 * u if name.endswith(".weight") else 0.1 * u
+        else:
+            v = 0.1 * u
+        P[name] = v.to(torch.float32).to(device)
+    return P
 
 
 def synth_inputs(B, H, W, seed, device):
     """Seeded N(0,1) normalised state, 'u'-task mask (h observed, u missing; datamodules/h5_dataset.py:245-247),
     cond = state*(1-mask) + N(0,1)*mask (models/mcedm.py:247), initial noise."""
+    import torch
     g = torch.Generator(device="cpu").manual_seed(seed)
     state = torch.randn(B, 2, H, W, generator=g)
     mask = torch.zeros(B, 2, H, W)
@@ -50,41 +115,178 @@ def synth_inputs(B, H, W, seed, device):
     return cond.to(device), mask.to(device), init.to(device)
 
 
-def cpu_baseline(cfg, wl, sample_states, steps=18):
-    """The oracle (CPU restatement of the reference, oracle/mcedm_oracle.py) timed on this host's cores on a
-    bounded sample of the same workload."""
+def host_cpu():
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+    except OSError:
+        pass
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    physical = min(len(cores), logical) if cores else logical
+    return model, physical, logical
+
+
+def cpu_baseline(wl, params_cpu):
+    """The oracle (CPU restatement of the reference, oracle/mcedm_oracle.py) on this host's cores, on a BOUNDED sample of
+    the same workload: one state through a shortened Heun pass (same network, same field size; cost per U-Net evaluation
+    is what matters, and a state costs 35 of them), 1 warm-up + median of 3, scaled to states/s of the 18-step sampler.
+    Run twice: all physical cores, and one thread."""
+    import torch
     from oracle import mcedm_oracle as orc
-    threads = torch.get_num_threads()
-    P = orc.make_params(cfg, 7)
-    cond, mask, init = synth_inputs(sample_states, wl["H"], wl["W"], 1, "cpu")
-    sp = orc.SamplerParams(timesteps=steps)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        orc.sample_edm(P, cfg, cond, mask, sp, init)
-    dt = time.perf_counter() - t0
-    return {"value": sample_states / dt, "unit": "states/s", "cores": threads, "kind": "port",
-            "sample": f"{sample_states} state(s) of the same workload, one 18-step Heun pass (35 NFE), {dt:.1f} s, "
-                      f"torch {torch.__version__} CPU fp32, {threads} threads"}
+    cfg = orc.UNetConfig(ch=wl["ch"], ch_mult=wl["ch_mult"], attn_resolutions=wl["attn"])
+    model, physical, logical = host_cpu()
+    big = wl["H"] * wl["W"] * wl["ch"] >= 128 * 128 * 64
+    out = {}
+    for label, threads, states, nsteps in (("all_cores", physical, 1 if big else 8, 4 if big else STEPS),
+                                           ("one_thread", 1, 1, 2 if big else 6)):
+        torch.set_num_threads(threads)
+        cond, mask, init = synth_inputs(states, wl["H"], wl["W"], 1, "cpu")
+        sp = orc.SamplerParams(timesteps=nsteps)
+        nfe = 2 * nsteps - 1
+        times = []
+        with torch.no_grad():
+            for rep in range(4):
+                t0 = time.perf_counter()
+                orc.sample_edm(params_cpu, cfg, cond, mask, sp, init)
+                times.append(time.perf_counter() - t0)
+        med = statistics.median(times[1:])
+        out[label] = {"states_per_s": states / (med * (2 * STEPS - 1) / nfe), "threads": threads,
+                      "sample": f"{states} state(s) x {nfe} U-Net evaluations ({nsteps}-step Heun), median of 3 after 1 warm-up: "
+                                f"{med:.2f} s; scaled x{(2 * STEPS - 1) / nfe:.2f} to the 35 evaluations of an 18-step state"}
+    torch.set_num_threads(physical)
+    a = out["all_cores"]
+    return {"value": a["states_per_s"], "unit": "states/s", "cores": a["threads"], "kind": "port",
+            "sample": a["sample"] + f"; torch {torch.__version__} CPU fp32", "cpu_model": model,
+            "physical_cores": physical, "logical_cpus": logical,
+            "one_thread": {"value": out["one_thread"]["states_per_s"], "unit": "states/s", "cores": 1,
+                           "sample": out["one_thread"]["sample"]}}
+
+
+def csrc_digest():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "m-cedm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py writes
+    profiles/r2_traffic.json with the digest of the kernel sources it was taken on); refused when the sources changed."""
+    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    try:
+        tr = json.load(open(path))
+    except Exception:
+        return None, "no committed PMC pass"
+    if tr.get("csrc_digest") != csrc_digest():
+        return None, f"stale: PMC pass taken at csrc {tr.get('csrc_digest')}, sources are now {csrc_digest()}"
+    for k, v in tr.get("kernels", {}).items():
+        if k.replace("mcedm::", "").replace(" ", "") == kernel_name.replace(" ", ""):
+            return v["traffic_bytes"], "rocprofv3 FETCH_SIZE + WRITE_SIZE (gfx950 corrections of MI355X_MICROARCH.md), avg per launch"
+    return None, "kernel not in the committed PMC pass"
+
+
+class Runner:
+    """One workload on this rank's GPU: plan, weights, inputs, graph."""
+
+    def __init__(self, key, B, device, rank, use_graph):
+        import torch
+        from mcedm_amd import lib
+        self.lib, self.torch = lib, torch
+        wl = WORKLOADS[key]
+        self.wl, self.B, self.H, self.W = wl, B or wl["batch"], wl["H"], wl["W"]
+        self.plan = lib.Plan(2, 2, 2, wl["ch"], wl["ch_mult"], 1, wl["attn"], 128)
+        self.params = synth_params(self.plan, 7, device)
+        self.packed = self.plan.pack(self.params)
+        self.cond, self.mask, self.init = synth_inputs(self.B, self.H, self.W, 1000 + rank, device)
+
+        class SP:      # configs/diff_sampler/edm_sampler.yaml with S_churn = 0 (deterministic Heun), w = 0
+            timesteps, sigma_min, sigma_max, rho, S_churn, S_min, S_max, S_noise, w = STEPS, 0.002, 80.0, 7.0, 0.0, 0.0, float("inf"), 1.0, 0.0
+        self.sd = lib.sampler_desc(SP)
+        self.ws = lib.Workspace()
+        self.graph = lib.GraphedSampler(self.plan, self.packed, self.sd, self.B, self.H, self.W) if use_graph else None
+
+    def step(self):
+        if self.graph is not None:
+            return self.graph(self.cond, self.mask, self.init)
+        return self.eager()
+
+    def eager(self):
+        return self.plan.sample(self.packed, self.sd, self.cond, self.mask, self.init, None, return_last=True, ws=self.ws)
+
+    def profile(self, steps):
+        """Separate event-timed pass (eager launches; HIP events cannot be recorded inside a graph)."""
+        lib, torch = self.lib, self.torch
+        self.eager()
+        torch.cuda.synchronize()
+        lib.prof_enable(True)
+        for _ in range(steps):
+            self.eager()
+        torch.cuda.synchronize()
+        lib.prof_enable(False)
+        return lib.prof_report()
+
+    def fwd_ms(self, reps=5):
+        torch = self.torch
+        x32 = self.init * 3.0
+        sig = torch.tensor([1.5], device=x32.device)
+        self.plan.denoise(self.packed, x32, sig, cond=self.cond, ws=self.ws)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self.plan.denoise(self.packed, x32, sig, cond=self.cond, ws=self.ws)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+
+def kernel_table(prof):
+    rows = sorted(({"name": r["name"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
+                    "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2),
+                    "gbps": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in prof if r["total_ms"] > 0),
+                  key=lambda r: -r["total_ms"])
+    return rows
+
+
+def roofline_of(prof):
+    total_ms = sum(r["total_ms"] for r in prof) or 1.0
+    dom = max(prof, key=lambda r: r["total_ms"])
+    avg_ms = dom["total_ms"] / dom["launches"]
+    achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+    traffic, note = committed_traffic(dom["name"])
+    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": note,
+            "kernel": dom["name"], "launches": dom["launches"], "avg_launch_ms": avg_ms,
+            "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
+            "share_of_kernel_time": dom["total_ms"] / total_ms,
+            "hbm_frac_on_algorithmic_bytes": dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            "measured": "HIP event pairs on the launch stream, separate eager pass after the timed region"}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="s128", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="states per GPU (default: the workload's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the (untimed) training-step measurement")
-    ap.add_argument("--cpu-states", type=int, default=0, help="states in the CPU baseline sample (default: auto)")
-    args = ap.parse_args()
-
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs one rank per GPU: launch with python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+
+    import torch
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -94,22 +296,9 @@ def main():
 
     import mcedm_amd  # noqa: F401
     from mcedm_amd import lib
-    from oracle import mcedm_oracle as orc       # only for the architecture record + deterministic weights + cpu_baseline
 
-    wl = WORKLOADS[args.workload]
-    B = args.batch or wl["batch"]
-    H, W = wl["H"], wl["W"]
-    cfg = orc.UNetConfig(ch=wl["ch"], ch_mult=wl["ch_mult"], attn_resolutions=wl["attn"])
-    plan = lib.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks,
-                    cfg.attn_resolutions, cfg.resolution)
-    params = {k: v.to(device) for k, v in orc.make_params(cfg, 7).items()}     # random-init weights of that architecture
-    packed = plan.pack(params)
-    cond, mask, init = synth_inputs(B, H, W, 1000 + rank, device)
-    sd = lib.sampler_desc(orc.SamplerParams(timesteps=18))                     # S_churn=0, w=0: deterministic Heun
-    ws = lib.Workspace()
-
-    def step():
-        return plan.sample(packed, sd, cond, mask, init, None, return_last=True, ws=ws)
+    run = Runner(args.workload, args.batch, device, rank, not args.no_graph)
+    wl, B, H, W = run.wl, run.B, run.H, run.W
 
     def barrier():
         if world > 1:
@@ -117,74 +306,42 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        run.step()
     barrier()
-    lib.prof_enable(rank == 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = run.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    lib.prof_enable(False)
-    prof = lib.prof_report() if rank == 0 else []
     assert torch.isfinite(out).all()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
-    # U-Net forward latency (one model_precond call, models/mcedm.py:199-211), outside the timed region
-    x32 = init * 3.0
-    sig = torch.tensor([1.5], device=device)
-    plan.denoise(packed, x32, sig, cond=cond, ws=ws)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    nf = 5
-    for _ in range(nf):
-        plan.denoise(packed, x32, sig, cond=cond, ws=ws)
-    e1.record()
-    torch.cuda.synchronize()
-    fwd_ms = e0.elapsed_time(e1) / nf
+    prof = run.profile(args.profile_steps) if rank == 0 else []
+    fwd_ms = run.fwd_ms()
 
     # one data-parallel training step (models/mcedm.py:254-281 + clip/Adam/EMA), outside the timed region:
     # noise -> denoise(training) -> loss -> backward -> gradient all-reduce -> fused clip+Adam+EMA
     train_ms = None
     if not args.no_train:
-        from mcedm_amd.train import allreduce_mean_, views_like
-        names = plan.param_names
-        flat_p = torch.cat([params[n].reshape(-1) for n in names])
-        pviews = dict(zip(names, views_like(flat_p, [params[n] for n in names])))
-        flat_g, flat_m, flat_v, flat_e = (torch.zeros_like(flat_p) for _ in range(4))
-        flat_e.copy_(flat_p)
-        gviews = views_like(flat_g, [params[n] for n in names])
-        sq = torch.zeros(1, dtype=torch.float64, device=device)
+        from mcedm_amd.train import FlatTrainState
+        ts = FlatTrainState(run.plan, run.params, packed=run.packed)
         gen = torch.Generator(device="cpu").manual_seed(7 + rank)
         xs = torch.randn(B, 2, H, W, generator=gen).to(device)
         nz = torch.randn(B, 2, H, W, generator=gen).to(device)
         rn = torch.randn(B, generator=gen).to(device)
-        tws = lib.Workspace()
-
-        def train_step(k):
-            pk = plan.pack(pviews, packed)
-            x_noise, sigma = lib.edm_noise_inputs(xs, mask, nz, rn)
-            D = plan.denoise(pk, x_noise, sigma, cond=cond, ws=tws, training=True)
-            loss, dD = lib.edm_loss(D, xs, mask, sigma)
-            plan.denoise_backward(pk, pviews, x_noise, sigma, cond, dD, gviews, tws)
-            allreduce_mean_(flat_g, average=False)
-            lib.sqnorm(flat_g, sq)
-            lib.adam_ema_step(flat_p, flat_g, flat_m, flat_v, flat_e, k, sqnorm_t=sq, grad_scale=1.0 / world)
-            return loss
-
-        train_step(1)
+        ts.step(xs, run.cond, run.mask, nz, rn)
         barrier()
         t1 = time.perf_counter()
         nt = 3
-        for k in range(nt):
-            loss = train_step(2 + k)
+        for _ in range(nt):
+            loss = ts.step(xs, run.cond, run.mask, nz, rn)
         barrier()
         train_ms = (time.perf_counter() - t1) / nt * 1e3
         assert torch.isfinite(loss).all()
+        del ts
 
     if rank != 0:
         if world > 1:
@@ -193,47 +350,50 @@ def main():
 
     states = B * world * args.steps
     value = states / elapsed
-    # dominant kernel of the timed region, timed live with HIP event pairs on the launch stream
-    total_ms = sum(r["total_ms"] for r in prof) or 1.0
-    dom = max(prof, key=lambda r: r["total_ms"])
-    avg_ms = dom["total_ms"] / dom["launches"]
-    achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                "kernel": dom["name"], "launches": dom["launches"], "avg_launch_ms": avg_ms,
-                "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
-                "share_of_kernel_time": dom["total_ms"] / total_ms,
-                "hbm_frac_on_algorithmic_bytes": dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS}
-    # HBM traffic of that kernel from the committed rocprofv3 PMC passes (tools/rocpd_summary.py traffic), per launch
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-        for k, v in tr.items():
-            norm = k.replace("mcedm::", "").replace(" ", "")
-            if norm == dom["name"].replace(" ", ""):
-                roofline["traffic"] = v["traffic_bytes"]
-                roofline["traffic_note"] = "rocprofv3 FETCH_SIZE (x2 gfx950 bracket upper end) + WRITE_SIZE, avg per launch"
-    except Exception:
-        pass
-    kernels = sorted(({"name": r["name"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
-                       "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2),
-                       "gbps": round(r["bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1)} for r in prof),
-                     key=lambda r: -r["total_ms"])
     line = {
         "metric": "denoised_states_per_sec_18step_edm_heun", "value": value, "unit": "states/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "states_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
                    "sampler": "EDM Heun, 18 steps, 35 NFE/state, S_churn=0, w=0, fp64 state / fp32 net",
-                   "parallelism": f"batch-sharded x{world}, no data-path collective"},
-        "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B, "train_step_ms": train_ms,
+                   "parallelism": f"batch-sharded x{world}, no data-path collective",
+                   "launch": "eager" if args.no_graph else "one HIP graph per sampler call"},
+        "timed_with_profiler": False, "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B, "train_step_ms": train_ms,
         "train_samples_per_sec": (B * world / (train_ms * 1e-3)) if train_ms else None,
-        "roofline": roofline, "kernels": kernels[:8],
+        "roofline": roofline_of(prof), "kernels": kernel_table(prof)[:8], "csrc_digest": csrc_digest(),
     }
+    flops_state = sum(r["flops"] for r in prof) / (args.profile_steps * B)
+    line["forward_fp32_frac"] = flops_state * B * world * args.steps / elapsed / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world)
+
+    # the other workloads, briefly (driver-timed numbers for BASELINE config 2 and the reference's own network)
+    line["secondary"] = {}
+    if not args.no_secondary and world == 1 and args.workload == "s128" and not args.batch:
+        del run.graph
+        torch.cuda.empty_cache()
+        for key in ("s32", "ref128", "s128l3"):
+            r2 = Runner(key, 0, device, 0, not args.no_graph)
+            r2.step()
+            torch.cuda.synchronize()
+            n2 = 5 if key == "s32" else 2
+            t2 = time.perf_counter()
+            for _ in range(n2):
+                r2.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t2) / n2
+            p2 = r2.profile(1)
+            ro = roofline_of(p2)
+            line["secondary"][key] = {"workload": r2.wl["name"], "states_per_gpu": r2.B, "value": r2.B / dt, "unit": "states/s",
+                                      "ms_per_step": dt * 1e3, "steps": n2, "unet_fwd_ms": r2.fwd_ms(),
+                                      "fp32_frac_whole_sampler": sum(r["flops"] for r in p2) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                      "dominant_kernel": ro["kernel"], "dominant_kernel_tflops": ro["achieved"],
+                                      "dominant_kernel_frac": ro["frac"], "dominant_kernel_share": ro["share_of_kernel_time"]}
+            del r2
+            torch.cuda.empty_cache()
+
     line["cpu_baseline"] = None          # timed on rank 0 of the 1-GPU run only
     if not args.no_cpu_baseline and world == 1:
-        n_cpu = args.cpu_states or (2 if H * W * wl["ch"] >= 128 * 128 * 64 else 8)
-        line["cpu_baseline"] = cpu_baseline(cfg, wl, n_cpu)
-        line["gpu_over_cpu"] = value / world / line["cpu_baseline"]["value"]
+        line["cpu_baseline"] = cpu_baseline(wl, {k: v.cpu() for k, v in run.params.items()})
+        line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

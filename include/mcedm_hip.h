@@ -150,6 +150,24 @@ int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* packed, const
                                const float* dD, float* const* grads, void* workspace,
                                size_t workspace_bytes, int B, int H, int W, double sigma_data, void* stream);
 
+/* Overlap hook for the data-parallel gradient exchange (the DDP bucketed all-reduce behind
+ * configs/trainer/trainer_ddim.yaml:7 `strategy: ddp`).  Same as
+ * mcedm_edm_denoise_backward, and additionally records the caller's HIP events on `stream`: bucket_events[k]
+ * (hipEvent_t) is recorded as soon as the gradient of EVERY parameter with index >= bucket_first_param[k] has been
+ * enqueued.  The backward finishes parameters from the last (out_conv) to the first (map_layer0), so the caller can
+ * all-reduce bucket k = parameters [bucket_first_param[k], bucket_first_param[k-1]) on another stream (after
+ * hipStreamWaitEvent) while the rest of the backward still runs.  bucket_first_param must decrease, end with 0 and
+ * name first parameters of blocks; mcedm_unet_grad_buckets proposes such a split into at most max_buckets
+ * roughly equal parts.  The library itself stays free of any communication dependency: the collective is the
+ * caller's (RCCL through torch.distributed in m-cedm_amd/train.py). */
+int mcedm_unet_grad_buckets(const mcedm_plan* plan, int max_buckets, int32_t* first_param, int* n_buckets);
+int mcedm_edm_denoise_backward_bucketed(const mcedm_plan* plan, const void* packed, const float* const* params,
+                                        const float* x, const float* sigma, int n_sigma, const float* cond,
+                                        const float* dD, float* const* grads, void* workspace,
+                                        size_t workspace_bytes, int B, int H, int W, double sigma_data,
+                                        int n_buckets, const int32_t* bucket_first_param,
+                                        void* const* bucket_events, void* stream);
+
 /* Squared L2 norm of a flat fp32 buffer, accumulated in fp64 into *sqnorm_out (device, overwritten). */
 int mcedm_sqnorm(const float* g, size_t n, double* sqnorm_out, void* stream);
 
@@ -188,6 +206,13 @@ int mcedm_op_gn_coef(const float* xa, const float* xb, int Ca, int Cb, int B, in
 int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch, int act,
                   int resample, int Hs, int Ws, int H, int W, const float* wpk, const float* bias_pk,
                   const float* res, int res_mode, float* out, int Cout, int B, int k, void* stream);
+/* sigma-embedding MLP + every block's FiLM rows in one launch (models/adm_blocks.py:192-199 PositionalEmbedding,
+ * :367-379 mapping MLP with SiLU, :143,163-165 per-block affine):  emb = silu(W1 silu(W0 pe(labels) + b0) + b1),
+ * film[n] = Waff emb[n] + baff.  labels [n]; w0, w1 [ch][ch] (out, in); waff [rows][ch] = the blocks' affine weights
+ * concatenated; freqs_scratch [ch/2]; emb_out [n][ch] (may be NULL); film_out [n][rows]. */
+int mcedm_op_embedding(const float* labels, int n, int ch, const float* w0, const float* b0, const float* w1,
+                       const float* b1, const float* waff, const float* baff, int rows, float* freqs_scratch,
+                       float* emb_out, float* film_out, void* stream);
 /* a = softmax(q^T k / sqrt(64)) v per (sample, head) (models/adm_blocks.py:103-109,174-178);
  * qkv is [B][heads][3][64][T] (the packed qkv conv's output), out [B][heads*64][T]. */
 int mcedm_op_attention(const float* qkv, float* out, int B, int heads, int T, void* stream);

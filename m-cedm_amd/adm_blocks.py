@@ -164,6 +164,7 @@ class DhariwalUNet(nn.Module):
         self._plan: Optional[_lib.Plan] = None
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
+        self._param_list = None
         self._ws = _lib.Workspace()
 
     # ---- HIP plumbing -------------------------------------------------------------------------------
@@ -179,10 +180,26 @@ class DhariwalUNet(nn.Module):
     def named_param_dict(self) -> Dict[str, torch.Tensor]:
         return dict(self.named_parameters())
 
+    def invalidate_packed(self) -> None:
+        """Force a re-pack at the next use.  The cache key below is (data_ptr, autograd version) per parameter; a write
+        through ``p.data`` (``p.data.mul_()``, ``p.data.copy_()``, some clip / init utilities) bumps neither, so any code
+        that writes parameters that way must call this.  ``load_state_dict`` and the fused trainer do."""
+        self._packed_key = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def packed_weights(self) -> torch.Tensor:
-        """MFMA-ordered copies of the weights; re-packed whenever a parameter was written or moved."""
+        """MFMA-ordered copies of the weights; re-packed whenever a parameter was written (autograd-visible) or moved."""
+        if self._packed_key is not None and self._param_list is not None:
+            params_l = self._param_list
+        else:
+            params_l = self._param_list = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params_l)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
         params = self.named_param_dict()
-        key = tuple((p.data_ptr(), p._version) for p in params.values())
         if self._packed is None or key != self._packed_key:
             self._packed = self.plan.pack(params, self._packed if (self._packed is not None and self._packed.device ==
                                                                   next(iter(params.values())).device) else None)
@@ -212,16 +229,22 @@ class EmaModel(nn.Module):
         import copy
         self.beta = beta
         plan, packed, model._plan, model._packed = model._plan, model._packed, None, None   # not deep-copyable
+        plist, model._param_list = model._param_list, None
         self.ma_model = copy.deepcopy(model)
-        model._plan, model._packed = plan, packed
+        model._plan, model._packed, model._param_list = plan, packed, plist
+        self.ma_model._packed_key = None
 
     def update(self, current_model):
         if isinstance(current_model, nn.parallel.DistributedDataParallel):
             current_model = current_model.module
         with torch.no_grad():
-            for cur, ma in zip(current_model.parameters(), self.ma_model.parameters()):
-                if cur.requires_grad:
-                    ma.copy_(ma * self.beta + (1 - self.beta) * cur.detach())
+            cur_p = [c for c in current_model.parameters()]
+            ma_p = [m for m in self.ma_model.parameters()]
+            live = [(c, m) for c, m in zip(cur_p, ma_p) if c.requires_grad]
+            if live:           # ma = ma * beta + (1 - beta) * cur, as two multi-tensor launches instead of 3 per parameter
+                mas = [m for _, m in live]
+                torch._foreach_mul_(mas, self.beta)
+                torch._foreach_add_(mas, [c.detach() for c, _ in live], alpha=1 - self.beta)
 
     def forward(self, *args, **kwargs):
         return self.ma_model(*args, **kwargs)

@@ -78,7 +78,7 @@ __global__ void colsum_kernel(const float* __restrict__ A, int rows, int cols, i
 
 struct BwdScratch {
   std::vector<size_t> g;     // gradient buffer per forward tensor id (NONE when not an activation)
-  size_t dact, dskip, xact, ab, wg, dfilm, lse, gF, pe, u1, u2, t1, t2, t3, total;
+  size_t dact, dskip, xact, ab, wg, dfilm, lse, gF, pe, u1, u2, t1, t2, t3, emb, total;
 };
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
@@ -118,6 +118,7 @@ static BwdScratch make_scratch(const mcedm_plan& P, const Layout& L, int B, int 
   S.gF = take((size_t)B * P.desc.out_channels * H * W * 4);
   S.pe = take((size_t)B * ch * 4); S.u1 = take((size_t)B * ch * 4); S.u2 = take((size_t)B * ch * 4);
   S.t1 = take((size_t)B * ch * 4); S.t2 = take((size_t)B * ch * 4); S.t3 = take((size_t)B * ch * 4);
+  S.emb = take((size_t)B * ch * 4);
   S.total = cur;
   return S;
 }
@@ -137,6 +138,10 @@ struct Ctx {
   int B, n_noise;
   hipStream_t s;
   std::vector<char> have;   // gradient buffer of tensor id already holds a contribution
+  const float* emb = nullptr;                 // [n_noise][ch] sigma embedding (recomputed up front)
+  int n_buckets = 0;                          // overlap hook: record bucket_events[k] once every parameter with index
+  const int32_t* bucket_first = nullptr;      // >= bucket_first[k] has its gradient enqueued
+  void* const* bucket_events = nullptr;
 
   float* T(int id) const { return id < 0 ? nullptr : reinterpret_cast<float*>(act + L.t[id].off); }
   Coef* CF(int id) const { return id < 0 ? nullptr : reinterpret_cast<Coef*>(act + L.t[id].off); }
@@ -227,20 +232,72 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
   if ((rc = launch_gn_bwd(g0, c.s))) return rc;
   c.have[bl.xa] = 1;
   if (bl.xb >= 0) c.have[bl.xb] = 1;
-  return norm_param_grads(c, b.norm0, nullptr, 0, nullptr);
+  if ((rc = norm_param_grads(c, b.norm0, nullptr, 0, nullptr))) return rc;
+  // this block's affine layer (film = emb Waff^T + baff): dWaff[r][k] = sum_n dfilm[n][r] emb[n][k], dbaff[r] = sum_n dfilm[n][r].
+  // Done here, not after the last block, so that the block's whole parameter range is complete (gradient buckets).
+  const int ch = c.P.desc.ch, R = c.P.film_rows;
+  const float* dfilm = c.X(c.S.dfilm) + b.film_row0;
+  if ((rc = launch_small_gemm(dfilm, c.emb, c.grads[b.aff_w], 2 * b.cout, ch, c.n_noise, R, ch, ch, 1, 0, 0, c.s))) return rc;
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(2 * b.cout, 64)), dim3(64), 0, c.s, dfilm, c.n_noise, 2 * b.cout, R,
+                     c.grads[b.aff_b]);
+  MCEDM_LAUNCH_CHECK("colsum_kernel");
+  for (int k = 0; k < c.n_buckets; ++k)
+    if (c.bucket_first[k] == b.norm0.w) MCEDM_HIP_TRY(hipEventRecord((hipEvent_t)c.bucket_events[k], c.s));
+  return MCEDM_OK;
 }
 
 }  // namespace mcedm
 
 using namespace mcedm;
 
-extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* packed, const float* const* params,
-                                          const float* x, const float* sigma, int n_sigma, const float* cond,
-                                          const float* dD, float* const* grads, void* workspace, size_t workspace_bytes,
-                                          int B, int H, int W, double sigma_data, void* stream) {
-  (void)sigma; (void)sigma_data;
+// first parameter index of every unit whose gradients complete together, in completion order of the backward:
+// (out_norm, out_conv), decoder blocks reversed, encoder blocks reversed, conv_in, the mapping MLP (index 0)
+static std::vector<int> bucket_candidates(const mcedm_plan& P) {
+  std::vector<int> c;
+  for (size_t i = P.dec.size(); i-- > 0;) c.push_back(P.dec[i].norm0.w);
+  for (size_t i = P.enc.size(); i-- > 0;) c.push_back(P.enc[i].norm0.w);
+  c.push_back(0);
+  return c;
+}
+
+extern "C" int mcedm_unet_grad_buckets(const mcedm_plan* plan, int max_buckets, int32_t* first_param, int* n_buckets) {
+  MCEDM_REQUIRE(plan && first_param && n_buckets && max_buckets >= 1, "grad_buckets: bad argument");
+  const mcedm_plan& P = *plan;
+  int64_t total = 0;
+  for (const ParamInfo& pi : P.params) total += pi.numel;
+  const std::vector<int> cand = bucket_candidates(P);
+  std::vector<int64_t> prefix(P.params.size() + 1, 0);
+  for (size_t i = 0; i < P.params.size(); ++i) prefix[i + 1] = prefix[i] + P.params[i].numel;
+  int n = 0;
+  int hi = (int)P.params.size();
+  for (int cfirst : cand) {
+    if (n == max_buckets - 1) break;
+    if (cfirst == 0) break;
+    if (prefix[hi] - prefix[cfirst] >= total / max_buckets) { first_param[n++] = cfirst; hi = cfirst; }
+  }
+  first_param[n++] = 0;
+  *n_buckets = n;
+  return MCEDM_OK;
+}
+
+static int denoise_backward_impl(const mcedm_plan* plan, const void* packed, const float* const* params,
+                                 const float* x, int n_sigma, const float* cond,
+                                 const float* dD, float* const* grads, void* workspace, size_t workspace_bytes,
+                                 int B, int H, int W, int n_buckets, const int32_t* bucket_first,
+                                 void* const* bucket_events, void* stream) {
   MCEDM_REQUIRE(plan && packed && params && x && dD && grads && workspace, "denoise_backward: null argument");
   const mcedm_plan& P = *plan;
+  if (n_buckets > 0) {
+    MCEDM_REQUIRE(bucket_first && bucket_events, "denoise_backward: null bucket arrays");
+    const std::vector<int> cand = bucket_candidates(P);
+    for (int k = 0; k < n_buckets; ++k) {
+      MCEDM_REQUIRE(bucket_events[k] != nullptr, "denoise_backward: bucket event %d is null", k);
+      MCEDM_REQUIRE(std::find(cand.begin(), cand.end(), bucket_first[k]) != cand.end(),
+                    "denoise_backward: bucket %d starts at parameter %d, which is not the first parameter of a block", k, bucket_first[k]);
+      MCEDM_REQUIRE(k == 0 || bucket_first[k] < bucket_first[k - 1], "denoise_backward: bucket starts must decrease");
+    }
+    MCEDM_REQUIRE(bucket_first[n_buckets - 1] == 0, "denoise_backward: the last bucket must start at parameter 0");
+  }
   for (size_t i = 0; i < P.params.size(); ++i)
     MCEDM_REQUIRE(grads[i] != nullptr, "denoise_backward: grads[%zu] (%s) is null", i, P.params[i].name.c_str());
   Layout L;
@@ -257,8 +314,25 @@ extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* pa
   char* scr = act + L.total_bytes;
   const float* pk = (const float*)packed;
   Ctx c{P, L, S, act, scr, pk, grads, B, n_sigma, s, std::vector<char>(L.t.size(), 0)};
+  c.n_buckets = n_buckets; c.bucket_first = bucket_first; c.bucket_events = bucket_events;
   const int ch = P.desc.ch;
   const size_t per = (size_t)P.desc.out_channels * H * W;
+
+  // sigma embedding and its pre-activations (the blocks' affine gradients need emb): pe, u1 = W0 pe + b0,
+  // u2 = W1 silu(u1) + b1, emb = silu(u2)
+  const int n = n_sigma, R = P.film_rows;
+  float* dfilm = c.X(S.dfilm);
+  float* pe = c.X(S.pe); float* u1 = c.X(S.u1); float* u2 = c.X(S.u2);
+  float* t1 = c.X(S.t1); float* t2 = c.X(S.t2); float* t3 = c.X(S.t3);
+  float* emb = c.X(S.emb);
+  hipLaunchKernelGGL(emb_save_kernel, dim3(n), dim3(256), 2 * ch * sizeof(float), s, at<float>(workspace, hd.c_noise),
+                     pk + P.freqs, pk + P.w0, pk + P.b0, pk + P.w1, pk + P.b1, ch, pe, u1, u2);
+  MCEDM_LAUNCH_CHECK("emb_save_kernel");
+  const size_t ne = (size_t)n * ch;
+  const int ge = (int)((ne + 255) / 256);
+  hipLaunchKernelGGL(silu_map_kernel, dim3(ge), dim3(256), 0, s, u2, nullptr, emb, ne, 0);
+  MCEDM_LAUNCH_CHECK("silu_map_kernel");
+  c.emb = emb;
 
   // dF = c_out * dD
   hipLaunchKernelGGL(scale_by_cout_kernel, dim3(grid_for(per * B)), dim3(256), 0, s, dD, at<float>(workspace, hd.coefs4),
@@ -288,26 +362,7 @@ extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* pa
                n_sigma > 1 ? 1 : 0, 0, RS_NONE, H, W, H, W, P.conv_in.cout, B, c.X(S.wg), nullptr};
   if ((rc = launch_wgrad(wi, 9, grads[P.conv_in.w], grads[P.conv_in.b], 0, c.X(c.S.xact), s))) return rc;
 
-  // embedding MLP + affine rows: film = emb Waff^T + baff, emb = silu(u2), u2 = W1 silu(u1) + b1, u1 = W0 pe + b0
-  const int n = n_sigma, R = P.film_rows;
-  float* dfilm = c.X(S.dfilm);
-  float* pe = c.X(S.pe); float* u1 = c.X(S.u1); float* u2 = c.X(S.u2);
-  float* t1 = c.X(S.t1); float* t2 = c.X(S.t2); float* t3 = c.X(S.t3);
-  hipLaunchKernelGGL(emb_save_kernel, dim3(n), dim3(256), 2 * ch * sizeof(float), s, at<float>(workspace, hd.c_noise),
-                     pk + P.freqs, pk + P.w0, pk + P.b0, pk + P.w1, pk + P.b1, ch, pe, u1, u2);
-  MCEDM_LAUNCH_CHECK("emb_save_kernel");
-  const size_t ne = (size_t)n * ch;
-  const int ge = (int)((ne + 255) / 256);
-  hipLaunchKernelGGL(silu_map_kernel, dim3(ge), dim3(256), 0, s, u2, nullptr, t1, ne, 0);                 // t1 = emb
-  MCEDM_LAUNCH_CHECK("silu_map_kernel");
-  for (auto* v : {&P.enc, &P.dec})
-    for (const BlockP& b : *v) {
-      // dWaff[r][k] = sum_n dfilm[n][r] emb[n][k] ; dbaff[r] = sum_n dfilm[n][r]
-      if ((rc = launch_small_gemm(dfilm + b.film_row0, t1, grads[b.aff_w], 2 * b.cout, ch, n, R, ch, ch, 1, 0, 0, s))) return rc;
-      hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(2 * b.cout, 64)), dim3(64), 0, s, dfilm + b.film_row0, n, 2 * b.cout, R,
-                         grads[b.aff_b]);
-      MCEDM_LAUNCH_CHECK("colsum_kernel");
-    }
+  // mapping MLP: film = emb Waff^T + baff, emb = silu(u2), u2 = W1 silu(u1) + b1, u1 = W0 pe + b0
   // demb[n][k] = sum_r dfilm[n][r] Waff[r][k]
   if ((rc = launch_small_gemm(dfilm, pk + P.waff, t2, n, ch, R, R, ch, ch, 0, 0, 0, s))) return rc;       // t2 = demb
   hipLaunchKernelGGL(silu_map_kernel, dim3(ge), dim3(256), 0, s, u2, t2, t3, ne, 1);                      // t3 = du2
@@ -320,5 +375,27 @@ extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* pa
   if ((rc = launch_small_gemm(t3, pe, grads[P.map0_w], ch, ch, n, ch, ch, ch, 1, 0, 0, s))) return rc;    // dW0 = du1^T pe
   hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(ch, 64)), dim3(64), 0, s, t3, n, ch, ch, grads[P.map0_b]);
   MCEDM_LAUNCH_CHECK("colsum_kernel");
+  if (n_buckets > 0) MCEDM_HIP_TRY(hipEventRecord((hipEvent_t)bucket_events[n_buckets - 1], s));
   return MCEDM_OK;
+}
+
+extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* packed, const float* const* params,
+                                          const float* x, const float* sigma, int n_sigma, const float* cond,
+                                          const float* dD, float* const* grads, void* workspace, size_t workspace_bytes,
+                                          int B, int H, int W, double sigma_data, void* stream) {
+  (void)sigma; (void)sigma_data;
+  return denoise_backward_impl(plan, packed, params, x, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W, 0,
+                               nullptr, nullptr, stream);
+}
+
+extern "C" int mcedm_edm_denoise_backward_bucketed(const mcedm_plan* plan, const void* packed, const float* const* params,
+                                                   const float* x, const float* sigma, int n_sigma, const float* cond,
+                                                   const float* dD, float* const* grads, void* workspace,
+                                                   size_t workspace_bytes, int B, int H, int W, double sigma_data,
+                                                   int n_buckets, const int32_t* bucket_first_param,
+                                                   void* const* bucket_events, void* stream) {
+  (void)sigma; (void)sigma_data;
+  MCEDM_REQUIRE(n_buckets >= 1, "denoise_backward_bucketed: n_buckets must be >= 1");
+  return denoise_backward_impl(plan, packed, params, x, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W,
+                               n_buckets, bucket_first_param, bucket_events, stream);
 }

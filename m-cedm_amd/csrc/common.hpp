@@ -54,6 +54,22 @@ struct __attribute__((aligned(16))) Coef {
 
 enum Resample { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
 
+// Geometry of a fused GroupNorm statistics table: the pixel tiling of the conv that produced the tensor.  One record
+// per (sample, tile, 4-channel block) = (sum, M2): the sum of the block's values inside the tile and their squared
+// deviations from the TILE's own mean, so no large-mean cancellation ever happens in fp32; the consumer merges the
+// records in fp64 (Chan et al.), with the element count of a tile recomputed from this geometry.
+struct SumTiles {
+  int tiles = 0;     // records per sample and 4-channel block
+  int tiles_x = 0;   // tiles along W
+  int ph = 0, pw = 0;
+};
+__host__ __device__ static inline int sum_tile_count(const SumTiles& g, int t, int H, int W) {
+  const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
+  const int h = H - ty * g.ph < g.ph ? H - ty * g.ph : g.ph;
+  const int w = W - tx * g.pw < g.pw ? W - tx * g.pw : g.pw;
+  return 4 * h * w;
+}
+
 // Arguments of the implicit-GEMM convolution (3x3 pad 1, or 1x1).
 // GroupNorm (+FiLM) -> per-(sample, channel) transform rows (K1)
 struct GnArgs {
@@ -66,8 +82,9 @@ struct GnArgs {
   float eps;
   Coef* coef;        // out [B][C]
   float* stats;      // out [B][groups][2] (mean, rstd) or null (kept for backward)
-  const float* suma; const float* sumb;     // launch_gn_coef_from_sums: per-tile (sum, sumsq) tables of xa / xb
-  int tiles_a, tiles_b;                     // tiles per sample in those tables
+  const float* suma; const float* sumb;     // launch_gn_coef_from_sums: per-tile (sum, M2) tables of xa / xb
+  SumTiles ta, tb;                          // tiling of those tables
+  int W;                                    // image width (H = HW / W): a tile's element count comes from its geometry
 };
 int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream);
 int launch_gn_coef(const GnArgs& a, hipStream_t stream);
@@ -91,10 +108,10 @@ struct ConvArgs {
   float* out;        // [B, Cout, H, W]
   int Cout;
   int B;
-  float* gsum;       // optional [B][tiles][ceil(Cout/4)][2]: per output tile and 4-channel group, (sum, sum of squares)
-                     // of the OUTPUT written by the epilogue (no atomics); feeds the next GroupNorm without a stats
-                     // pass.  Must hold B * conv_max_tiles(H, W) * ceil(Cout/4) * 2 floats.
-  int* gsum_tiles;   // host out: tiles per sample the launcher used (row count of gsum per sample)
+  float* gsum;       // optional [B][tiles][ceil(Cout/4)][2]: per output tile and 4-channel block, (sum, M2 about the
+                     // tile mean) of the OUTPUT written by the epilogue (no atomics); feeds the next GroupNorm without
+                     // a stats pass.  Must hold B * conv_max_tiles(H, W) * ceil(Cout/4) * 2 floats.
+  SumTiles* gsum_tiles;   // host out: the tiling the launcher used (rows of gsum per sample, tile shape)
   // gn_on: the kernel derives this sample's transform rows itself from the producers' per-tile (sum, sumsq) tables
   // (gn.suma / gn.sumb ...; gn.coef / gn.stats / gn.xa / gn.xb are not used), so no GroupNorm kernel runs at all
   GnArgs gn; int gn_on;

@@ -107,7 +107,7 @@ __device__ Coef k_identity_coef = {0.f, 1.f, 0.f, 0.f};   // the table of a conv
 
 // This sample's Ca + Cb transform rows -> LDS, once per workgroup; the commit phase reads them as wave-uniform
 // broadcasts (24 fewer VGPRs and 8 fewer loads per chunk than carrying the rows of the next chunk in registers).
-// gn_on: the rows are derived right here from the per-tile (sum, sumsq) tables that the PRODUCING convs' epilogues
+// gn_on: the rows are derived right here from the per-tile (sum, M2) tables that the PRODUCING convs' epilogues
 // wrote (GroupNorm statistics in fp64, fixed-order butterfly over the lanes that share a group; + FiLM), so the
 // inference path runs no GroupNorm kernel at all: the input is normalised by the conv that consumes it.
 // Otherwise they are copied from the table p.coef (the launcher points a missing table at one identity row).
@@ -129,24 +129,28 @@ __device__ __forceinline__ void stage_coef_rows(const ConvArgs& p, int n, Coef* 
     const bool live = gi < G;
     const int c0 = live ? gi * cpg : 0;
     const int nq = cpg / 4;          // the group = nq 4-channel blocks, each in xa's or xb's table (may straddle)
-    double s1 = 0, s2 = 0;
+    // Chan merge of the per-tile records (sum_t, M2_t about the tile mean), all in fp64:
+    //   M2 = sum_t M2_t + sum_t s_t^2 / n_t - (sum_t s_t)^2 / N      (s_t are fp32 values: exact in fp64)
+    double s1 = 0, sq = 0, mw = 0;
+    const int Himg = g.HW / g.W;
     for (int q = 0; q < (live ? nq : 0); ++q) {
       const int cb = c0 + 4 * q;
       const bool in_a = cb < g.Ca;
       const float* sums = in_a ? g.suma : g.sumb;
-      const int tiles = in_a ? g.tiles_a : g.tiles_b;
+      const SumTiles& tg = in_a ? g.ta : g.tb;
       const int q4 = ((in_a ? g.Ca : g.Cb) + 3) / 4;
       const int qi = (in_a ? cb : cb - g.Ca) / 4;
-      for (int t = sub; t < tiles; t += lpg) {
-        const float* row = sums + (((size_t)n * tiles + t) * q4 + qi) * 2;
-        s1 += (double)row[0]; s2 += (double)row[1];
+      for (int t = sub; t < tg.tiles; t += lpg) {
+        const float* row = sums + (((size_t)n * tg.tiles + t) * q4 + qi) * 2;
+        const double st = (double)row[0];
+        s1 += st; sq += st * st / (double)sum_tile_count(tg, t, Himg, g.W); mw += (double)row[1];
       }
     }
-    for (int off = lpg >> 1; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    for (int off = lpg >> 1; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); sq += __shfl_xor(sq, off); mw += __shfl_xor(mw, off); }
     if (live) {
       const double N = (double)cpg * g.HW;
       const double m = s1 / N;
-      double var = s2 / N - m * m;
+      double var = (mw + sq - s1 * s1 / N) / N;
       if (var < 0) var = 0;
       const float mean = (float)m;
       const float rstd = (float)(1.0 / sqrt(var + (double)g.eps));
@@ -340,6 +344,10 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[C
 }
 
 // FULL: every output channel of the tile exists (m0 + MT <= Cout).  Store-only: nothing here waits on memory.
+// STATS: fused GroupNorm statistics of what is stored.  Per wave and 4-channel block a record (count, sum, M2) with
+// M2 = sum (v - wave mean)^2: two passes over the accumulator registers, so a large mean never cancels in fp32
+// (E[x^2] - E[x]^2 on fp32 partial sums loses rstd at |mean|/std ~ 30).  Records go to the LDS slot of the wave
+// (3 floats per block); conv_stats_combine merges the waves of the tile in a fixed order.
 template <class C, bool FULL, bool STATS>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C::TM][C::TN], int n, int m0, int y0,
                                               int x0, int wm, int wn, int lane, float* red) {
@@ -347,7 +355,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) {
     const int cbase = m0 + (wm * C::TM + i) * 32 + 4 * (lane >> 5);     // + (r&3) + 8*(r>>2)
-    float gs1[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};
+    float gs1[4] = {0.f, 0.f, 0.f, 0.f}, cnt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
       const int pix = (wn * C::TN + j) * 32 + (lane & 31);
@@ -360,27 +368,65 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
           const float v = acc[i][j][r];
           if (FULL || co < p.Cout) {
             p.out[((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x] = v;
-            if (STATS) { gs1[r >> 2] += v; gs2[r >> 2] += v * v; }
+            if (STATS) { gs1[r >> 2] += v; cnt[r >> 2] += 1.f; }
           }
         }
       }
     }
     if (STATS) {
-      // fused GroupNorm statistics of the output tile: lane -> 32-lane half (pixels) -> LDS slot of this wave.
-      // 4-channel group inside the MT tile: gl = 8 (wm TM + i) + 2 (r>>2) + (lane>>5).
+      // 4-channel block inside the MT tile: gl = 8 (wm TM + i) + 2 (r>>2) + (lane>>5); pixels = the 32-lane half.
+      float mean[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float a = gs1[q], b = gs2[q];
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+        for (int off = 16; off > 0; off >>= 1) { gs1[q] += __shfl_xor(gs1[q], off); cnt[q] += __shfl_xor(cnt[q], off); }
+        mean[q] = cnt[q] > 0.f ? gs1[q] / cnt[q] : 0.f;
+      }
+      float gm2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) {
+        const int pix = (wn * C::TN + j) * 32 + (lane & 31);
+        const int y = y0 + pix / C::PW;
+        const int x = x0 + pix % C::PW;
+        if (y < p.H && x < p.W) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = cbase + (r & 3) + 8 * (r >> 2);
+            if (FULL || co < p.Cout) { const float d = acc[i][j][r] - mean[r >> 2]; gm2[r >> 2] = fmaf(d, d, gm2[r >> 2]); }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float b = gm2[q];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) b += __shfl_xor(b, off);
         if ((lane & 31) == 0) {
           const int gl = (wm * C::TM + i) * 8 + 2 * q + (lane >> 5);
-          red[(wn * (C::MT / 4) + gl) * 2] = a;
-          red[(wn * (C::MT / 4) + gl) * 2 + 1] = b;
+          float* slot = red + (wn * (C::MT / 4) + gl) * 3;
+          slot[0] = cnt[q]; slot[1] = gs1[q]; slot[2] = b;
         }
       }
     }
   }
+}
+
+// Merge NW per-wave records (count, sum, M2) of one 4-channel block in a fixed order (bitwise reproducible):
+// M2 = sum_w [M2_w + n_w (mean_w - mean)^2].  Returns (sum, M2).
+template <int NW>
+__device__ __forceinline__ void conv_stats_combine(const float* red, int stride_w, float& sum_out, float& m2_out) {
+  float nt = 0.f, st = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { nt += red[w * stride_w]; st += red[w * stride_w + 1]; }
+  const float mean = nt > 0.f ? st / nt : 0.f;
+  float m2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const float nw = red[w * stride_w], sw = red[w * stride_w + 1];
+    const float d = (nw > 0.f ? sw / nw : mean) - mean;
+    m2 += red[w * stride_w + 2] + nw * d * d;
+  }
+  sum_out = st; m2_out = m2;
 }
 
 // One K chunk (KC input channels x all taps) of the implicit GEMM out of the LDS slabs.
@@ -535,15 +581,17 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   }
   if (p.gsum) {               // wave-uniform: every wave of the workgroup reaches this barrier
     __syncthreads();
-    constexpr int NG2 = C::MT / 4 * 2;            // (sum, sumsq) pairs of the tile's 4-channel groups
-    if (tid < NG2) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < C::WN; ++w) t += red[w * NG2 + tid];        // fixed order: bitwise reproducible
-      const int g = m0 / 4 + tid / 2;
+    constexpr int NG = C::MT / 4;                 // 4-channel blocks of the tile
+    if (tid < NG) {
+      float sum, m2;
+      conv_stats_combine<C::WN>(red + tid * 3, NG * 3, sum, m2);
+      const int g = m0 / 4 + tid;
       const int ngroups = (p.Cout + 3) / 4;
       const int ntiles = tiles_x * tiles_y;
-      if (g < ngroups) p.gsum[(((size_t)n * ntiles + ty * tiles_x + tx) * ngroups + g) * 2 + (tid & 1)] = t;
+      if (g < ngroups) {
+        float* row = p.gsum + (((size_t)n * ntiles + ty * tiles_x + tx) * ngroups + g) * 2;
+        row[0] = sum; row[1] = m2;
+      }
     }
   }
 }
@@ -718,18 +766,19 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
   if (p.gsum) {
     __syncthreads();
     // two 8 x 32 sub-tile records (rows 0-7: waves 0-3, rows 8-15: waves 4-7), each the 4-wave sum of the 4-wave kernel
-    constexpr int NG2 = C::MT / 4 * 2;
-    if (tid < 2 * NG2) {
-      const int sub = tid / NG2, e = tid - sub * NG2;
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) t += red[(sub * 4 + w) * NG2 + e];
-      const int g = m0 / 4 + e / 2;
+    constexpr int NG = C::MT / 4;
+    if (tid < 2 * NG) {
+      const int sub = tid / NG, e = tid - sub * NG;
+      float sum, m2;
+      conv_stats_combine<4>(red + (sub * 4 * NG + e) * 3, NG * 3, sum, m2);
+      const int g = m0 / 4 + e;
       const int ngroups = (p.Cout + 3) / 4;
       const int tiles_y8 = (p.H + 7) / 8;
       const int ty8 = 2 * ty + sub;
-      if (g < ngroups && ty8 < tiles_y8)
-        p.gsum[(((size_t)n * (tiles_x * tiles_y8) + ty8 * tiles_x + tx) * ngroups + g) * 2 + (e & 1)] = t;
+      if (g < ngroups && ty8 < tiles_y8) {
+        float* row = p.gsum + (((size_t)n * (tiles_x * tiles_y8) + ty8 * tiles_x + tx) * ngroups + g) * 2;
+        row[0] = sum; row[1] = m2;
+      }
     }
   }
 }
@@ -902,7 +951,7 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
     return MCEDM_ERR_INVALID;
   }
   // algorithmic cost of this launch: 2*MAC flops; bytes = input read once + output written once + weights + residual
-  static char name[96];
+  char name[96] = "";
   if (prof_enabled())
     snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d>, %d>", C::MT, C::PH, C::PW,
              C::WM, C::WN, C::TAPS, C::KC, C::NT, (int)a.resample);   // = rocprofv3's name
@@ -926,7 +975,7 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
     hipLaunchKernelGGL((conv_mfma_kernel<C, RS_DOWN>), dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, tiles_x, tiles_y,
                        mtiles, nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_mfma_kernel");
-  if (a.gsum_tiles) *a.gsum_tiles = tiles_x * tiles_y;
+  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
   return MCEDM_OK;
 }
 
@@ -961,7 +1010,7 @@ static int launch_conv8(const ConvArgs& a_in, hipStream_t stream) {
       attr_set[dev] = true;
     }
   }
-  static char name[96];
+  char name[96] = "";
   if (prof_enabled()) snprintf(name, sizeof(name), "conv8_mfma_kernel<ConvCfg<128, 16, 32, 1, 8, 9, 8, 512> >");
   const double px = (double)a.B * a.H * a.W;
   const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
@@ -971,7 +1020,7 @@ static int launch_conv8(const ConvArgs& a_in, hipStream_t stream) {
   hipLaunchKernelGGL((conv8_mfma_kernel<C>), dim3((unsigned)blocks), dim3(512), lds_bytes, stream, a, tiles_x, tiles_y, mtiles,
                      nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv8_mfma_kernel");
-  if (a.gsum_tiles) *a.gsum_tiles = tiles_x * ceil_div(a.H, 8);     // records are per 8 x 32 sub-tile
+  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * ceil_div(a.H, 8), tiles_x, 8, C::PW};     // records are per 8 x 32 sub-tile
   return MCEDM_OK;
 }
 

@@ -98,7 +98,7 @@ int launch_gn_coef(const GnArgs& a, hipStream_t stream) {
   return MCEDM_OK;
 }
 
-// K1': the same table from the (sum, sum of squares) per 4 channels that the PRODUCING conv's epilogue
+// K1': the same table from the (sum, M2 about the tile mean) records per 4 channels that the PRODUCING conv's epilogue
 // wrote per output tile (ConvArgs::gsum): no pass over the tensor at all.  One wave per (sample, group): lanes
 // stride over the producer's tiles (fp64 partial sums), a fixed-order butterfly combines them (bitwise reproducible,
 // independent of the batch size), lanes 0..cpg-1 then write the group's channel rows.
@@ -113,24 +113,27 @@ __global__ __launch_bounds__(256) void gn_coef_from_sums_kernel(GnArgs a) {
   // the group is a run of 4-channel blocks; each block lives in xa's or xb's table (a group may straddle the
   // concat boundary: Ca is a multiple of 4, see gn_sums_usable)
   const int nq = cpg / 4;
-  double s1 = 0, s2 = 0;
+  // Chan merge of the per-tile records (sum_t, M2_t about the tile mean) in fp64, as in conv_mfma.hip stage_coef_rows
+  double s1 = 0, sq = 0, mw = 0;
+  const int Himg = a.HW / a.W;
   for (int q = 0; q < nq; ++q) {
     const int cb = c0 + 4 * q;
     const bool in_a = cb < a.Ca;
     const float* sums = in_a ? a.suma : a.sumb;
-    const int tiles = in_a ? a.tiles_a : a.tiles_b;
+    const SumTiles& tg = in_a ? a.ta : a.tb;
     const int q4 = ((in_a ? a.Ca : a.Cb) + 3) / 4;
     const int qi = (in_a ? cb : cb - a.Ca) / 4;
-    for (int t = lane; t < tiles; t += 64) {
-      const float* row = sums + (((size_t)n * tiles + t) * q4 + qi) * 2;
-      s1 += (double)row[0]; s2 += (double)row[1];
+    for (int t = lane; t < tg.tiles; t += 64) {
+      const float* row = sums + (((size_t)n * tg.tiles + t) * q4 + qi) * 2;
+      const double st = (double)row[0];
+      s1 += st; sq += st * st / (double)sum_tile_count(tg, t, Himg, a.W); mw += (double)row[1];
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); sq += __shfl_xor(sq, off); mw += __shfl_xor(mw, off); }
   const double N = (double)cpg * a.HW;
   const double m = s1 / N;
-  double var = s2 / N - m * m;
+  double var = (mw + sq - s1 * s1 / N) / N;
   if (var < 0) var = 0;
   const float mean = (float)m;
   const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -156,7 +159,8 @@ bool gn_sums_usable(const GnArgs& a) {
   const int C = a.Ca + a.Cb;
   if (a.groups <= 0 || C % a.groups != 0) return false;
   const int cpg = C / a.groups;
-  return cpg % 4 == 0 && a.Ca % 4 == 0 && a.suma != nullptr && (a.Cb == 0 || a.sumb != nullptr);
+  return cpg % 4 == 0 && a.Ca % 4 == 0 && a.suma != nullptr && (a.Cb == 0 || a.sumb != nullptr) && a.W > 0 &&
+         a.HW % a.W == 0 && a.ta.tiles > 0 && (a.Cb == 0 || a.tb.tiles > 0);
 }
 
 int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream) {

@@ -31,7 +31,7 @@ extern "C" int mcedm_op_gn_coef(const float* xa, const float* xb, int Ca, int Cb
   const int C = Ca + Cb;
   MCEDM_REQUIRE(C >= 4, "op_gn_coef: C=%d < 4 gives zero groups (adm_blocks.py:89)", C);
   GnArgs a{xa, xb, Ca, Cb, HW, B, C / 4 < 32 ? C / 4 : 32, gamma, beta, film, film_batch, film_stride, eps,
-           reinterpret_cast<Coef*>(coef_out), stats_out, nullptr, nullptr, 0, 0};
+           reinterpret_cast<Coef*>(coef_out), stats_out, nullptr, nullptr, SumTiles{}, SumTiles{}, 0};
   return launch_gn_coef(a, (hipStream_t)stream);
 }
 
@@ -48,6 +48,23 @@ extern "C" int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, c
   a.wpk = wpk; a.bias = bias_pk; a.res = res; a.res_mode = res_mode;
   a.out = out; a.Cout = Cout; a.B = B;
   return launch_conv(a, k * k, (hipStream_t)stream);
+}
+
+// freqs[k] = (1/10000)^(k/half) exactly as the plan packs them (adm_blocks.py:193-196, endpoint=False)
+__global__ void op_freqs_kernel(float* f, int half) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < half) f[k] = powf(1.0f / 10000.0f, (float)k / (float)half);
+}
+
+extern "C" int mcedm_op_embedding(const float* labels, int n, int ch, const float* w0, const float* b0, const float* w1,
+                                  const float* b1, const float* waff, const float* baff, int rows, float* freqs_scratch,
+                                  float* emb_out, float* film_out, void* stream) {
+  MCEDM_REQUIRE(labels && w0 && b0 && w1 && b1 && waff && baff && freqs_scratch && film_out, "op_embedding: null pointer");
+  MCEDM_REQUIRE(n > 0 && ch > 0 && ch % 2 == 0 && rows > 0, "op_embedding: bad shape n=%d ch=%d rows=%d", n, ch, rows);
+  hipLaunchKernelGGL(op_freqs_kernel, dim3(ceil_div(ch / 2, 64)), dim3(64), 0, (hipStream_t)stream, freqs_scratch, ch / 2);
+  MCEDM_LAUNCH_CHECK("op_freqs_kernel");
+  EmbArgs e{labels, n, ch, freqs_scratch, w0, b0, w1, b1, waff, baff, rows, emb_out, film_out};
+  return launch_embedding(e, (hipStream_t)stream);
 }
 
 extern "C" int mcedm_op_attention(const float* qkv, float* out, int B, int heads, int T, void* stream) {

@@ -515,11 +515,11 @@ static int gn_for_conv(const GnArgs& g, ConvArgs& c, bool need_table, hipStream_
 }
 
 static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl, const Layout& L, void* act,
-                     const float* pk, int B, int n_noise, hipStream_t s, std::vector<int>& st) {
+                     const float* pk, int B, int n_noise, hipStream_t s, std::vector<SumTiles>& st) {
   auto T = [&](int id) -> float* { return id < 0 ? nullptr : at<float>(act, L.t[id].off); };
   auto CF = [&](int id) -> Coef* { return id < 0 ? nullptr : at<Coef>(act, L.t[id].off); };
   auto SUMS = [&](int id) -> float* { return (id < 0 || L.t[id].sums == NONE) ? nullptr : at<float>(act, L.t[id].sums); };
-  auto TL = [&](int id) -> int { return id < 0 ? 0 : st[id]; };      // tiles per sample of that tensor's table
+  auto TL = [&](int id) -> SumTiles { return id < 0 ? SumTiles{} : st[id]; };      // tiling of that tensor's statistics table
   const float* xa = T(bl.xa);
   const float* xb = T(bl.xb);
   const int Ca = L.t[bl.xa].C, Cb = bl.xb >= 0 ? L.t[bl.xb].C : 0;
@@ -527,7 +527,7 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   int rc;
   // norm0 -> transform table for conv0
   GnArgs g0{xa, xb, Ca, Cb, bl.Hin * bl.Win, B, b.norm0.groups, pk + b.norm0.gamma, pk + b.norm0.beta,
-            nullptr, 0, 0, eps, CF(bl.coef0), T(bl.stats0), SUMS(bl.xa), SUMS(bl.xb), TL(bl.xa), TL(bl.xb)};
+            nullptr, 0, 0, eps, CF(bl.coef0), T(bl.stats0), SUMS(bl.xa), SUMS(bl.xb), TL(bl.xa), TL(bl.xb), bl.Win};
   // h = conv0(resample(silu(norm0(x))))
   ConvArgs c0{};
   c0.xa = xa; c0.xb = xb; c0.Ca = Ca; c0.Cb = Cb;
@@ -550,7 +550,7 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   // norm1 + FiLM -> transform table for conv1
   const float* film = at<float>(act, L.t[L.film].off) + b.film_row0;
   GnArgs g1{T(bl.h), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm1.groups, pk + b.norm1.gamma, pk + b.norm1.beta,
-            film, n_noise > 1 ? 1 : 0, P.film_rows, eps, CF(bl.coef1), T(bl.stats1), SUMS(bl.h), nullptr, TL(bl.h), 0};
+            film, n_noise > 1 ? 1 : 0, P.film_rows, eps, CF(bl.coef1), T(bl.stats1), SUMS(bl.h), nullptr, TL(bl.h), SumTiles{}, bl.W};
   // skip path
   const float* res = xa;
   int res_mode = RS_NONE;
@@ -578,7 +578,7 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   if (!b.attn) return MCEDM_OK;
   // attention: z = proj(attn(qkv(norm2(y)))) + y
   GnArgs g2{T(bl.y), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm2.groups, pk + b.norm2.gamma, pk + b.norm2.beta,
-            nullptr, 0, 0, eps, CF(bl.coef2), T(bl.stats2), SUMS(bl.y), nullptr, TL(bl.y), 0};
+            nullptr, 0, 0, eps, CF(bl.coef2), T(bl.stats2), SUMS(bl.y), nullptr, TL(bl.y), SumTiles{}, bl.W};
   ConvArgs cq{};
   cq.xa = T(bl.y); cq.Ca = b.cout;
   cq.coef = CF(bl.coef2); cq.coef_batch = 1; cq.act = 0;
@@ -606,7 +606,7 @@ static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, c
   EmbArgs e{noise_labels, n_noise, ch, pk + P.freqs, pk + P.w0, pk + P.b0, pk + P.w1, pk + P.b1,
             pk + P.waff, pk + P.baff, P.film_rows, nullptr, at<float>(act, L.t[L.film].off)};
   if ((rc = launch_embedding(e, s))) return rc;
-  std::vector<int> st(L.t.size(), 0);     // tiles per sample of each tensor's fused-statistics table
+  std::vector<SumTiles> st(L.t.size());     // tiling of each tensor's fused-statistics table
   // conv_in on cat(cond, x)  (cond FIRST, adm_blocks.py:332)
   ConvArgs ci{};
   ci.xa = cond; ci.Ca = P.desc.cond_channels;
@@ -625,7 +625,7 @@ static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, c
   GnArgs go{at<float>(act, last.off), nullptr, last.C, 0, H * W, B, P.out_norm.groups, pk + P.out_norm.gamma,
             pk + P.out_norm.beta, nullptr, 0, 0, 1e-5f, at<Coef>(act, L.t[L.coef_out].off),
             L.stats_out >= 0 ? at<float>(act, L.t[L.stats_out].off) : nullptr,
-            last.sums != NONE ? at<float>(act, last.sums) : nullptr, nullptr, st[L.last], 0};
+            last.sums != NONE ? at<float>(act, last.sums) : nullptr, nullptr, st[L.last], SumTiles{}, W};
   ConvArgs co{};
   co.xa = at<float>(act, last.off); co.Ca = last.C;
   co.coef = at<Coef>(act, L.t[L.coef_out].off); co.coef_batch = 1; co.act = 1;

@@ -339,7 +339,7 @@ static int launch_wg(const WgradArgs& a, const float* xact, hipStream_t s) {
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
   const int cop = ctiles * 64, cip = itiles * 64;
-  static char name[64];
+  char name[64] = "";
   if (prof_enabled()) snprintf(name, sizeof(name), "wgrad_kernel<WgCfg<%d, %d, %d>>", C::PH, C::PW, C::TAPS);
   const double flops = 2.0 * a.B * a.H * (double)a.W * a.Cout * (a.Ca + a.Cb) * C::TAPS;
   ProfScope ps(name, flops, 4.0 * a.B * ((double)a.Cout * a.H * a.W + (double)(a.Ca + a.Cb) * a.H * a.W), s);

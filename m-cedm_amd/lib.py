@@ -21,7 +21,8 @@ EXPORTS = [
     "mcedm_unet_param_count", "mcedm_unet_param_info", "mcedm_unet_packed_bytes", "mcedm_unet_pack_weights",
     "mcedm_unet_workspace_bytes", "mcedm_unet_forward", "mcedm_edm_denoise", "mcedm_sampler_workspace_bytes",
     "mcedm_heun_sample", "mcedm_edm_t_steps", "mcedm_edm_loss", "mcedm_edm_noise_inputs",
-    "mcedm_edm_denoise_backward", "mcedm_sqnorm", "mcedm_adam_ema_step",
+    "mcedm_edm_denoise_backward", "mcedm_edm_denoise_backward_bucketed", "mcedm_unet_grad_buckets", "mcedm_sqnorm",
+    "mcedm_adam_ema_step",
     "mcedm_swe_fv_step", "mcedm_swe_fv_residual", "mcedm_darcy_residual",
 ]
 
@@ -76,6 +77,10 @@ def load() -> C.CDLL:
                                            f32p, vp]
     lib.mcedm_edm_denoise_backward.argtypes = [vp, vp, C.POINTER(vp), f32p, f32p, i32, f32p, f32p, C.POINTER(vp), vp,
                                                sz, i32, i32, i32, C.c_double, vp]
+    lib.mcedm_edm_denoise_backward_bucketed.argtypes = [vp, vp, C.POINTER(vp), f32p, f32p, i32, f32p, f32p, C.POINTER(vp),
+                                                        vp, sz, i32, i32, i32, C.c_double, i32, C.POINTER(C.c_int32),
+                                                        C.POINTER(vp), vp]
+    lib.mcedm_unet_grad_buckets.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int)]
     lib.mcedm_sqnorm.argtypes = [f32p, sz, f64p, vp]
     lib.mcedm_adam_ema_step.argtypes = [f32p, f32p, f32p, f32p, f32p, sz, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_double, f64p, C.c_double, C.c_double, C.c_double, C.c_int64, vp]
@@ -235,29 +240,99 @@ class Plan:
                                           _stream()), "edm_denoise")
         return (D, F) if want_F else D
 
+    def grad_buckets(self, max_buckets: int) -> List[int]:
+        """First parameter index of each gradient bucket, in the order the backward completes them (last one is 0)."""
+        arr = (C.c_int32 * max(1, max_buckets))()
+        n = C.c_int()
+        check(self._lib.mcedm_unet_grad_buckets(self._h, int(max_buckets), arr, C.byref(n)), "grad_buckets")
+        return [arr[i] for i in range(n.value)]
+
     def denoise_backward(self, packed, params: Dict[str, torch.Tensor], x, sigma, cond, dD, grads: Sequence[torch.Tensor],
-                         ws: Workspace, sigma_data: float = 1.0) -> None:
-        """Backward of denoise(..., training=True) on the SAME workspace: grads[i] <- dLoss/dparam_i (overwritten)."""
+                         ws: Workspace, sigma_data: float = 1.0, bucket_first: Optional[Sequence[int]] = None,
+                         bucket_events: Optional[Sequence[torch.cuda.Event]] = None) -> None:
+        """Backward of denoise(..., training=True) on the SAME workspace: grads[i] <- dLoss/dparam_i (overwritten).
+        With bucket_first / bucket_events the library records event k once every parameter >= bucket_first[k] is done."""
         B, _, H, W = x.shape
         buf = ws.get(self.workspace_bytes(B, H, W, True), x.device)
         parr = (C.c_void_p * len(self.param_names))(*[_ptr(params[n].detach()) for n in self.param_names])
         garr = (C.c_void_p * len(self.param_names))(*[_ptr(g) for g in grads])
-        check(self._lib.mcedm_edm_denoise_backward(self._h, packed.data_ptr(), parr, _ptr(x), _ptr(sigma), sigma.numel(),
-                                                   _ptr(cond), _ptr(dD), garr, buf.data_ptr(), buf.numel(), B, H, W,
-                                                   float(sigma_data), _stream()), "edm_denoise_backward")
+        if bucket_first is None:
+            check(self._lib.mcedm_edm_denoise_backward(self._h, packed.data_ptr(), parr, _ptr(x), _ptr(sigma), sigma.numel(),
+                                                       _ptr(cond), _ptr(dD), garr, buf.data_ptr(), buf.numel(), B, H, W,
+                                                       float(sigma_data), _stream()), "edm_denoise_backward")
+            return
+        nb = len(bucket_first)
+        firsts = (C.c_int32 * nb)(*[int(f) for f in bucket_first])
+        handles = [int(e.cuda_event) for e in bucket_events]
+        if len(handles) != nb or not all(handles):
+            raise RuntimeError("denoise_backward: one created (recorded at least once) torch.cuda.Event per bucket is needed")
+        evs = (C.c_void_p * nb)(*handles)
+        check(self._lib.mcedm_edm_denoise_backward_bucketed(self._h, packed.data_ptr(), parr, _ptr(x), _ptr(sigma),
+                                                            sigma.numel(), _ptr(cond), _ptr(dD), garr, buf.data_ptr(),
+                                                            buf.numel(), B, H, W, float(sigma_data), nb, firsts, evs,
+                                                            _stream()), "edm_denoise_backward_bucketed")
 
     def sample(self, packed, sd: SamplerDesc, cond, mask, init_noise, step_noise=None, return_last: bool = True,
-               ws: Optional[Workspace] = None) -> torch.Tensor:
+               ws: Optional[Workspace] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, _, H, W = init_noise.shape
         ws = ws or Workspace()
-        buf = ws.get(self.sampler_workspace_bytes(B, H, W), cond.device)
+        buf = ws.get(self.sampler_workspace_bytes(B, H, W), init_noise.device)
         T = 1 if return_last else sd.timesteps + 1
-        out = torch.empty((B, T, H, W, self.in_channels), dtype=torch.float64, device=cond.device)
+        if out is None:
+            out = torch.empty((B, T, H, W, self.in_channels), dtype=torch.float64, device=init_noise.device)
+        elif tuple(out.shape) != (B, T, H, W, self.in_channels):
+            raise RuntimeError(f"sample: out has shape {tuple(out.shape)}, expected {(B, T, H, W, self.in_channels)}")
         check(self._lib.mcedm_heun_sample(self._h, packed.data_ptr(), C.byref(sd), _ptr(cond), _ptr(mask),
                                           _ptr(init_noise), _ptr(step_noise, torch.float64), _ptr(out, torch.float64),
                                           int(return_last), buf.data_ptr(), buf.numel(), B, H, W, _stream()),
               "heun_sample")
         return out
+
+
+class GraphedSampler:
+    """The whole Heun sampling call (every U-Net evaluation and state update of mcedm_heun_sample: ~4000 launches at
+    18 steps) captured ONCE into a HIP graph and replayed.  The library never allocates or synchronises and the sigma
+    schedule is host-side arithmetic baked into kernel arguments, so a replay is exact; inputs are copied into static
+    buffers first.  Shapes, sampler parameters and the packed-weight buffer are fixed per instance (re-packing weights
+    in place into the same buffer is fine)."""
+
+    def __init__(self, plan: "Plan", packed: torch.Tensor, sd: SamplerDesc, B: int, H: int, W: int, masked: bool = True,
+                 has_cond: bool = True, churn: bool = False, return_last: bool = True):
+        dev = packed.device
+        self.plan, self.packed, self.sd, self.return_last = plan, packed, sd, return_last
+        C = plan.in_channels
+        self.cond = torch.zeros((B, plan.cond_channels, H, W), device=dev) if has_cond else None
+        self.mask = torch.zeros((B, C, H, W), device=dev) if masked else None
+        self.init = torch.zeros((B, C, H, W), device=dev)
+        self.step_noise = torch.zeros((sd.timesteps, B, C, H, W), dtype=torch.float64, device=dev) if churn else None
+        T = 1 if return_last else sd.timesteps + 1
+        self.out = torch.empty((B, T, H, W, C), dtype=torch.float64, device=dev)
+        self.ws = Workspace()
+        self.ws.get(plan.sampler_workspace_bytes(B, H, W), dev)
+        side = torch.cuda.Stream(device=dev)          # warm-up off the capture: lazily initialised library state settles
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._run()
+
+    def _run(self):
+        self.plan.sample(self.packed, self.sd, self.cond, self.mask, self.init, self.step_noise, self.return_last, self.ws,
+                         out=self.out)
+
+    def __call__(self, cond, mask, init_noise, step_noise=None) -> torch.Tensor:
+        """Returns the instance's static output tensor (overwritten by the next call)."""
+        for dst, src, name in ((self.cond, cond, "cond"), (self.mask, mask, "mask"), (self.init, init_noise, "init_noise"),
+                               (self.step_noise, step_noise, "step_noise")):
+            if (dst is None) != (src is None):
+                raise RuntimeError(f"GraphedSampler: '{name}' presence differs from the captured call")
+            if dst is not None:
+                dst.copy_(src)
+        self.graph.replay()
+        return self.out
 
 
 # ---- flat-buffer training helpers -------------------------------------------------------------
@@ -334,6 +409,7 @@ def _bind_ops():
     lib.mcedm_op_conv.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32,
                                   i32, i32, vp]
     lib.mcedm_op_attention.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.mcedm_op_embedding.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.mcedm_op_wgrad_scratch_floats.argtypes = [i32, i32, i32, i32, i32, i32]
     lib.mcedm_op_wgrad_scratch_floats.restype = sz
     lib.mcedm_op_conv_wgrad.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
@@ -341,7 +417,7 @@ def _bind_ops():
     lib.mcedm_op_gn_bwd.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp,
                                     i32, vp, i32, vp, vp, vp, vp, i32, vp]
     lib.mcedm_op_attention_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
-    for n in ("mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv", "mcedm_op_attention", "mcedm_op_conv_wgrad",
+    for n in ("mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv", "mcedm_op_attention", "mcedm_op_embedding", "mcedm_op_conv_wgrad",
               "mcedm_op_gn_bwd", "mcedm_op_attention_bwd"):
         getattr(lib, n).restype = C.c_int
     _OPS_BOUND = True
@@ -351,7 +427,7 @@ def _bind_ops():
 OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv",
               "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report",
               "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd",
-              "mcedm_op_set_conv_debug", "mcedm_op_set_conv8"]
+              "mcedm_op_set_conv_debug", "mcedm_op_set_conv8", "mcedm_op_embedding"]
 
 
 def prof_enable(on: bool) -> None:
@@ -421,6 +497,18 @@ def op_conv(xa, xb, wpk, bias_pk, Cout, k, coef=None, coef_batch=1, act=0, resam
     check(lib.mcedm_op_conv(_ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, resample, Hs, Ws, H, W, _ptr(wpk),
                             _ptr(bias_pk), _ptr(res), res_mode, _ptr(out), Cout, B, k, _stream()), "op_conv")
     return out
+
+
+def op_embedding(labels, w0, b0, w1, b1, waff, baff):
+    """-> (emb [n, ch], film [n, rows]): sigma-embedding MLP + the concatenated per-block affine rows (K6)."""
+    lib = _bind_ops()
+    n, ch, rows = labels.numel(), w0.shape[0], waff.shape[0]
+    freqs = torch.empty(ch // 2, dtype=torch.float32, device=labels.device)
+    emb = torch.empty((n, ch), dtype=torch.float32, device=labels.device)
+    film = torch.empty((n, rows), dtype=torch.float32, device=labels.device)
+    check(lib.mcedm_op_embedding(_ptr(labels), n, ch, _ptr(w0), _ptr(b0), _ptr(w1), _ptr(b1), _ptr(waff), _ptr(baff), rows,
+                                 _ptr(freqs), _ptr(emb), _ptr(film), _stream()), "op_embedding")
+    return emb, film
 
 
 def op_attention(qkv: torch.Tensor, heads: int) -> torch.Tensor:

@@ -15,6 +15,7 @@ Deliberate differences, all documented in INTEGRATION.md:
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -87,20 +88,31 @@ class _EdmTrainLoss(torch.autograd.Function):
         ws = module._train_ws
         D = plan.denoise(packed, x_noise, sigma, cond=cond, ws=ws, training=True, sigma_data=module.sigma_data)
         loss, dD = _lib.edm_loss(D, x, mask, sigma, sigma_data=module.sigma_data, want_grad=True)
-        ctx.module, ctx.saved = module, (x_noise, sigma, cond, dD)
+        # the activations of THIS forward live in the module's single training workspace until its backward runs
+        module._train_generation += 1
+        ctx.module, ctx.saved, ctx.generation = module, (x_noise, sigma, cond, dD), module._train_generation
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         module = ctx.module
         net: DhariwalUNet = module.model
+        if ctx.generation != module._train_generation:
+            raise RuntimeError("training_step: another training forward overwrote this one's activations before its "
+                               "backward ran (one outstanding forward per module; run backward before the next forward)")
         x_noise, sigma, cond, dD = ctx.saved
         params = list(net.parameters())
         grads = module._grad_views(params)
         net.plan.denoise_backward(net.packed_weights(), net.named_param_dict(), x_noise, sigma, cond, dD, grads,
                                   ws=module._train_ws, sigma_data=module.sigma_data)
-        scale = g.to(torch.float32)
-        return (None, None, None, None, None, None) + tuple(gr * scale for gr in grads)
+        # one scale of the flat buffer into a FRESH tensor (autograd may keep the returned views as .grad, so they
+        # must not alias the buffer the next backward overwrites) instead of one multiply per parameter
+        flat = module._grad_buf * g.to(torch.float32)
+        out, off = [], 0
+        for p in params:
+            out.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return (None, None, None, None, None, None) + tuple(out)
 
 
 class PlMcedm(_Base):
@@ -142,6 +154,8 @@ class PlMcedm(_Base):
         self._train_ws = _lib.Workspace()
         self._sample_ws = _lib.Workspace()
         self._grad_buf = None
+        self._train_generation = 0
+        self._graphs = {}
 
     # ---- configuration hooks (same names as the reference) ------------------------------------------
     @staticmethod
@@ -297,9 +311,23 @@ class PlMcedm(_Base):
         t = _lib.edm_t_steps(sd)
         churn = any((min(sd.S_churn / N, math.sqrt(2) - 1) if sd.S_min <= t[i] <= sd.S_max else 0) > 0 for i in range(N))
         step_noise = torch.randn((N,) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if churn else None
+        cond, hu_mask, hu_noise = cond.float().contiguous(), hu_mask.float().contiguous(), hu_noise.contiguous()
         with torch.no_grad():
-            return net.plan.sample(net.packed_weights(), sd, cond.float().contiguous(), hu_mask.float().contiguous(),
-                                   hu_noise.contiguous(), step_noise, return_last=return_last, ws=self._sample_ws)
+            packed = net.packed_weights()
+            if os.environ.get("MCEDM_HIP_GRAPH", "1") != "0":
+                # the ~4000 launches of one sampling call replayed from one HIP graph (lib.GraphedSampler); instances are
+                # kept per (shape, sampler parameters, weight buffer) -- test / validation loops repeat the same call
+                B, _, H, W = hu_noise.shape
+                key = (B, H, W, bool(return_last), churn, packed.data_ptr(), hu_noise.device.index,
+                       tuple(getattr(sd, f) for f, _ in sd._fields_))
+                gs = self._graphs.get(key)
+                if gs is None:
+                    if len(self._graphs) >= 4:
+                        self._graphs.pop(next(iter(self._graphs)))
+                    gs = self._graphs[key] = _lib.GraphedSampler(net.plan, packed, sd, B, H, W, masked=True, has_cond=True,
+                                                                churn=churn, return_last=return_last)
+                return gs(cond, hu_mask, hu_noise, step_noise).clone()
+            return net.plan.sample(packed, sd, cond, hu_mask, hu_noise, step_noise, return_last=return_last, ws=self._sample_ws)
 
     # ---- evaluation loops (host-side bookkeeping, mcedm.py:283-441) ----------------------------------------
     def get_pde_loss(self, x_denoised, x_gt_unnorm=None, noise_level=None, clamp_loss=True, do_rearrange=True,

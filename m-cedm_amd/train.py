@@ -5,17 +5,22 @@ One process per GPU.  Per step (models/mcedm.py:254-281 + Lightning's DDP / clip
     x_noise, sigma      <- mcedm_edm_noise_inputs            (HIP)
     D                   <- mcedm_edm_denoise(training)        (HIP, activations kept in the workspace)
     loss, dD            <- mcedm_edm_loss                     (HIP)
-    grads (flat)        <- mcedm_edm_denoise_backward         (HIP)
-    grads               <- all-reduce(sum) over ranks          (RCCL via torch.distributed; ONE message: the flat buffer)
-    |g|^2               <- mcedm_sqnorm                        (HIP)
+    grads (flat)        <- mcedm_edm_denoise_backward_bucketed (HIP; records one event per gradient bucket)
+    grads               <- sum all-reduce, bucket by bucket, on a side stream as soon as a bucket's event fires, i.e.
+                           UNDER the rest of the backward (RCCL over xGMI through torch.distributed; gloo on CPU)
+    |g|^2               <- mcedm_sqnorm                        (HIP, after the side stream is joined)
     params, m, v, ema   <- mcedm_adam_ema_step                 (HIP: 1/world scaling + clip + Adam + EMA fused)
 
 The flat layout is the parameter order of ``DhariwalUNet.state_dict()``; each ``nn.Parameter`` of the model (and of the
 EMA copy) is re-pointed to a view of the flat buffer, so ``state_dict()`` / checkpoints are unchanged.
+
+Reproducibility: the weight-gradient kernel accumulates its split-K partial sums with fp32 atomics
+(csrc/wgrad_mfma.hip), so TRAINING gradients differ in the last bits from run to run and between shardings; only the
+inference / sampling path is bit-identical under batch sharding (tests/test_hip_fullsize.py).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -30,9 +35,13 @@ def shard_range(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def allreduce_mean_(flat: torch.Tensor, world: Optional[int] = None, average: bool = True) -> torch.Tensor:
     """In-place sum all-reduce of one flat buffer (RCCL on GPUs, gloo on CPU), optionally divided by world."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _world() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if average:
             flat.div_(world or dist.get_world_size())
@@ -62,46 +71,132 @@ def views_like(flat: torch.Tensor, params: Sequence[torch.Tensor]) -> List[torch
     return out
 
 
-class EdmTrainer:
-    """Fused training step for a ``mcedm_amd.mcedm.PlMcedm`` (or anything with ``.model`` / ``.ema_model``)."""
+class GradSync:
+    """Sum all-reduce of the flat gradient buffer in buckets that follow the backward's completion order.
 
-    def __init__(self, module, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, clip=1.0, ema_beta=0.999,
-                 P_mean=-1.2, P_std=1.2, sigma_data=1.0):
-        self.module = module
-        self.net = module.model
-        self.hp = dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, max_norm=clip,
-                       ema_beta=ema_beta)
+    ``bucket_first`` (from ``Plan.grad_buckets``) are first-parameter indices, decreasing, ending with 0; bucket k is
+    the element range of parameters [bucket_first[k], bucket_first[k-1]).  On a GPU, ``launch()`` makes a side stream
+    wait for bucket k's event (recorded by the library inside the backward) and issues that bucket's all-reduce there,
+    so the exchange of the decoder's gradients overlaps the encoder's backward; ``join()`` makes the caller's stream
+    wait for the side stream.  On CPU tensors (gloo, tests) the same bucket ranges are reduced in order, synchronously.
+    With world size 1 nothing is launched."""
+
+    def __init__(self, flat_g: torch.Tensor, numels: Sequence[int], bucket_first: Sequence[int]):
+        self.flat_g = flat_g
+        offs = [0]
+        for n in numels:
+            offs.append(offs[-1] + int(n))
+        self.bucket_first = [int(f) for f in bucket_first]
+        if not self.bucket_first or self.bucket_first[-1] != 0 or any(a <= b for a, b in zip(self.bucket_first, self.bucket_first[1:])):
+            raise RuntimeError("bucket_first must decrease and end with 0")
+        his = [len(numels)] + self.bucket_first[:-1]
+        self.ranges = [(offs[lo], offs[hi]) for lo, hi in zip(self.bucket_first, his)]      # element ranges, completion order
+        self.world = _world()
+        self.events: Optional[List[torch.cuda.Event]] = None
+        self.side: Optional[torch.cuda.Stream] = None
+        if flat_g.is_cuda:
+            self.side = torch.cuda.Stream(device=flat_g.device)
+            self.events = [torch.cuda.Event(enable_timing=False) for _ in self.ranges]
+            for e in self.events:
+                e.record()                 # torch creates the HIP event lazily; the library needs the handle
+
+    def launch(self) -> None:
+        if self.world == 1:
+            return
+        if self.side is None:
+            for lo, hi in self.ranges:
+                dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM)
+            return
+        for ev, (lo, hi) in zip(self.events, self.ranges):
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM)
+
+    def join(self) -> None:
+        if self.world > 1 and self.side is not None:
+            torch.cuda.current_stream(self.flat_g.device).wait_stream(self.side)
+
+
+def clip_adam_ema_(flat_p, flat_g, flat_m, flat_v, flat_ema, step: int, world: int, hp: Dict[str, float], sq: torch.Tensor,
+                   sqnorm_fn: Callable = _lib.sqnorm, adam_fn: Callable = _lib.adam_ema_step) -> None:
+    """What follows the all-reduce, as Lightning orders it (DDP mean -> clip_grad_norm_(1.0) -> Adam.step -> EmaModel.update):
+    ``flat_g`` holds the SUM over ranks; the 1/world of DDP's mean is folded into the fused kernel as ``grad_scale`` and the
+    clip factor is formed from the norm of the scaled gradient.  The two device functions are injectable so that the
+    world_size-2 CPU test drives this very function with reference implementations."""
+    sqnorm_fn(flat_g, sq)
+    adam_fn(flat_p, flat_g, flat_m, flat_v, flat_ema, step, sqnorm_t=sq, grad_scale=1.0 / world, **hp)
+
+
+class FlatTrainState:
+    """Flat parameter / gradient / Adam / EMA buffers of one network and the fused optimisation step on them."""
+
+    def __init__(self, plan: "_lib.Plan", params: Dict[str, torch.Tensor], packed: Optional[torch.Tensor] = None,
+                 ema: Optional[Dict[str, torch.Tensor]] = None, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                 clip=1.0, ema_beta=0.999, P_mean=-1.2, P_std=1.2, sigma_data=1.0, max_buckets: int = 4):
+        self.plan = plan
+        names = plan.param_names
+        tens = [params[n] for n in names]
+        self.hp = dict(lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, max_norm=clip, ema_beta=ema_beta)
         self.P_mean, self.P_std, self.sigma_data = P_mean, P_std, sigma_data
-        params = list(self.net.parameters())
-        self.flat_p = flatten_params_(params)
+        self.flat_p = torch.cat([t.detach().reshape(-1) for t in tens]).contiguous()
+        self.pviews = dict(zip(names, views_like(self.flat_p, tens)))
         self.flat_g = torch.zeros_like(self.flat_p)
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         self.flat_ema = None
-        if getattr(module, "ema_model", None) is not None:
-            self.flat_ema = flatten_params_(list(module.ema_model.ma_model.parameters()))
-        self.grad_views = views_like(self.flat_g, params)
+        if ema is not None:
+            self.flat_ema = torch.cat([ema[n].detach().reshape(-1) for n in names]).contiguous()
+        self.grad_views = views_like(self.flat_g, tens)
         self.sq = torch.zeros(1, dtype=torch.float64, device=self.flat_p.device)
         self.step_count = 0
         self.ws = _lib.Workspace()
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.packed = packed
+        self.world = _world()
+        self.sync = GradSync(self.flat_g, [t.numel() for t in tens], plan.grad_buckets(max_buckets if self.world > 1 else 1))
 
     def step(self, x, cond_in, mask, noise, rnd_normal):
         """One optimisation step on this rank's shard (all tensors NCHW fp32 on the device). Returns the local loss."""
-        net = self.net
-        plan, packed = net.plan, net.packed_weights()
+        plan = self.plan
+        self.packed = plan.pack(self.pviews, self.packed)
         x_noise, sigma = _lib.edm_noise_inputs(x, mask, noise, rnd_normal.reshape(-1).contiguous(), self.P_mean, self.P_std)
-        D = plan.denoise(packed, x_noise, sigma, cond=cond_in, ws=self.ws, training=True, sigma_data=self.sigma_data)
+        D = plan.denoise(self.packed, x_noise, sigma, cond=cond_in, ws=self.ws, training=True, sigma_data=self.sigma_data)
         loss, dD = _lib.edm_loss(D, x, mask, sigma, sigma_data=self.sigma_data, want_grad=True)
-        plan.denoise_backward(packed, net.named_param_dict(), x_noise, sigma, cond_in, dD, self.grad_views, self.ws,
-                              sigma_data=self.sigma_data)
-        allreduce_mean_(self.flat_g, average=False)                       # sum; the 1/world goes into the fused step
-        _lib.sqnorm(self.flat_g, self.sq)
+        plan.denoise_backward(self.packed, self.pviews, x_noise, sigma, cond_in, dD, self.grad_views, self.ws,
+                              sigma_data=self.sigma_data, bucket_first=self.sync.bucket_first, bucket_events=self.sync.events)
+        self.sync.launch()                 # bucketed sum all-reduce, overlapping the tail of the backward
+        self.sync.join()
         self.step_count += 1
-        _lib.adam_ema_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.flat_ema, self.step_count,
-                           sqnorm_t=self.sq, grad_scale=1.0 / self.world, **self.hp)
-        # the kernel wrote parameters (and the EMA copy) in place behind autograd's back: drop the packed copies
-        net._packed_key = None
+        clip_adam_ema_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.flat_ema, self.step_count, self.world, self.hp,
+                       self.sq)
+        return loss
+
+
+class EdmTrainer(FlatTrainState):
+    """Fused training step for a ``mcedm_amd.mcedm.PlMcedm`` (or anything with ``.model`` / ``.ema_model``): the module's
+    parameters (and its EMA copy's) are re-pointed at the flat buffers, so the module sees every update."""
+
+    def __init__(self, module, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, clip=1.0, ema_beta=0.999,
+                 P_mean=-1.2, P_std=1.2, sigma_data=1.0, max_buckets: int = 4):
+        self.module = module
+        self.net = module.model
+        net = self.net
+        params = dict(net.named_parameters())
+        ema_net = module.ema_model.ma_model if getattr(module, "ema_model", None) is not None else None
+        ema = dict(ema_net.named_parameters()) if ema_net is not None else None
+        super().__init__(net.plan, params, packed=None, ema=ema, lr=lr, beta1=beta1, beta2=beta2, eps=eps,
+                         weight_decay=weight_decay, clip=clip, ema_beta=ema_beta, P_mean=P_mean, P_std=P_std,
+                         sigma_data=sigma_data, max_buckets=max_buckets)
+        with torch.no_grad():
+            for n, p in params.items():
+                p.data = self.pviews[n]
+            if ema is not None:
+                for p, v in zip(ema.values(), views_like(self.flat_ema, list(ema.values()))):
+                    p.data = v
+
+    def step(self, x, cond_in, mask, noise, rnd_normal):
+        loss = super().step(x, cond_in, mask, noise, rnd_normal)
+        # the kernel wrote parameters (and the EMA copy) in place behind autograd's back: drop the modules' packed copies
+        self.net.invalidate_packed()
         if self.flat_ema is not None:
-            self.module.ema_model.ma_model._packed_key = None
+            self.module.ema_model.ma_model.invalidate_packed()
         return loss

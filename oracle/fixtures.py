@@ -190,3 +190,34 @@ def pde_darcy_inputs(name):
     a = 1.0 + 0.5 * torch.from_numpy(uniform(f"pde/darcy/{name}/a", B, S, S).astype(np.float32))
     u = 0.1 * randn(f"pde/darcy/{name}/u", B, S, S)
     return torch.stack((a, u), dim=-1)
+
+
+# ---- evaluation loops: test_step / validation_step of models/mcedm.py:283-441 ----------------
+# tag -> system, n_samples, datamodule.down_factor / down_interp.  'darcy_n16' is BASELINE config 4's path (n_samples=16:
+# the `n_samples < 15` branch of mcedm.py:438 drops the traj_* / gt_* entries) at plumbing size.
+STEP_CASES = {
+    "swe_n2": dict(system="swe_per", n_samples=2, down_factor=1, down_interp=False),
+    "swe_n2_down": dict(system="swe_per", n_samples=2, down_factor=2, down_interp=True),
+    "darcy_n16": dict(system="darcy", n_samples=16, down_factor=1, down_interp=False),
+}
+STEP_NORM_STATS = (1.4, 0.05, 0.0, 0.1)       # input mean/std, target mean/std: keeps un-normalised h (or a) positive
+STEP_B, STEP_T, STEP_X = 2, 32, 32
+
+
+def step_inputs(tag: str):
+    """The reference's evaluation batch (NHWC, h5_dataset.py:244-261): h, u un-normalised, masks {"u", "h"} (1 = missing),
+    and per task the injected noises: cond noise (get_cond_in, mcedm.py:247) and the sampler's initial noise (mcedm.py:576)."""
+    c = STEP_CASES[tag]
+    B, T, X, n = STEP_B, STEP_T, STEP_X, c["n_samples"]
+    st = STEP_NORM_STATS
+    h = randn(f"steps/{tag}/h", B, T, X, 1) * st[1] + st[0]
+    u = randn(f"steps/{tag}/u", B, T, X, 1) * st[3] + st[2]
+    masks = {"u": torch.zeros(B, T, X, 2), "h": torch.zeros(B, T, X, 2)}
+    masks["u"][..., 1] = 1.0
+    masks["h"][..., 0] = 1.0
+    noises = {k: (randn(f"steps/{tag}/{k}/cond_noise", B, T, X, 2), randn(f"steps/{tag}/{k}/init", n * B, 2, T, X))
+              for k in masks}
+    return h, u, masks, noises
+
+
+CFG_SAMPLER_W = 0.5       # classifier-free guidance weight of the 'cfg_u' sampler case (mcedm.py:453-458)

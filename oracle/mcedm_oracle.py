@@ -470,3 +470,83 @@ def adam_ema_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, ema: Tensor, step:
     p = p - (lr / bc1) * m / denom
     ema = ema * ema_beta + (1 - ema_beta) * p
     return p, m, v, ema
+
+
+# --------------------------------------------------------------------------- #
+# evaluation loops (host-side bookkeeping of models/mcedm.py:283-441)
+# --------------------------------------------------------------------------- #
+def masked_l1(pred: Tensor, target: Tensor, mask: Tensor, loss_dim=None) -> Tensor:
+    """MaskedLoss('l1'), models/losses.py:62-78."""
+    pred, target = pred * mask, target * mask
+    if loss_dim is None:
+        return (pred - target).abs().sum() / mask.sum()
+    return (pred[..., loss_dim] - target[..., loss_dim]).abs().sum() / mask[..., loss_dim].sum()
+
+
+def pde_metric(system: str, x_nhwc: Tensor, norm_stats) -> Tensor:
+    """get_pde_loss with x_gt_unnorm None, clamp_loss False, reduce True (mcedm.py:468-498) for the loss objects of
+    models/loss_helper.py:16-27 ('swe_per', 'swe', 'darcy'); norm_stats = (input mean, std, target mean, std)."""
+    from . import pde_oracle as po
+    st = [torch.as_tensor(s, dtype=torch.float32) for s in norm_stats]
+    h = x_nhwc[..., 0:1].to(torch.float32) * st[1] + st[0]                 # inverse_data_transform, mcedm.py:186-197
+    u = x_nhwc[..., 1:2].to(torch.float32) * st[3] + st[2]
+    x_un = torch.cat([h, u], dim=-1)
+    if system == "darcy":
+        return po.darcy_residual(x_un, clamp_loss=False).sum()
+    Tn, lo, hi = (0.128, -0.5, 0.5) if system == "swe_per" else (1.28, -2.5, 2.5)
+    return po.swe_fv_residual(x_un, x_un, st[1], st[3], Tn, lo, hi, 2, clamp_loss=False).sum()
+
+
+def eval_test_step(P, cfg, h: Tensor, u: Tensor, masks: Dict[str, Tensor], noises, norm_stats, sp: SamplerParams,
+                   n_samples: int, system: str, down_factor: int = 1) -> Dict[str, Tensor]:
+    """PlMcedm.test_step, mcedm.py:343-441 (return_last True, guide_dx False).  ``noises[name]`` = (cond noise NHWC,
+    sampler initial noise [(n b), C, T, X]) replace the randn_like draws of :247 and :576.  Returns the step dict plus
+    the logged scalars under 'log::<name>'."""
+    st = norm_stats
+    state_gt = torch.cat([(h - st[0]) / st[1], (u - st[2]) / st[3]], dim=-1)           # data_transform, b h w c
+    nb = len(h)
+    out: Dict[str, Tensor] = {}
+    for name, mask in masks.items():
+        lo = 0 if name.startswith("h") else 1
+        loss_dim = torch.arange(lo, lo + 1).long()
+        cond_noise, init = noises[name]
+        cond_rep = cond_input(state_gt, mask, cond_noise).permute(0, 3, 1, 2).repeat(n_samples, 1, 1, 1)
+        mask_rep = mask.permute(0, 3, 1, 2).repeat(n_samples, 1, 1, 1)
+        xs = sample_edm(P, cfg, cond_rep, mask_rep, sp, init)                               # [(n b), 1, T, X, 2] fp64
+        xs_mean = xs.reshape(n_samples, nb, *xs.shape[1:]).mean(dim=0)
+        hu_last = xs_mean[:, -1]
+        mask_loss = mask
+        if down_factor > 1:
+            each = 2 ** (down_factor - 1)
+            sel = torch.zeros_like(mask)
+            sel[:, ::each, ::each] = 1.0
+            mask_loss = mask * sel
+        out[f"loss_{name}"] = masked_l1(hu_last, state_gt, mask_loss, loss_dim)
+        un = torch.cat([hu_last[..., 0:1] * st[1] + st[0], hu_last[..., 1:2] * st[3] + st[2]], dim=-1)
+        out[f"loss_{name}_un"] = masked_l1(un, torch.cat([h, u], dim=-1), mask_loss, loss_dim)
+        out[f"log::test_pde_loss_{name}"] = pde_metric(system, xs[:, -1], st) / n_samples / nb
+        out["log::test_pde_loss_gt"] = pde_metric(system, state_gt, st) / nb
+        if n_samples < 15:
+            last = xs[:, -1]
+            out[f"traj_{name}"] = last.reshape(n_samples, nb, *last.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)
+            out[f"gt_{name}"] = state_gt
+    return out
+
+
+def eval_validation_step(P, cfg, h, u, masks, noises, norm_stats, sp: SamplerParams, system: str) -> Dict[str, Tensor]:
+    """PlMcedm.validation_step on an evaluated epoch, mcedm.py:283-341; noises[name] = (cond noise, initial noise [b,C,T,X])."""
+    st = norm_stats
+    state_gt = torch.cat([(h - st[0]) / st[1], (u - st[2]) / st[3]], dim=-1)
+    out: Dict[str, Tensor] = {}
+    for name, mask in masks.items():
+        cond_noise, init = noises[name]
+        cond_in = cond_input(state_gt, mask, cond_noise).permute(0, 3, 1, 2)
+        xs = sample_edm(P, cfg, cond_in, mask.permute(0, 3, 1, 2), sp, init)
+        hu_last = xs[:, -1]
+        out[f"loss_{name}"] = masked_l1(hu_last, state_gt, mask)
+        un = torch.cat([hu_last[..., 0:1] * st[1] + st[0], hu_last[..., 1:2] * st[3] + st[2]], dim=-1)
+        out[f"loss_{name}_un"] = masked_l1(un, torch.cat([h, u], dim=-1), mask)
+        out[f"log::val_pde_loss_{name}"] = pde_metric(system, hu_last, st) / len(h)
+        out[f"traj_{name}"] = hu_last.unsqueeze(1)
+        out[f"gt_{name}"] = state_gt
+    return out

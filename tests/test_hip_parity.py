@@ -323,6 +323,51 @@ def test_model_precond_golden(lib, golden, net_P):
     close(F, orc.unet_forward(P, fx.CFG_P, c_in * x, c_noise.flatten(), cond), what="F_x")
 
 
+def test_fused_groupnorm_statistics_with_large_means(lib):
+    """activations whose mean dwarfs their spread (|mean| / std ~ 50 at the conv_in output, ~20-40
+    after two residual blocks) through the FUSED statistics path (producer epilogue records -> consumer).  The records
+    are (sum, M2 about the tile mean) merged in fp64, so rstd keeps full precision; E[x^2] - E[x]^2 on fp32 partial
+    sums loses 1e-3 here.  Both consumers are covered: in-kernel rows (inference) and the table kernel (training layout)."""
+    plan = make_plan(lib, fx.CFG_P)
+    P = {k: v.clone() for k, v in orc.make_params(fx.CFG_P, 7).items()}
+    P["enc.128x128_conv.bias"] = 30.0 + 0.05 * fx.randn("t/bigmean/b0", 64)
+    P["enc.128x128_block0.conv1.bias"] = -20.0 + 0.05 * fx.randn("t/bigmean/b1", 64)
+    P["enc.64x64_block0.conv1.bias"] = 25.0 + 0.05 * fx.randn("t/bigmean/b2", 64)
+    P["dec.64x64_up.conv0.bias"] = 40.0 + 0.05 * fx.randn("t/bigmean/b3", 64)
+    packed = plan.pack({k: dev(v) for k, v in P.items()})
+    x, cond = fx.randn("t/bigmean/x", 3, 2, 40, 24), fx.randn("t/bigmean/c", 3, 2, 40, 24)     # ragged tiles too
+    lab = torch.tensor([0.4])
+    with torch.no_grad():
+        ref = orc.unet_forward(P, fx.CFG_P, x, lab, cond)
+        t0 = orc.conv2d(torch.cat([cond, x], 1), P["enc.128x128_conv.weight"], P["enc.128x128_conv.bias"])
+    ratio = float(t0.mean().abs() / t0.reshape(3, 16, -1).std(dim=-1).mean())
+    assert ratio > 40, ratio
+    close(plan.forward(packed, dev(x), dev(lab), cond=dev(cond)), ref, what=f"large-mean fused GN (|mean|/std = {ratio:.0f})")
+    close(plan.forward(packed, dev(x), dev(lab), cond=dev(cond), training=True), ref, what="large-mean GN, training layout")
+
+
+def test_embedding_kernel_golden(lib, golden):
+    """A1 at op level: PositionalEmbedding (golden pe_y) -> mapping MLP -> the blocks' affine rows, one launch (K6)."""
+    ch, rows = 64, 2 * (64 + 128 + 64)
+    lab = fx.PE_LABELS
+    w0, b0 = fx.param("t/emb", "map_layer0.weight", (ch, ch)), fx.param("t/emb", "map_layer0.bias", (ch,))
+    w1, b1 = fx.param("t/emb", "map_layer1.weight", (ch, ch)), fx.param("t/emb", "map_layer1.bias", (ch,))
+    wa, ba = fx.param("t/emb", "affine.weight", (rows, ch)), fx.param("t/emb", "affine.bias", (rows,))
+    pe = torch.as_tensor(golden("ops.npz")["pe_y"])                      # the reference's PositionalEmbedding output
+    e_ref = torch.nn.functional.silu(orc.linear(torch.nn.functional.silu(orc.linear(pe, w0, b0)), w1, b1))
+    emb, film = lib.op_embedding(dev(lab), dev(w0), dev(b0), dev(w1), dev(b1), dev(wa), dev(ba))
+    close(emb, e_ref, what="emb (mapping MLP on the golden positional embedding)")
+    close(film, orc.linear(e_ref, wa, ba), what="film rows")
+    # the positional embedding alone: identity layers expose it (silu is monotone; compare through its inverse-free form)
+    eye, zero = torch.eye(ch), torch.zeros(ch)
+    emb_id, _ = lib.op_embedding(dev(lab), dev(eye), dev(zero), dev(eye), dev(zero), dev(wa), dev(ba))
+    silu = torch.nn.functional.silu
+    close(emb_id, silu(silu(pe)), what="positional embedding through identity layers")
+    # n = 1 (sampling) takes the split-row grid
+    emb1, film1 = lib.op_embedding(dev(lab[2:3]), dev(w0), dev(b0), dev(w1), dev(b1), dev(wa), dev(ba))
+    close(film1, orc.linear(e_ref[2:3], wa, ba), what="film rows n=1")
+
+
 def test_unet_rectangular_and_odd_batch(lib, net_P):
     # T=64 x X=32 variant of BASELINE config 2 (net only needs H, W divisible by 4), batch 3
     plan, packed, P = net_P

@@ -170,3 +170,49 @@ def test_cond_edm_training(golden):
     for n in fx.COND_GRAD_NAMES:
         ref = torch.as_tensor(g[f"grad::{n}"])
         close(Pg[n].grad, ref, rtol=1e-3, atol=2e-6 * float(ref.abs().max()))
+
+
+# ---- evaluation loops + classifier-free sampler (tests/golden/steps.npz, oracle/make_golden_steps.py) -----------------
+@pytest.mark.parametrize("tag", ["swe_n2", "darcy_n16"])
+def test_eval_test_step(golden, tag):
+    """PlMcedm.test_step (models/mcedm.py:343-441); 'darcy_n16' is BASELINE config 4's path."""
+    g = golden("steps.npz")
+    c = fx.STEP_CASES[tag]
+    P = orc.make_params(fx.CFG_P, int(g["seed"]))
+    h, u, masks, noises = fx.step_inputs(tag)
+    with torch.no_grad():
+        o = orc.eval_test_step(P, fx.CFG_P, h, u, masks, noises, fx.STEP_NORM_STATS, orc.SamplerParams(), c["n_samples"],
+                               c["system"], c["down_factor"] if c["down_interp"] else 1)
+    ref_keys = sorted(k.split("::", 1)[1] for k in g if k.startswith(tag + "::") and "::log::" not in k)
+    assert ref_keys == sorted(k for k in o if not k.startswith("log::"))
+    assert ("traj_u" in o) == (c["n_samples"] < 15)
+    for k in ref_keys:
+        close(o[k], g[f"{tag}::{k}"], rtol=1e-4, atol=1e-5)
+    for name in masks:
+        close(o[f"log::test_pde_loss_{name}"], g[f"{tag}::log::test_pde_loss_{name}"], rtol=2e-3, atol=1e-6)
+    close(o["log::test_pde_loss_gt"], g[f"{tag}::log::test_pde_loss_gt"], rtol=1e-5, atol=1e-6)
+
+
+def test_eval_validation_step(golden):
+    g = golden("steps.npz")
+    P = orc.make_params(fx.CFG_P, int(g["seed"]))
+    h, u, masks, noises = fx.step_inputs("swe_n2")
+    vnoise = {k: (noises[k][0], noises[k][1][:fx.STEP_B]) for k in masks}
+    with torch.no_grad():
+        o = orc.eval_validation_step(P, fx.CFG_P, h, u, masks, vnoise, fx.STEP_NORM_STATS, orc.SamplerParams(), "swe_per")
+    for k in sorted(k[5:] for k in g if k.startswith("val::") and "::log::" not in k):
+        close(o[k], g[f"val::{k}"], rtol=1e-4, atol=1e-5)
+    for name in masks:
+        close(o[f"log::val_pde_loss_{name}"], g[f"val::log::val_pde_loss_{name}"], rtol=2e-3, atol=1e-6)
+
+
+def test_sample_edm_classifier_free(golden):
+    """w = 0.5 through all 35 evaluations (get_denoised's blend, models/mcedm.py:453-458)."""
+    g = golden("steps.npz")
+    P = orc.make_params(fx.CFG_P, int(g["seed"]))
+    cond, m, init, steps = fx.sampler_inputs("det_u")
+    with torch.no_grad():
+        xs = orc.sample_edm(P, fx.CFG_P, cond, m, orc.SamplerParams(w=fx.CFG_SAMPLER_W), init, steps, return_last=False)
+    scale = float(np.abs(g["cfg_u_xs_last"]).max())
+    close(xs[:, -1:], g["cfg_u_xs_last"], rtol=1e-4, atol=1e-5 * scale)
+    close(xs[:, ::6], g["cfg_u_xs_traj"], rtol=1e-4, atol=1e-5 * scale)

@@ -1,7 +1,10 @@
-"""CPU, world_size 2 over gloo: the data-parallel host logic of the N > 1 path -- batch sharding and the single
-flat-buffer gradient all-reduce -- gives the full-batch gradient (sum of per-shard gradients == full-batch gradient,
-SURVEY.md section 4 item 4).  The per-shard gradients come from the oracle; the HIP kernels themselves are covered by the
--m gpu tests."""
+"""CPU, world_size 2 over gloo: the data-parallel host logic of the N > 1 path, driven through the SAME host code the
+GPU trainer runs (mcedm_amd.train.GradSync and clip_adam_ema_): batch sharding, the bucketed sum all-reduce of the flat
+gradient buffer in the backward's completion order, and 1/world scaling + clip-after-average + Adam + EMA, must equal
+one full-batch step (Lightning: DDP mean -> clip_grad_norm_(1.0) -> Adam.step -> EmaModel.update).  The per-shard
+gradients come from the oracle and the two device functions (squared norm, fused Adam/EMA) are replaced by their CPU
+restatements; the HIP kernels themselves are covered by the -m gpu tests."""
+import math
 import os
 import sys
 
@@ -19,13 +22,15 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     import mcedm_amd  # noqa: F401
-    from mcedm_amd.train import allreduce_mean_, shard_range
+    from mcedm_amd import lib as L
+    from mcedm_amd.train import GradSync, clip_adam_ema_, shard_range
     from oracle import fixtures as fx
     from oracle import mcedm_oracle as orc
     cfg = orc.UNetConfig(ch=32, ch_mult=(1, 1), attn_resolutions=(), resolution=16)
     P = orc.make_params(cfg, 5)
+    names = [n for n, _ in orc.param_shapes(cfg)]
     B, H, W = 6, 8, 8
-    x = fx.randn("par/x", B, 2, H, W)
+    x = fx.randn("par/x", B, 2, H, W) * 3          # large enough that the clip (max_norm 1) is active
     mk = torch.zeros(B, 2, H, W)
     mk[:, 1] = 1
     cond = x * (1 - mk) + fx.randn("par/c", B, 2, H, W) * mk
@@ -34,15 +39,46 @@ def _worker(rank, world, port, out):
     def grads_of(lo, hi):
         Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
         orc.training_loss(Pg, cfg, x[lo:hi], cond[lo:hi], mk[lo:hi], noise[lo:hi], rnd[lo:hi]).backward()
-        return torch.cat([Pg[n].grad.reshape(-1) for n, _ in orc.param_shapes(cfg)])
+        return torch.cat([Pg[n].grad.reshape(-1) for n in names])
 
+    # the plan's bucket split (host-only C call) and the product's reducer on CPU tensors
+    plan = L.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks,
+                  cfg.attn_resolutions, cfg.resolution)
+    assert plan.param_names == names
+    firsts = plan.grad_buckets(3)
     lo, hi = shard_range(B, rank, world)
-    flat = grads_of(lo, hi)
-    allreduce_mean_(flat)                       # ONE message: the flat gradient buffer
+    flat_g = grads_of(lo, hi)
+    sync = GradSync(flat_g, [P[n].numel() for n in names], firsts)
+    assert sorted(sync.ranges) == sorted(set(sync.ranges)) and sum(b - a for a, b in sync.ranges) == flat_g.numel()
+    sync.launch()
+    sync.join()
     full = grads_of(0, B)
-    err = float((flat - full).abs().max() / full.abs().max())
+    err_sum = float((flat_g / world - full).abs().max() / full.abs().max())
+
+    # clip + Adam + EMA through the product's host function, device functions replaced by CPU restatements
+    flat_p = torch.cat([P[n].reshape(-1) for n in names])
+    st = dict(p=flat_p.clone(), m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), e=flat_p.clone())
+    seen = {}
+
+    def sqnorm_fn(g, sq):
+        sq[0] = float((g.double() ** 2).sum())
+
+    def adam_fn(p, g, m, v, e, step, sqnorm_t, grad_scale, lr, beta1, beta2, eps, weight_decay, max_norm, ema_beta):
+        total = math.sqrt(float(sqnorm_t)) * grad_scale               # norm of the AVERAGED gradient
+        clip = min(1.0, max_norm / (total + 1e-6))
+        seen["clip"] = clip
+        p1, m1, v1, e1 = orc.adam_ema_step(p, g * grad_scale, m, v, e, step, lr, beta1, beta2, eps, clip, ema_beta)
+        p.copy_(p1); m.copy_(m1); v.copy_(v1); e.copy_(e1)
+
+    hp = dict(lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, max_norm=1.0, ema_beta=0.999)
+    sq = torch.zeros(1, dtype=torch.float64)
+    clip_adam_ema_(st["p"], flat_g, st["m"], st["v"], st["e"], 1, world, hp, sq, sqnorm_fn=sqnorm_fn, adam_fn=adam_fn)
+    coef, _ = orc.clip_scale([full], 1.0)
+    p_ref, _, _, e_ref = orc.adam_ema_step(flat_p, full, torch.zeros_like(flat_p), torch.zeros_like(flat_p), flat_p, 1, clip=coef)
+    err_p = float((st["p"] - p_ref).abs().max())
+    err_e = float((st["e"] - e_ref).abs().max())
     if rank == 0:
-        out.put((err, (lo, hi)))
+        out.put((err_sum, (lo, hi), firsts, seen["clip"], coef, err_p, err_e))
     dist.destroy_process_group()
 
 
@@ -57,7 +93,7 @@ def test_shard_ranges_cover_the_batch():
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
 
 
-def test_two_rank_gradient_allreduce_equals_full_batch():
+def test_two_rank_bucketed_allreduce_clip_adam_equals_full_batch_step():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = 29500 + os.getpid() % 2000
@@ -67,5 +103,8 @@ def test_two_rank_gradient_allreduce_equals_full_batch():
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    err, rng = out.get(timeout=5)
+    err, rng, firsts, clip, clip_ref, err_p, err_e = out.get(timeout=5)
     assert rng == (0, 3) and err < 1e-5, (err, rng)
+    assert len(firsts) >= 2 and firsts[-1] == 0 and all(a > b for a, b in zip(firsts, firsts[1:])), firsts
+    assert clip_ref < 0.9 and abs(clip - clip_ref) < 1e-5 * clip_ref, (clip, clip_ref)     # the clip really was active
+    assert err_p < 5e-7 and err_e < 5e-9, (err_p, err_e)       # one fp32 ulp of O(1) parameters
