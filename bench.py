@@ -18,7 +18,7 @@ What is timed, and how:
   * `roofline` / `kernels`: a SEPARATE pass of `--profile-steps` eager calls with HIP event pairs around every launch
     on the launch stream (mcedm_prof_enable): per-kernel average duration against algorithmic flops / bytes;
   * `cpu_baseline`: the oracle (CPU restatement of the reference) on a bounded sample, 1 warm-up + median of 3, on all
-    physical cores and on one thread.
+    usable physical cores (host cores capped by the container's CPU quota) and on one thread.
 
 Workloads (BASELINE.json `configs`):
   s128    SWE-periodic 128x128, EDM U-Net ch=128, ch_mult [1,1,1,1], attention at 16^2, 32 states / GPU  (config 3; default,
@@ -134,7 +134,21 @@ def host_cpu():
         pass
     logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     physical = min(len(cores), logical) if cores else logical
-    return model, physical, logical
+    # the share of the host this process may actually use (container CPU quota): more threads than that only thrash
+    usable = physical
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = max(1, min(physical, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                usable = max(1, min(physical, int(math.ceil(q / per))))
+        except (OSError, ValueError):
+            pass
+    return model, physical, logical, usable
 
 
 def cpu_baseline(wl, params_cpu):
@@ -145,10 +159,10 @@ def cpu_baseline(wl, params_cpu):
     import torch
     from oracle import mcedm_oracle as orc
     cfg = orc.UNetConfig(ch=wl["ch"], ch_mult=wl["ch_mult"], attn_resolutions=wl["attn"])
-    model, physical, logical = host_cpu()
+    model, physical, logical, usable = host_cpu()
     big = wl["H"] * wl["W"] * wl["ch"] >= 128 * 128 * 64
     out = {}
-    for label, threads, states, nsteps in (("all_cores", physical, 1 if big else 8, 4 if big else STEPS),
+    for label, threads, states, nsteps in (("all_cores", usable, 2 if big else 8, 4 if big else STEPS),
                                            ("one_thread", 1, 1, 2 if big else 6)):
         torch.set_num_threads(threads)
         cond, mask, init = synth_inputs(states, wl["H"], wl["W"], 1, "cpu")
@@ -164,11 +178,11 @@ def cpu_baseline(wl, params_cpu):
         out[label] = {"states_per_s": states / (med * (2 * STEPS - 1) / nfe), "threads": threads,
                       "sample": f"{states} state(s) x {nfe} U-Net evaluations ({nsteps}-step Heun), median of 3 after 1 warm-up: "
                                 f"{med:.2f} s; scaled x{(2 * STEPS - 1) / nfe:.2f} to the 35 evaluations of an 18-step state"}
-    torch.set_num_threads(physical)
+    torch.set_num_threads(usable)
     a = out["all_cores"]
     return {"value": a["states_per_s"], "unit": "states/s", "cores": a["threads"], "kind": "port",
             "sample": a["sample"] + f"; torch {torch.__version__} CPU fp32", "cpu_model": model,
-            "physical_cores": physical, "logical_cpus": logical,
+            "physical_cores": physical, "logical_cpus": logical, "usable_cores_cpu_quota": usable,
             "one_thread": {"value": out["one_thread"]["states_per_s"], "unit": "states/s", "cores": 1,
                            "sample": out["one_thread"]["sample"]}}
 

@@ -77,6 +77,8 @@ class PlCondEdm(_Base):
         self.test_sparams = self.sparams
         self.h_ch, self.u_ch = m.cond_channels, m.out_ch
         self._train_ws, self._sample_ws, self._grad_buf = _lib.Workspace(), _lib.Workspace(), None
+        self._train_generation = 0
+        self._graphs = {}
 
     # ---- configuration ----------------------------------------------------------------------------------
     @staticmethod

@@ -206,7 +206,7 @@ def test_training_step_golden(lib, golden):
     plan, loss, grads = run_training_step(lib, fx.CFG_P, P, xc, cond_in, mc, noise, rnd_normal)
     close(loss, torch.as_tensor(g["loss"]).reshape(1), what="loss")
     for n in fx.TRAIN_GRAD_NAMES:
-        close(grads[n], g[f"grad::{n}"], rtol=1e-3, rel_atol=1e-4, what=f"grad {n}")
+        close(grads[n], g[f"grad::{n}"], rtol=1e-4, rel_atol=1e-5, what=f"grad {n}")
     sq = sum(float((v.double() ** 2).sum()) for v in grads.values())
     assert abs(sq - float(g["grad_sqnorm_total"])) <= 1e-3 * float(g["grad_sqnorm_total"])
     each = np.array([float((grads[n].double() ** 2).sum()) for n in plan.param_names])
@@ -239,7 +239,7 @@ def test_training_step_all_grads_vs_oracle(lib, cfg_name):
     plan, loss, grads = run_training_step(lib, cfg, P, xc, cond_in, mc, noise, rnd_normal)
     close(loss, ref_loss.detach().reshape(1), what="loss")
     for n in plan.param_names:
-        close(grads[n], Pg[n].grad, rtol=1e-3, rel_atol=1e-4, what=f"grad {n}")
+        close(grads[n], Pg[n].grad, rtol=1e-4, rel_atol=1e-5, what=f"grad {n}")
 
 
 def test_inference_forward_wide_multipliers_vs_oracle(lib):

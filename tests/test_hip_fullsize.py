@@ -95,4 +95,4 @@ def test_one_state_against_oracle_full_size(net):
     torch.set_num_threads(max(torch.get_num_threads(), 8))
     with torch.no_grad():
         ref = orc.sample_edm(P, CFG, cond, m, orc.SamplerParams(timesteps=18), init)
-    torch.testing.assert_close(xs.cpu(), ref, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(xs.cpu(), ref, rtol=1e-4, atol=1e-5)
