@@ -202,6 +202,8 @@ int mcedm_op_gn_coef(const float* xa, const float* xb, int Ca, int Cb, int B, in
                      mcedm_coef* coef_out, float* stats_out, void* stream);
 /* out = conv_k(resample(act(coef(cat(xa, xb))))) + bias + resample(res)   (models/adm_blocks.py:57-82 with the
  * pointwise ops of :161,166,171,179 fused).  resample / res_mode: 0 none, 1 nearest-2x up, 2 2x2-mean down.
+ * resample 3 (k = 3 only, no residual): the conv itself has stride 2 over the source padded by one zero row / column at
+ * the bottom / right -- the DDPM Downsample of models/ddim_blocks.py:85-104; then (Hs, Ws) = (2H, 2W).
  * (Hs, Ws) is the source size, (H, W) the conv size. */
 int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch, int act,
                   int resample, int Hs, int Ws, int H, int W, const float* wpk, const float* bias_pk,
@@ -251,6 +253,77 @@ int mcedm_op_set_conv8(int enable);
  * counter at the K loop's ends, [8..] per-phase cycle sums (MCEDM_CONV_TIMELINE builds) or per-wave HW_ID (8-wave
  * kernel).  NULL switches it off. */
 int mcedm_op_set_conv_debug(unsigned long long* buf);
+
+/* ---- RePaint-style EDM sampling on the DDPM U-Net ---------------------------------------
+ * The joint-DDPM baseline PlDdim (models/ddim.py) sampled with the EDM Heun sampler and RePaint-style resampling:
+ * `sample_edm` (ddim.py:959-1051: n_repeat inner loops per step, the known region re-noised to the current level
+ * after every loop), `get_denoised` (:915-947, VP preconditioning c_skip 1, c_out -sigma, c_noise = the nearest DDPM
+ * timestep), `round_sigma` (:949-957), `compute_alpha` (:700-704), on the ermongroup/ddim U-Net `Model`
+ * (models/ddim_blocks.py:222-470; configs/model/ddim_res32.yaml).  Inference only, one noise level per call,
+ * cond = None, x_self_cond = None (zeros), dx = None -- exactly what sample_edm evaluates. */
+typedef struct {
+  int32_t in_channels;       /* hparams.model.in_channels (state channels h_ch + u_ch), 2 */
+  int32_t out_channels;      /* out_ch */
+  int32_t ch;                /* base width (multiple of 32); temb width is 4 * ch */
+  int32_t n_levels;
+  int32_t ch_mult[MCEDM_MAX_LEVELS];
+  int32_t num_res_blocks;
+  int32_t resolution;        /* the network asserts input size == resolution (ddim_blocks.py:411); levels are resolution >> l */
+  int32_t n_attn_resolutions;
+  int32_t attn_resolutions[MCEDM_MAX_LEVELS];
+  int32_t self_cond;         /* 1: conv_in takes cat(x_self_cond, x) (ddim_blocks.py:262, 366-370) */
+  float eps;                 /* GroupNorm eps, 1e-6 (ddim_blocks.py:62-63) */
+} mcedm_ddpm_desc;
+
+/* configs/diff_sampler/edm_sampler_inv.yaml + the diffusion schedule tables PlDdim derives from `betas`
+ * (host pointers, fp32 as the reference holds them): edm_steps[n] = get_edm_steps() (ddim.py:131-137, largest sigma
+ * first), alphas_cumprod_ext[n + 1] = cumprod(1 - cat(0, betas)) (the table compute_alpha indexes with t + 1). */
+typedef struct {
+  int32_t timesteps;
+  double sigma_min, sigma_max, rho;
+  double S_churn, S_min, S_max, S_noise;
+  double w;                  /* must be 0 on this path (cond is None) */
+  int32_t n_repeat;          /* resampling loops per step */
+  int32_t n_time_h, n_time_u;/* rows [0, n_time_*) of the h / u channels are KNOWN (conditioning) */
+  int32_t h_ch, u_ch;
+  int32_t num_diffusion_timesteps;
+  const float* edm_steps;
+  const float* alphas_cumprod_ext;
+} mcedm_repaint_desc;
+
+typedef struct mcedm_ddpm_plan mcedm_ddpm_plan;
+int mcedm_ddpm_plan_create(const mcedm_ddpm_desc* desc, mcedm_ddpm_plan** out);
+void mcedm_ddpm_plan_destroy(mcedm_ddpm_plan* plan);
+/* Parameter table in Model.state_dict() order (names as the reference's: "temb.dense.0.weight", "down.0.block.0.norm1.weight", ...). */
+int mcedm_ddpm_param_count(const mcedm_ddpm_plan* plan);
+int mcedm_ddpm_param_info(const mcedm_ddpm_plan* plan, int index, const char** name, int64_t* numel, int32_t* ndim,
+                          int64_t shape[4]);
+int mcedm_ddpm_packed_bytes(const mcedm_ddpm_plan* plan, size_t* bytes);
+/* temb_freqs: device array [ch / 2] = exp(arange(ch/2) * -(ln 10000 / (ch/2 - 1))) exactly as get_timestep_embedding
+ * builds it (ddim_blocks.py:22-24); the caller owns that expression because t * freqs reaches ~1000 and a 1-ulp
+ * difference in a frequency is a 1e-4 difference in sin / cos. */
+int mcedm_ddpm_pack_weights(const mcedm_ddpm_plan* plan, const float* const* params, const float* temb_freqs, void* packed,
+                            void* stream);
+int mcedm_ddpm_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* bytes);
+/* Model.forward(x, t) (ddim_blocks.py:410-470), one timestep t for the whole batch; x [B, in_channels, R, R]. */
+int mcedm_ddpm_forward(const mcedm_ddpm_plan* plan, const void* packed, const float* x, float t, float* out, void* workspace,
+                       size_t workspace_bytes, int B, void* stream);
+/* PlDdim.get_denoised at a scalar sigma: D = x - sigma * F(x / sqrt(sigma^2 + 1), c_noise); c_noise is the timestep
+ * num_timesteps - 1 - round_sigma(sigma, return_index) the caller (or mcedm_repaint_sample) derives.  F_out may be NULL. */
+int mcedm_ddpm_denoise(const mcedm_ddpm_plan* plan, const void* packed, const float* x, float sigma, float c_noise,
+                       float* D_out, float* F_out, void* workspace, size_t workspace_bytes, int B, void* stream);
+/* Host helper: the rounded sigma schedule of ddim.py:982-986 (timesteps + 1 values, last = 0). */
+int mcedm_repaint_schedule(const mcedm_repaint_desc* sp, double* t_steps);
+/* PlDdim.sample_edm (ddim.py:959-1051), guide_dx False.
+ *  hu           [B, C, R, R] fp32 normalised joint state ('b h w c' of cat(h, u) rearranged to NCHW, ddim.py:967-968)
+ *  init_noise   [B, C, R, R] fp32            randn_like(hu) (:969), also the noise of every known-region re-noising
+ *  step_noise   [timesteps][B, C, R, R] fp64  the per-step draw (:1004); may be NULL when no step raises sigma
+ *  repeat_noise [timesteps][n_repeat - 1][B, C, R, R] fp64  the draw between inner loops (:1037); NULL iff n_repeat == 1
+ *  out          fp64 [B, 1 or timesteps + 1, R, R, C] */
+int mcedm_repaint_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* bytes);
+int mcedm_repaint_sample(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_repaint_desc* sp, const float* hu,
+                         const float* init_noise, const double* step_noise, const double* repeat_noise, double* out,
+                         int return_last, void* workspace, size_t workspace_bytes, int B, void* stream);
 
 /* ---- PDE residuals (forward) ----------------------------------------------
  * Replace the tensor-op bodies of models/pde_loss.py; results are bit-identical to the PyTorch CPU path.

@@ -52,7 +52,9 @@ struct __attribute__((aligned(16))) Coef {
   float mean, scale, offset, pad;
 };
 
-enum Resample { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2 };
+// RS_S2: no resampling of the source but the conv itself has stride 2 over a source padded by one zero row / column at
+// the bottom / right (the DDPM Downsample, models/ddim_blocks.py:97-101); forward conv only.
+enum Resample { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2, RS_S2 = 3 };
 
 // Geometry of a fused GroupNorm statistics table: the pixel tiling of the conv that produced the tensor.  One record
 // per (sample, tile, 4-channel block) = (sum, M2): the sum of the block's values inside the tile and their squared

@@ -67,7 +67,7 @@ __device__ __forceinline__ float apply_coef(float v, const Coef& c, int act) {
 // rows are prefetched with the inputs.
 template <class C, int RS>
 struct TileGeom {
-  static constexpr int NL = (RS == RS_DOWN) ? 4 : 1;
+  static constexpr int NL = (RS == RS_DOWN || RS == RS_S2) ? 4 : 1;
   static constexpr int SUB = (C::PLANE + C::NT - 1) / C::NT;
   unsigned boff[SUB][NL];   // clamped BYTE offsets inside one channel plane (the same for every channel)
   unsigned keep[SUB];       // all-ones: element lies inside the image; 0: it is conv zero padding
@@ -87,8 +87,10 @@ __device__ __forceinline__ void make_geom(const ConvArgs& p, TileGeom<C, RS>& G,
     const int e = tid + sub * C::NT;
     const int r = e / C::PITCH;
     const int c = e - r * C::PITCH;
-    const int y = y0 + r - C::HALO;
-    const int x = x0 + c - C::HALO;
+    // RS_S2: tile element (r, c) stands for the four source pixels (2y + {0,1}, 2x + {0,1}) of output-grid position
+    // (y, x) = (y0 + r, x0 + c); tap (a, b) of output pixel (py, px) reads phase (a&1, b&1) at (py + a/2, px + b/2)
+    const int y = y0 + r - (RS == RS_S2 ? 0 : C::HALO);
+    const int x = x0 + c - (RS == RS_S2 ? 0 : C::HALO);
     const bool inb = (e < C::PLANE) && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
     G.keep[sub] = inb ? 0xffffffffu : 0u;
     const int yc = inb ? y : 0, xc = inb ? x : 0;
@@ -220,6 +222,16 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
     const unsigned ckeep = chan_ok ? 0xffffffffu : 0u;
 #pragma unroll
     for (int sub = 0; sub < TileGeom<C, RS>::SUB; ++sub) {
+      if constexpr (RS == RS_S2) {
+        // the four phases go to four planes of the (4x larger) LDS tile: [ci_local][phase][ROWS][PITCH]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float vq = apply_coef(R.raw[cil][sub][q], R.cf[cil], p.act);
+          vq = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, vq) & (G.keep[sub] & ckeep));
+          if ((sub + 1) * C::NT <= C::PLANE || tid + sub * C::NT < C::PLANE) xl[(cil * 4 + q) * C::PLANE + tid + sub * C::NT] = vq;
+        }
+        continue;
+      }
       float v;
       if constexpr (RS == RS_DOWN) {
         // 2x2 box filter of the ACTIVATED source (adm_blocks.py:75-77 runs after silu(norm(x)))
@@ -432,9 +444,16 @@ __device__ __forceinline__ void conv_stats_combine(const float* red, int stride_
 // One K chunk (KC input channels x all taps) of the implicit GEMM out of the LDS slabs.
 // UNROLL_TAPS: the tap loop fully unrolled (all LDS offsets immediates, no loop-carried address arithmetic; VALU
 // and bubbles in this loop are paid in matrix time): +6...18 % on the small tiles, +0.6 % on <128, 8, 32>.
-template <class C, bool UNROLL_TAPS = true>
+// S2: stride-2 conv on the 4-phase tile (channel stride 4 planes; tap (a, b) -> phase (a&1, b&1), offset (a/2, b/2)).
+template <class C, bool UNROLL_TAPS = true, bool S2 = false>
 __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32x16 (&acc)[C::TM][C::TN], int aoff,
                                            const int (&boff)[C::TN]) {
+  constexpr int CS = S2 ? 4 * C::PLANE : C::PLANE;          // floats between consecutive input channels in LDS
+  auto tap_off = [](int tap) {
+    if (C::TAPS != 9) return 0;
+    const int a = tap / 3, b = tap % 3;
+    return S2 ? ((a & 1) * 2 + (b & 1)) * C::PLANE + (a >> 1) * C::PITCH + (b >> 1) : a * C::PITCH + b;
+  };
   // Register double-buffered operand fragments: the LDS reads of k-step s+1 are issued before the MFMAs
   // of k-step s; the fragment for the next tap's first k-step is fetched at the end of the current tap.
   float fa[2][C::TM], fb[2][C::TN];
@@ -445,9 +464,9 @@ __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32
   constexpr int TAP_UNROLL = UNROLL_TAPS ? C::TAPS : 1;
 #pragma unroll TAP_UNROLL
   for (int tap = 0; tap < C::TAPS; ++tap) {
-    const int toff = (C::TAPS == 9) ? (tap / 3) * C::PITCH + (tap % 3) : 0;
+    const int toff = tap_off(tap);
     const int tn = (tap + 1 < C::TAPS) ? tap + 1 : tap;         // clamped: the last prefetch is discarded
-    const int toff_n = (C::TAPS == 9) ? (tn / 3) * C::PITCH + (tn % 3) : 0;
+    const int toff_n = tap_off(tn);
     const float* wt = wl + aoff + tap * C::KC * C::MT;
     const float* wt_n = wl + aoff + tn * C::KC * C::MT;
 #pragma unroll
@@ -457,7 +476,7 @@ __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) fa[nxt][i] = wt[2 * (kk + 1) * C::MT + i * 32];
 #pragma unroll
-        for (int j = 0; j < C::TN; ++j) fb[nxt][j] = xl[boff[j] + toff + 2 * (kk + 1) * C::PLANE];
+        for (int j = 0; j < C::TN; ++j) fb[nxt][j] = xl[boff[j] + toff + 2 * (kk + 1) * CS];
       } else {
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) fa[nxt][i] = wt_n[i * 32];
@@ -500,7 +519,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) {
     const int pix = (wn * C::TN + j) * 32 + (lane & 31);
-    boff[j] = (lane >> 5) * C::PLANE + (pix / C::PW) * C::PITCH + (pix % C::PW);
+    boff[j] = (lane >> 5) * (RS == RS_S2 ? 4 * C::PLANE : C::PLANE) + (pix / C::PW) * C::PITCH + (pix % C::PW);
   }
   const int aoff = (lane >> 5) * C::MT + wm * C::TM * 32 + (lane & 31);
 
@@ -549,7 +568,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
       load_input<C, RS, false>(p, geom, xin, n, chn * C::KC);
     }
     MCEDM_STAMP(2)
-    if (wave < C::NWAVE) mfma_chunk<C>(xl, wl, acc, aoff, boff);
+    if (wave < C::NWAVE) mfma_chunk<C, true, RS == RS_S2>(xl, wl, acc, aoff, boff);
     MCEDM_STAMP(3)
     __syncthreads();
     MCEDM_STAMP(4)
@@ -606,6 +625,17 @@ __global__ __launch_bounds__(256, RSK == RS_DOWN ? 2 : C::OCC) void conv_mfma_ke
   __shared__ __attribute__((aligned(16))) float wl[C::WL];
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];      // (Ca + Cb) transform rows
   conv_body<C, RSK>(p, xl, wl, reinterpret_cast<Coef*>(dyn_lds), tiles_x, tiles_y, mtiles, nchunks, coutp);
+}
+
+// Stride-2 3x3 conv (DDPM Downsample, models/ddim_blocks.py:85-104): the same body on a 4-phase input tile.
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_s2_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles, int nchunks,
+                                                             int coutp) {
+  static_assert(C::TAPS == 9, "stride-2 conv is 3x3");
+  __shared__ __attribute__((aligned(16))) float xl[4 * C::XL];
+  __shared__ __attribute__((aligned(16))) float wl[C::WL];
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  conv_body<C, RS_S2>(p, xl, wl, reinterpret_cast<Coef*>(dyn_lds), tiles_x, tiles_y, mtiles, nchunks, coutp);
 }
 
 // Weight slab global -> LDS without passing through VGPRs (LDS-DMA, 16 bytes per lane): the LDS image is the linear
@@ -979,6 +1009,53 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   return MCEDM_OK;
 }
 
+template <class C>
+static int launch_cfg_s2(const ConvArgs& a_in, hipStream_t stream) {
+  ConvArgs a = a_in;
+  a.dbg = nullptr;
+  a.coef_rows = 1;
+  if (!a.coef) {
+    static const Coef* ident[64] = {};
+    int dev = 0;
+    MCEDM_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device index %d out of range", dev); return MCEDM_ERR_INVALID; }
+    if (!ident[dev]) MCEDM_HIP_TRY(hipGetSymbolAddress((void**)&ident[dev], HIP_SYMBOL(k_identity_coef)));
+    a.coef = ident[dev]; a.coef_batch = 0; a.coef_rows = 0;
+  }
+  const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
+  const int mtiles = ceil_div(a.Cout, C::MT);
+  const int nchunks = ceil_div(a.Ca + a.Cb, C::KC);
+  const long long blocks = (long long)a.B * tiles_x * tiles_y * mtiles;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv grid out of range (%lld blocks)", blocks); return MCEDM_ERR_INVALID; }
+  char name[96] = "";
+  if (prof_enabled())
+    snprintf(name, sizeof(name), "conv_s2_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d> >", C::MT, C::PH, C::PW, C::WM,
+             C::WN, C::TAPS, C::KC, C::NT);
+  const double px = (double)a.B * a.H * a.W;
+  ProfScope ps(name, 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * 9,
+               4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout + (double)a.Cout * (a.Ca + a.Cb) * 9), stream);
+  const unsigned rows_bytes = (unsigned)(a.Ca + a.Cb) * (unsigned)sizeof(Coef);
+  MCEDM_REQUIRE((4 * C::XL + C::WL) * sizeof(float) + rows_bytes <= 64 * 1024, "conv: %d input channels exceed the LDS row table",
+                a.Ca + a.Cb);
+  hipLaunchKernelGGL((conv_s2_mfma_kernel<C>), dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, tiles_x, tiles_y,
+                     mtiles, nchunks, cout_padded(a.Cout));
+  MCEDM_LAUNCH_CHECK("conv_s2_mfma_kernel");
+  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
+  return MCEDM_OK;
+}
+
+static int dispatch_s2(const ConvArgs& a, hipStream_t stream) {
+  const int coutp = cout_padded(a.Cout);
+  // pixel tile by image size only (as in dispatch: batch-independent bits); channel tile 64 when it divides
+  if ((long long)a.H * a.W <= 256 || a.W < 12) {
+    if (coutp % 64 == 0) return launch_cfg_s2<ConvCfg<64, 8, 8, 2, 2, 9, 8>>(a, stream);
+    return launch_cfg_s2<ConvCfg<32, 8, 8, 1, 2, 9, 8>>(a, stream);
+  }
+  if (coutp % 64 != 0) return launch_cfg_s2<ConvCfg<32, 8, 8, 1, 2, 9, 8>>(a, stream);
+  if (a.W >= 48) return launch_cfg_s2<ConvCfg<64, 8, 32, 1, 4, 9, 8>>(a, stream);
+  return launch_cfg_s2<ConvCfg<64, 8, 16, 1, 4, 9, 8>>(a, stream);
+}
+
 typedef ConvCfg<128, 16, 32, 1, 8, 9, 8, 512> Conv8Cfg;
 static int g_conv8 = -1;     // MCEDM_CONV8=1 selects the 8-wave kernel for the large layers (off: it only ties)
 
@@ -1126,6 +1203,8 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {
   MCEDM_REQUIRE(a.out && a.wpk, "conv: null output / weights");
   if (a.resample == RS_UP) MCEDM_REQUIRE(a.Hs * 2 == a.H && a.Ws * 2 == a.W, "conv: up-resample needs H = 2*Hs");
   else if (a.resample == RS_DOWN) MCEDM_REQUIRE(a.Hs == a.H * 2 && a.Ws == a.W * 2, "conv: down-resample needs Hs = 2*H");
+  else if (a.resample == RS_S2) MCEDM_REQUIRE(taps == 9 && a.Hs == a.H * 2 && a.Ws == a.W * 2 && !a.res,
+                                              "conv: the stride-2 conv is 3x3 on an even-sized source, without residual");
   else MCEDM_REQUIRE(a.Hs == a.H && a.Ws == a.W, "conv: source size mismatch");
   if (a.res && a.res_mode == RS_UP) MCEDM_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0, "conv: up residual needs even size");
   // 32-bit buffer offsets: one channel plane and the packed weight table must each stay below 4 GiB
@@ -1141,6 +1220,7 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {
   // (at <= 32 x 32 the padded matrix kernel is still faster: 43 vs 60 us at B = 64)
   if (taps == 9 && a.Cout <= 4 && a.resample == RS_NONE && !a.res && !a.gsum && !g_force_mt && (long long)a.H * a.W >= 4096)
     return launch_small_cout(a, stream);
+  if (a.resample == RS_S2) return dispatch_s2(a, stream);
   return taps == 9 ? dispatch<9, 8>(a, stream) : dispatch<1, 16>(a, stream);
 }
 

@@ -167,6 +167,69 @@ int launch_heun_store(const double* x, int C, size_t hw, int t, int T, size_t to
   return MCEDM_OK;
 }
 
+// ---- RePaint-style EDM sampling on the DDPM U-Net (PlDdim, models/ddim.py:915-1051) -------------------------------
+__global__ void vp_finish_kernel(const float* __restrict__ x, const float* __restrict__ F, float c_out, size_t total,
+                                 float* __restrict__ D) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    D[i] = 1.0f * x[i] + c_out * F[i];                                // c_skip * xt + c_out * F_x, ddim.py:945
+}
+int launch_vp_finish(const float* x, const float* F, float sigma, size_t total, float* D, hipStream_t s) {
+  hipLaunchKernelGGL(vp_finish_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, F, -sigma, total, D);
+  MCEDM_LAUNCH_CHECK("vp_finish_kernel");
+  return MCEDM_OK;
+}
+
+__global__ void vp_coef_kernel(float c_in, int n_self, int n_in, Coef* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c < n_self + n_in) out[c] = Coef{0.f, c < n_self ? 1.0f : c_in, 0.f, 0.f};
+}
+int launch_vp_coef(float c_in, int n_self, int n_in, Coef* out, hipStream_t s) {
+  MCEDM_REQUIRE(n_self + n_in <= 64, "vp_coef: too many input channels");
+  hipLaunchKernelGGL(vp_coef_kernel, dim3(1), dim3(64), 0, s, c_in, n_self, n_in, out);
+  MCEDM_LAUNCH_CHECK("vp_coef_kernel");
+  return MCEDM_OK;
+}
+
+__global__ void repaint_init_kernel(const float* __restrict__ hu, const float* __restrict__ noise,
+                                    const float* __restrict__ mask, float sa, float sb, double t0, size_t total,
+                                    double* __restrict__ x, float* __restrict__ x32) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float m = mask[i], nz = noise[i];
+    const float known = hu[i] * sa + nz * sb;                          // hu * aT.sqrt() + hu_noise * (1 - aT).sqrt(), fp32
+    const float v32 = known * m + nz * (1.0f - m);
+    const double v = (double)v32 * t0;
+    x[i] = v;
+    x32[i] = (float)v;
+  }
+}
+int launch_repaint_init(const float* hu, const float* noise, const float* mask, float sa, float sb, double t0, size_t total,
+                        double* x, float* x32, hipStream_t s) {
+  hipLaunchKernelGGL(repaint_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, hu, noise, mask, sa, sb, t0, total, x, x32);
+  MCEDM_LAUNCH_CHECK("repaint_init_kernel");
+  return MCEDM_OK;
+}
+
+__global__ void repaint_known_kernel(double* __restrict__ x, const float* __restrict__ hu, const float* __restrict__ noise,
+                                     const float* __restrict__ mask, float sa, float sb, int final_clean, size_t total,
+                                     float* __restrict__ x32) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float m = mask[i];
+    // at_next.sqrt() * hu + (1 - at_next).sqrt() * hu_noise in fp32; the final replacement uses the clean hu
+    const float known = final_clean ? hu[i] : sa * hu[i] + sb * noise[i];
+    const float km = known * m;                                        // fp32 * fp32
+    const double v = (double)km + x[i] * (double)(1.0f - m);           // fp64 * fp32 promotes to fp64
+    x[i] = v;
+    x32[i] = (float)v;
+  }
+}
+int launch_repaint_known(double* x, const float* hu, const float* noise, const float* mask, float sa, float sb, int final_clean,
+                         size_t total, float* x32, hipStream_t s) {
+  hipLaunchKernelGGL(repaint_known_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, hu, noise, mask, sa, sb, final_clean,
+                     total, x32);
+  MCEDM_LAUNCH_CHECK("repaint_known_kernel");
+  return MCEDM_OK;
+}
+
 // ---- training-side elementwise ----------------------------------------------------------------
 // sigma = exp(rnd*P_std + P_mean) (mcedm.py:271); x_noise = x + mask*noise*sigma (mcedm.py:216)
 __global__ void noise_inputs_kernel(const float* __restrict__ x, const float* __restrict__ mask,

@@ -19,4 +19,16 @@ int launch_heun_correct(const double* x_hat, const double* d_cur, const float* D
                         double dt, size_t total, double* x_next, float* x32, hipStream_t s);
 int launch_heun_store(const double* x, int C, size_t hw, int t, int T, size_t total, double* out, hipStream_t s);
 
+// ---- RePaint-style sampler on the DDPM U-Net (models/ddim.py:915-1051): VP preconditioning and known-region kernels
+// D = x + (-sigma) * F                                                   (get_denoised, ddim.py:923-946: c_skip 1, c_out -sigma)
+int launch_vp_finish(const float* x, const float* F, float sigma, size_t total, float* D, hipStream_t s);
+// conv_in transform rows of the VP network input: n_self zero/self-conditioning channels pass, the state is scaled by c_in
+int launch_vp_coef(float c_in, int n_self, int n_in, Coef* out, hipStream_t s);
+// x0 = ((hu*sa + nz*sb)*m + nz*(1-m)) [fp32] -> fp64, times t0        (ddim.py:989-994), m = 1 marks KNOWN entries
+int launch_repaint_init(const float* hu, const float* noise, const float* mask, float sa, float sb, double t0, size_t total,
+                        double* x, float* x32, hipStream_t s);
+// x = (sa*hu + sb*nz)*m [fp32] + x*(1-m) [fp64]                          (ddim.py:1029-1031); final: x = hu*m + x*(1-m) (:1041-1043)
+int launch_repaint_known(double* x, const float* hu, const float* noise, const float* mask, float sa, float sb, int final_clean,
+                         size_t total, float* x32, hipStream_t s);
+
 }  // namespace mcedm

@@ -40,7 +40,7 @@ extern "C" int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, c
                              const float* bias_pk, const float* res, int res_mode, float* out, int Cout, int B, int k,
                              void* stream) {
   MCEDM_REQUIRE(k == 1 || k == 3, "op_conv: k must be 1 or 3");
-  MCEDM_REQUIRE(resample >= 0 && resample <= 2 && res_mode >= 0 && res_mode <= 2, "op_conv: bad resample mode");
+  MCEDM_REQUIRE(resample >= 0 && resample <= 3 && res_mode >= 0 && res_mode <= 2, "op_conv: bad resample mode");
   ConvArgs a{};
   a.xa = xa; a.xb = xb; a.Ca = Ca; a.Cb = Cb;
   a.coef = reinterpret_cast<const Coef*>(coef); a.coef_batch = coef_batch; a.act = act;

@@ -1,7 +1,9 @@
 // plan.hpp -- host-side description of the network (block list, parameter table, packed-weight
 // layout) and of the activation layout inside the caller's workspace.
 #pragma once
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -9,6 +11,36 @@
 namespace mcedm {
 
 constexpr size_t NONE = (size_t)-1;
+
+// first-fit pool over the caller's workspace, simulated on the host (offsets only)
+struct Pool {
+  std::vector<std::pair<size_t, size_t>> free_;   // (offset, bytes), sorted by offset
+  size_t top = 0, peak = 0;
+  bool keep_all = false;
+  size_t alloc(size_t bytes) {
+    bytes = align_up(bytes ? bytes : 1, 256);
+    for (size_t i = 0; i < free_.size(); ++i)
+      if (free_[i].second >= bytes) {
+        const size_t off = free_[i].first;
+        if (free_[i].second == bytes) free_.erase(free_.begin() + i);
+        else { free_[i].first += bytes; free_[i].second -= bytes; }
+        return off;
+      }
+    const size_t off = top;
+    top += bytes;
+    peak = std::max(peak, top);
+    return off;
+  }
+  void release(size_t off, size_t bytes) {
+    if (keep_all) return;
+    bytes = align_up(bytes ? bytes : 1, 256);
+    auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(off, (size_t)0));
+    it = free_.insert(it, {off, bytes});
+    if (it + 1 != free_.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; free_.erase(it + 1); }
+    if (it != free_.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; it = free_.erase(it) - 1; }
+    if (it->first + it->second == top) { top = it->first; free_.erase(it); }
+  }
+};
 
 struct ParamInfo {
   std::string name;

@@ -1,4 +1,11 @@
-"""Drop-in ``PlCondEdm`` for the reference's ``models/ddim.py:1608-1773`` (single-task conditional EDM: the
+"""Drop-ins for the reference's ``models/ddim.py``:
+
+``PlDdim`` (bottom of this file): the joint DDPM baseline sampled with the EDM Heun sampler and
+RePaint-style resampling -- ``sample_edm`` (models/ddim.py:959-1051), ``get_denoised`` (:915-947), ``round_sigma``
+(:949-957), ``compute_alpha`` (:700-704) on the DDPM U-Net of ``m-cedm_amd/ddim_blocks.py``; the loop runs in
+``mcedm_repaint_sample`` (csrc/ddpm.hip).
+
+``PlCondEdm`` for ``models/ddim.py:1608-1773`` (single-task conditional EDM: the
 conditioning field h is given, the state u is generated) -- SURVEY.md section 8(f2).
 
 It runs on the same HIP path as ``PlMcedm``: the same ``DhariwalUNet`` (``in_channels`` 1 + ``cond_channels`` 1 ->
@@ -254,3 +261,132 @@ class PlCondEdm(_Base):
         last = xs[:, -1]
         traj = last.reshape(n, nb, *last.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)       # '(n b) h w c -> b h w n c'
         return {"loss": loss_u, "loss_u_un": loss_u_un, "traj": traj, "gt": u}
+
+
+class PlDdim(_Base):
+    """models/ddim.py:16-1051, the part BASELINE config 5 exercises: EDM / RePaint sampling of the joint (h, u) DDPM.
+    Constructor, buffers (``betas``, ``logvar``), attributes and the signatures of ``set_test_sampler_params``,
+    ``get_edm_steps``, ``compute_alpha``, ``round_sigma``, ``get_denoised`` and ``sample_edm`` follow the reference.
+    DDPM training, the DDIM ``sample`` / ``sample_with_repeat`` loops and PDE guidance are not built and raise."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.save_hyperparameters()
+        m, o, d, df = hparams.model, hparams.optimization, hparams.data, hparams.diffusion
+        for flag in ("dx_cond", "node_type"):
+            if hasattr(m, flag) and getattr(m, flag):
+                raise NotImplementedError(f"hparams.model.{flag}=True is outside the built path")
+        if str(hparams.name).startswith("adm"):
+            raise NotImplementedError("PlDdim with the ADM U-Net is not built; use PlMcedm / PlCondEdm for ADM networks")
+        from .ddim_blocks import Model
+        betas = _beta_schedule(df.beta_schedule, df.beta_start, df.beta_end, df.num_diffusion_timesteps)
+        acp = (1.0 - betas).cumprod(dim=0)
+        post_var = betas * (1.0 - torch.cat([torch.ones(1), acp[:-1]])) / (1.0 - acp)
+        self.model_var_type = m.var_type
+        self.register_buffer("betas", betas)
+        self.num_timesteps = betas.shape[0]
+        if m.var_type == "fixedlarge":
+            self.register_buffer("logvar", betas.log())
+        elif m.var_type == "fixedsmall":
+            self.register_buffer("logvar", post_var.clamp(min=1e-20).log())
+        self.cond_p = 0.0
+        self.dx_cond = self.node_type = False
+        self.model = Model(hparams)
+        self.ema_model = EmaModel(self.model, beta=m.ema_rate) if m.ema else None
+        self.normalization, self.rescaled = d.normalization, d.rescaled
+        self.uniform_dequantization, self.gaussian_dequantization = d.uniform_dequantization, d.gaussian_dequantization
+        n_state = m.out_ch // 2
+        self.normalizer_input = Normalizer((n_state,) if n_state > 1 else ())
+        self.normalizer_target = Normalizer((n_state,) if n_state > 1 else ())
+        self.optimizer, self.lr, self.weight_decay = o.optimizer, o.lr, o.weight_decay
+        self.beta1, self.amsgrad, self.eps = o.beta1, o.amsgrad, o.eps
+        self.sparams = hparams.sampler if hparams.get("sampler", None) is not None else \
+            DotDict(type="ddim", timesteps=50, skip_type="uniform", eta=0.0, n_samples=1, n_repeat=5, n_time_h=128, n_time_u=0)
+        self.test_sparams = self.sparams
+        self.h_ch = self.u_ch = n_state
+        self.edm_steps = None
+        self.sigma_min = self.sigma_max = None
+        self._sample_ws = _lib.Workspace()
+        self._graphs = {}
+
+    # ---- schedule (host side, the reference's own expressions on CPU tensors) ----------------------------------
+    def set_test_sampler_params(self, params):
+        self.test_sparams = params
+        if params.type == "edm":                                   # models/ddim.py:125-129
+            self.edm_steps = self.get_edm_steps()
+            self.sigma_min = float(self.edm_steps[self.num_timesteps - 1])
+            self.sigma_max = float(self.edm_steps[0])
+
+    def get_edm_steps(self):
+        """models/ddim.py:131-137, evaluated on the CPU like the schedule buffers themselves."""
+        b = self.betas.detach().cpu()
+        alphas_bar = (1.0 - b).cumprod(dim=0)
+        return ((1 - alphas_bar) / alphas_bar).sqrt().flip(dims=(0,))
+
+    def _alphas_ext(self):
+        b = self.betas.detach().cpu()
+        return (1 - torch.cat([torch.zeros(1), b], dim=0)).cumprod(dim=0)
+
+    def compute_alpha(self, t):
+        """models/ddim.py:700-704."""
+        return self._alphas_ext().index_select(0, torch.as_tensor(t).cpu().reshape(-1) + 1).view(-1, 1, 1, 1)
+
+    def round_sigma(self, sigma, return_index=False):
+        """models/ddim.py:949-957 (host tensors: the schedule is scalar work)."""
+        if self.edm_steps is None:
+            raise RuntimeError("call set_test_sampler_params(params) with params.type == 'edm' first (models/ddim.py:122-129)")
+        sigma = torch.as_tensor(sigma)
+        s32 = sigma.detach().cpu().to(torch.float32)
+        index = torch.cdist(s32.reshape(1, -1, 1), self.edm_steps.reshape(1, -1, 1)).argmin(2)
+        result = index if return_index else self.edm_steps[index.flatten()]
+        return result.to(device=sigma.device).type_as(sigma).reshape(sigma.shape)
+
+    def _net(self, model):
+        return model.ma_model if isinstance(model, EmaModel) else model
+
+    def get_denoised(self, model, xt, t, cond=None, x_self_cond=None, dx=None, w=None):
+        """models/ddim.py:915-947 at one noise level: VP preconditioning around the DDPM network."""
+        if cond is not None or x_self_cond is not None or dx is not None:
+            raise NotImplementedError("cond / x_self_cond / dx are outside the built path")
+        net = self._net(model)
+        t = torch.as_tensor(t).reshape(-1)
+        if t.numel() != 1:
+            raise NotImplementedError("one noise level for the whole batch (what sample_edm evaluates)")
+        sigma = t.to(torch.float32)
+        c_noise = self.num_timesteps - 1 - self.round_sigma(sigma.reshape(1, 1, 1, 1), return_index=True).to(torch.float32)
+        with torch.no_grad():
+            return net.plan.denoise(net.packed_weights(), xt.to(torch.float32).contiguous(), float(sigma), float(c_noise),
+                                    ws=net._ws, want_F=True)
+
+    # ---- sampling -----------------------------------------------------------------------------------------------
+    def sample_edm(self, h, u, sparams, return_last=True, guide_dx=False):
+        """models/ddim.py:959-1051.  h, u: 'b h w c' normalised fields; returns [b, t, h, w, c] float64.
+        The known region is rows < n_time_h of h and rows < n_time_u of u; every step runs n_repeat Heun updates with the
+        known region re-noised to the current level in between (RePaint)."""
+        if guide_dx:
+            raise NotImplementedError("guide_dx=True (PDE guidance) is outside the built path")
+        if self.edm_steps is None:
+            self.set_test_sampler_params(sparams)
+        net = self._net(self.ema_model if self.ema_model is not None else self.model)
+        hu = _nchw(torch.cat([h, u], dim=-1)).float()
+        rd, keep = _lib.repaint_desc(sparams, self.edm_steps, self._alphas_ext(), self.h_ch, self.u_ch)
+        hu_noise = torch.randn_like(hu)
+        N, R = rd.timesteps, rd.n_repeat
+        t = _lib.repaint_schedule(rd)
+        # the reference draws a per-step tensor every step; it only matters where round_sigma(t_cur + gamma t_cur) > t_cur
+        churn = float(sparams.S_churn) > 0
+        step_noise = torch.randn((N,) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if churn else None
+        repeat_noise = torch.randn((N, R - 1) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if R > 1 else None
+        with torch.no_grad():
+            return net.plan.repaint_sample(net.packed_weights(), rd, hu, hu_noise, step_noise, repeat_noise,
+                                           return_last=return_last, ws=self._sample_ws)
+
+    def sample(self, *a, **k):
+        raise NotImplementedError("the DDIM sampler (models/ddim.py:706-806) is not built; use sample_edm")
+
+    def sample_with_repeat(self, *a, **k):
+        raise NotImplementedError("the DDIM RePaint sampler (models/ddim.py:808-913) is not built; use sample_edm")
+
+    def training_step(self, *a, **k):
+        raise NotImplementedError("DDPM (epsilon-prediction) training is not built: SURVEY.md section 8 f1 covers EDM sampling "
+                                  "of a trained DDPM checkpoint")

@@ -24,6 +24,9 @@ EXPORTS = [
     "mcedm_edm_denoise_backward", "mcedm_edm_denoise_backward_bucketed", "mcedm_unet_grad_buckets", "mcedm_sqnorm",
     "mcedm_adam_ema_step",
     "mcedm_swe_fv_step", "mcedm_swe_fv_residual", "mcedm_darcy_residual",
+    "mcedm_ddpm_plan_create", "mcedm_ddpm_plan_destroy", "mcedm_ddpm_param_count", "mcedm_ddpm_param_info",
+    "mcedm_ddpm_packed_bytes", "mcedm_ddpm_pack_weights", "mcedm_ddpm_workspace_bytes", "mcedm_ddpm_forward",
+    "mcedm_ddpm_denoise", "mcedm_repaint_schedule", "mcedm_repaint_workspace_bytes", "mcedm_repaint_sample",
 ]
 
 
@@ -39,6 +42,21 @@ class SamplerDesc(C.Structure):
                 ("S_churn", C.c_double), ("S_min", C.c_double), ("S_max", C.c_double), ("S_noise", C.c_double),
                 ("w", C.c_double), ("sigma_data", C.c_double), ("net_sigma_min", C.c_double),
                 ("net_sigma_max", C.c_double)]
+
+
+class DdpmDesc(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("ch", C.c_int32), ("n_levels", C.c_int32),
+                ("ch_mult", C.c_int32 * MAX_LEVELS), ("num_res_blocks", C.c_int32), ("resolution", C.c_int32),
+                ("n_attn_resolutions", C.c_int32), ("attn_resolutions", C.c_int32 * MAX_LEVELS), ("self_cond", C.c_int32),
+                ("eps", C.c_float)]
+
+
+class RepaintDesc(C.Structure):
+    _fields_ = [("timesteps", C.c_int32), ("sigma_min", C.c_double), ("sigma_max", C.c_double), ("rho", C.c_double),
+                ("S_churn", C.c_double), ("S_min", C.c_double), ("S_max", C.c_double), ("S_noise", C.c_double),
+                ("w", C.c_double), ("n_repeat", C.c_int32), ("n_time_h", C.c_int32), ("n_time_u", C.c_int32),
+                ("h_ch", C.c_int32), ("u_ch", C.c_int32), ("num_diffusion_timesteps", C.c_int32),
+                ("edm_steps", C.POINTER(C.c_float)), ("alphas_cumprod_ext", C.POINTER(C.c_float))]
 
 
 _lib = None
@@ -88,9 +106,23 @@ def load() -> C.CDLL:
     lib.mcedm_swe_fv_residual.argtypes = [f32p, f32p, f32p, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                           i32, vp]
     lib.mcedm_darcy_residual.argtypes = [f32p, f32p, i32, i32, C.c_float, C.c_float, i32, vp]
+    lib.mcedm_ddpm_plan_create.argtypes = [C.POINTER(DdpmDesc), C.POINTER(vp)]
+    lib.mcedm_ddpm_plan_destroy.argtypes = [vp]
+    lib.mcedm_ddpm_plan_destroy.restype = None
+    lib.mcedm_ddpm_param_count.argtypes = [vp]
+    lib.mcedm_ddpm_param_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int64 * 4)]
+    lib.mcedm_ddpm_packed_bytes.argtypes = [vp, C.POINTER(sz)]
+    lib.mcedm_ddpm_pack_weights.argtypes = [vp, C.POINTER(vp), f32p, vp, vp]
+    lib.mcedm_ddpm_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]
+    lib.mcedm_ddpm_forward.argtypes = [vp, vp, f32p, C.c_float, f32p, vp, sz, i32, vp]
+    lib.mcedm_ddpm_denoise.argtypes = [vp, vp, f32p, C.c_float, C.c_float, f32p, f32p, vp, sz, i32, vp]
+    lib.mcedm_repaint_schedule.argtypes = [C.POINTER(RepaintDesc), C.POINTER(C.c_double)]
+    lib.mcedm_repaint_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]
+    lib.mcedm_repaint_sample.argtypes = [vp, vp, C.POINTER(RepaintDesc), f32p, f32p, f64p, f64p, f64p, i32, vp, sz, i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)          # AttributeError here == header/library drift
-        if name not in ("mcedm_last_error", "mcedm_unet_plan_destroy"):
+        if name not in ("mcedm_last_error", "mcedm_unet_plan_destroy", "mcedm_ddpm_plan_destroy"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -289,6 +321,135 @@ class Plan:
         return out
 
 
+def repaint_desc(sp, edm_steps: torch.Tensor, alphas_ext: torch.Tensor, h_ch: int, u_ch: int):
+    """C description of PlDdim.sample_edm's parameters (configs/diff_sampler/edm_sampler_inv.yaml) + the schedule tables
+    (host fp32 tensors: get_edm_steps(), cumprod(1 - cat(0, betas))).  Returns (desc, keepalive)."""
+    es = edm_steps.detach().to("cpu", torch.float32).contiguous()
+    ae = alphas_ext.detach().to("cpu", torch.float32).contiguous()
+    if ae.numel() != es.numel() + 1:
+        raise RuntimeError("alphas_ext must have one more entry than edm_steps")
+    d = RepaintDesc(int(sp.timesteps), float(sp.sigma_min), float(sp.sigma_max), float(sp.rho), float(sp.S_churn),
+                    float(sp.S_min), float(sp.S_max), float(sp.S_noise), float(sp.w), int(sp.n_repeat), int(sp.n_time_h),
+                    int(sp.n_time_u), int(h_ch), int(u_ch), int(es.numel()),
+                    C.cast(es.data_ptr(), C.POINTER(C.c_float)), C.cast(ae.data_ptr(), C.POINTER(C.c_float)))
+    return d, (es, ae)
+
+
+def repaint_schedule(rd: RepaintDesc) -> List[float]:
+    arr = (C.c_double * (rd.timesteps + 1))()
+    check(load().mcedm_repaint_schedule(C.byref(rd), arr), "repaint_schedule")
+    return list(arr)
+
+
+class DdpmPlan:
+    """Host-side handle of one DDPM U-Net (models/ddim_blocks.py Model; mcedm_ddpm_plan_create)."""
+
+    def __init__(self, in_channels: int, out_channels: int, ch: int, ch_mult: Sequence[int], num_res_blocks: int,
+                 attn_resolutions: Sequence[int], resolution: int, self_cond: bool = True, eps: float = 1e-6):
+        lib = load()
+        if len(ch_mult) > MAX_LEVELS or len(attn_resolutions) > MAX_LEVELS:
+            raise RuntimeError("too many levels / attention resolutions")
+        d = DdpmDesc()
+        d.in_channels, d.out_channels, d.ch, d.n_levels = in_channels, out_channels, ch, len(ch_mult)
+        for i, m in enumerate(ch_mult):
+            d.ch_mult[i] = int(m)
+        d.num_res_blocks, d.resolution, d.n_attn_resolutions = num_res_blocks, resolution, len(attn_resolutions)
+        for i, r in enumerate(attn_resolutions):
+            d.attn_resolutions[i] = int(r)
+        d.self_cond, d.eps = int(bool(self_cond)), eps
+        self.desc = d
+        h = C.c_void_p()
+        check(lib.mcedm_ddpm_plan_create(C.byref(d), C.byref(h)), "ddpm_plan_create")
+        self._h, self._lib = h, lib
+        self.param_names: List[str] = []
+        self.param_shapes: List[tuple] = []
+        for i in range(lib.mcedm_ddpm_param_count(h)):
+            name, numel, ndim, shape = C.c_char_p(), C.c_int64(), C.c_int32(), (C.c_int64 * 4)()
+            check(lib.mcedm_ddpm_param_info(h, i, C.byref(name), C.byref(numel), C.byref(ndim), C.byref(shape)))
+            self.param_names.append(name.value.decode())
+            self.param_shapes.append(tuple(shape[j] for j in range(ndim.value)))
+        sz = C.c_size_t()
+        check(lib.mcedm_ddpm_packed_bytes(h, C.byref(sz)))
+        self.packed_bytes = sz.value
+        self.in_channels, self.out_channels, self.resolution, self.ch = in_channels, out_channels, resolution, ch
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mcedm_ddpm_plan_destroy(h)
+
+    def pack(self, params: Dict[str, torch.Tensor], temb_freqs: torch.Tensor, packed: Optional[torch.Tensor] = None):
+        """params keyed like Model.state_dict(); temb_freqs [ch/2] device fp32, built by the caller exactly as
+        get_timestep_embedding does (models/ddim_blocks.py:22-24)."""
+        tens = []
+        for name, shape in zip(self.param_names, self.param_shapes):
+            t = params[name]
+            if tuple(t.shape) != shape:
+                raise RuntimeError(f"parameter {name}: shape {tuple(t.shape)} != {shape}")
+            tens.append(t.detach())
+        if temb_freqs.numel() != self.ch // 2:
+            raise RuntimeError("temb_freqs must have ch / 2 entries")
+        if packed is None:
+            packed = torch.empty(self.packed_bytes, dtype=torch.uint8, device=tens[0].device)
+        arr = (C.c_void_p * len(tens))(*[_ptr(t) for t in tens])
+        check(self._lib.mcedm_ddpm_pack_weights(self._h, arr, _ptr(temb_freqs), packed.data_ptr(), _stream()), "ddpm_pack_weights")
+        return packed
+
+    def workspace_bytes(self, B: int) -> int:
+        sz = C.c_size_t()
+        check(self._lib.mcedm_ddpm_workspace_bytes(self._h, B, C.byref(sz)), "ddpm_workspace_bytes")
+        return sz.value
+
+    def repaint_workspace_bytes(self, B: int) -> int:
+        sz = C.c_size_t()
+        check(self._lib.mcedm_repaint_workspace_bytes(self._h, B, C.byref(sz)), "repaint_workspace_bytes")
+        return sz.value
+
+    def _check_x(self, x):
+        if tuple(x.shape[1:]) != (self.in_channels, self.resolution, self.resolution):
+            raise RuntimeError(f"input {tuple(x.shape)} != [B, {self.in_channels}, {self.resolution}, {self.resolution}] "
+                               "(the network asserts input size == resolution, ddim_blocks.py:411)")
+
+    def forward(self, packed, x, t: float, ws: Optional[Workspace] = None) -> torch.Tensor:
+        self._check_x(x)
+        B = x.shape[0]
+        ws = ws or Workspace()
+        buf = ws.get(self.workspace_bytes(B), x.device)
+        out = torch.empty((B, self.out_channels, self.resolution, self.resolution), dtype=torch.float32, device=x.device)
+        check(self._lib.mcedm_ddpm_forward(self._h, packed.data_ptr(), _ptr(x), float(t), _ptr(out), buf.data_ptr(),
+                                           buf.numel(), B, _stream()), "ddpm_forward")
+        return out
+
+    def denoise(self, packed, x, sigma: float, c_noise: float, ws: Optional[Workspace] = None, want_F: bool = False):
+        self._check_x(x)
+        B = x.shape[0]
+        ws = ws or Workspace()
+        buf = ws.get(self.workspace_bytes(B), x.device)
+        D = torch.empty((B, self.out_channels, self.resolution, self.resolution), dtype=torch.float32, device=x.device)
+        F = torch.empty_like(D) if want_F else None
+        check(self._lib.mcedm_ddpm_denoise(self._h, packed.data_ptr(), _ptr(x), float(sigma), float(c_noise), _ptr(D), _ptr(F),
+                                           buf.data_ptr(), buf.numel(), B, _stream()), "ddpm_denoise")
+        return (D, F) if want_F else D
+
+    def repaint_sample(self, packed, rd: RepaintDesc, hu, init_noise, step_noise=None, repeat_noise=None,
+                       return_last: bool = True, ws: Optional[Workspace] = None, out: Optional[torch.Tensor] = None):
+        self._check_x(hu)
+        B = hu.shape[0]
+        ws = ws or Workspace()
+        buf = ws.get(self.repaint_workspace_bytes(B), hu.device)
+        T = 1 if return_last else rd.timesteps + 1
+        shape = (B, T, self.resolution, self.resolution, self.in_channels)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float64, device=hu.device)
+        elif tuple(out.shape) != shape:
+            raise RuntimeError(f"repaint_sample: out has shape {tuple(out.shape)}, expected {shape}")
+        check(self._lib.mcedm_repaint_sample(self._h, packed.data_ptr(), C.byref(rd), _ptr(hu), _ptr(init_noise),
+                                             _ptr(step_noise, torch.float64), _ptr(repeat_noise, torch.float64),
+                                             _ptr(out, torch.float64), int(return_last), buf.data_ptr(), buf.numel(), B,
+                                             _stream()), "repaint_sample")
+        return out
+
+
 class GraphedSampler:
     """The whole Heun sampling call (every U-Net evaluation and state update of mcedm_heun_sample: ~4000 launches at
     18 steps) captured ONCE into a HIP graph and replayed.  The library never allocates or synchronises and the sigma
@@ -458,7 +619,7 @@ def set_conv8(enable: int = -1) -> None:
     check(lib.mcedm_op_set_conv8(int(enable)), "set_conv8")
 
 
-RS_NONE, RS_UP, RS_DOWN = 0, 1, 2
+RS_NONE, RS_UP, RS_DOWN, RS_S2 = 0, 1, 2, 3
 
 
 def op_pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], qkv_heads: int = 0, dgrad: bool = False):
@@ -491,7 +652,7 @@ def op_conv(xa, xb, wpk, bias_pk, Cout, k, coef=None, coef_batch=1, act=0, resam
     lib = _bind_ops()
     B, Ca, Hs, Ws = xa.shape
     Cb = xb.shape[1] if xb is not None else 0
-    H, W = (Hs * 2, Ws * 2) if resample == RS_UP else ((Hs // 2, Ws // 2) if resample == RS_DOWN else (Hs, Ws))
+    H, W = (Hs * 2, Ws * 2) if resample == RS_UP else ((Hs // 2, Ws // 2) if resample in (RS_DOWN, RS_S2) else (Hs, Ws))
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xa.device)
     check(lib.mcedm_op_conv(_ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, resample, Hs, Ws, H, W, _ptr(wpk),

@@ -1,0 +1,326 @@
+"""CPU oracle for the RePaint-style EDM sampler on the DDPM U-Net.  TEST INFRASTRUCTURE ONLY.
+
+Plain-PyTorch restatement of
+  * the DDPM U-Net ``Model``            models/ddim_blocks.py:222-470 (ResnetBlock :107-164, AttnBlock :167-219,
+                                          Downsample :85-104, Upsample :66-82, get_timestep_embedding :12-30)
+  * ``PlDdim.get_denoised``             models/ddim.py:915-947   (VP preconditioning: c_skip 1, c_out -sigma)
+  * ``PlDdim.round_sigma``              models/ddim.py:949-957,  ``compute_alpha`` :700-704, ``get_edm_steps`` :131-137
+  * ``PlDdim.sample_edm``               models/ddim.py:959-1051  (inner ``n_repeat`` loop, known-region re-noising)
+for the configuration of configs/model/ddim_res32.yaml (type simple, self_cond True, cond_channels 0, dx_cond False,
+dropout 0, resamp_with_conv True).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+Pinned by tests/golden/ddpm.npz, which oracle/make_golden_ddpm.py writes by running the reference itself.
+Parameters are a flat dict keyed exactly like ``Model.state_dict()``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class DdpmConfig:
+    """Subset of hparams.model / hparams.diffusion the path reads (configs/model/ddim_res32.yaml:4-40)."""
+    in_channels: int = 2
+    out_ch: int = 2
+    ch: int = 64
+    ch_mult: Tuple[int, ...] = (1, 1, 1)
+    num_res_blocks: int = 1
+    attn_resolutions: Tuple[int, ...] = (32,)
+    resolution: int = 128
+    self_cond: bool = True
+    num_timesteps: int = 1000
+    beta_start: float = 1e-4
+    beta_end: float = 0.02
+
+
+# --------------------------------------------------------------------------- #
+# parameter table (registration order of Model.__init__, ddim_blocks.py:252-362)
+# --------------------------------------------------------------------------- #
+def _res_shapes(k, cin, cout, temb):
+    o = [(f"{k}.norm1.weight", (cin,)), (f"{k}.norm1.bias", (cin,)),
+         (f"{k}.conv1.weight", (cout, cin, 3, 3)), (f"{k}.conv1.bias", (cout,)),
+         (f"{k}.temb_proj.weight", (cout, temb)), (f"{k}.temb_proj.bias", (cout,)),
+         (f"{k}.norm2.weight", (cout,)), (f"{k}.norm2.bias", (cout,)),
+         (f"{k}.conv2.weight", (cout, cout, 3, 3)), (f"{k}.conv2.bias", (cout,))]
+    if cin != cout:
+        o += [(f"{k}.nin_shortcut.weight", (cout, cin, 1, 1)), (f"{k}.nin_shortcut.bias", (cout,))]
+    return o
+
+
+def _attn_shapes(k, c):
+    o = [(f"{k}.norm.weight", (c,)), (f"{k}.norm.bias", (c,))]
+    for n in ("q", "k", "v", "proj_out"):
+        o += [(f"{k}.{n}.weight", (c, c, 1, 1)), (f"{k}.{n}.bias", (c,))]
+    return o
+
+
+def param_shapes(cfg: DdpmConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    ch, temb = cfg.ch, 4 * cfg.ch
+    nres = len(cfg.ch_mult)
+    in_total = cfg.in_channels * (2 if cfg.self_cond else 1)
+    out = [("temb.dense.0.weight", (temb, ch)), ("temb.dense.0.bias", (temb,)),
+           ("temb.dense.1.weight", (temb, temb)), ("temb.dense.1.bias", (temb,)),
+           ("conv_in.weight", (ch, in_total, 3, 3)), ("conv_in.bias", (ch,))]
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    res = cfg.resolution
+    block_in = ch
+    for lv in range(nres):
+        block_in, block_out = ch * in_mult[lv], ch * cfg.ch_mult[lv]
+        blocks, attns = [], []
+        for j in range(cfg.num_res_blocks):
+            blocks += _res_shapes(f"down.{lv}.block.{j}", block_in, block_out, temb)
+            block_in = block_out
+            if res in cfg.attn_resolutions:
+                attns += _attn_shapes(f"down.{lv}.attn.{j}", block_in)
+        out += blocks + attns
+        if lv != nres - 1:
+            out += [(f"down.{lv}.downsample.conv.weight", (block_in, block_in, 3, 3)), (f"down.{lv}.downsample.conv.bias", (block_in,))]
+            res //= 2
+    out += _res_shapes("mid.block_1", block_in, block_in, temb) + _attn_shapes("mid.attn_1", block_in) + \
+        _res_shapes("mid.block_2", block_in, block_in, temb)
+    ups = {}
+    for lv in reversed(range(nres)):
+        block_out = ch * cfg.ch_mult[lv]
+        skip_in = ch * cfg.ch_mult[lv]
+        blocks, attns = [], []
+        for j in range(cfg.num_res_blocks + 1):
+            if j == cfg.num_res_blocks:
+                skip_in = ch * in_mult[lv]
+            blocks += _res_shapes(f"up.{lv}.block.{j}", block_in + skip_in, block_out, temb)
+            block_in = block_out
+            if res in cfg.attn_resolutions:
+                attns += _attn_shapes(f"up.{lv}.attn.{j}", block_in)
+        lvl = blocks + attns
+        if lv != 0:
+            lvl += [(f"up.{lv}.upsample.conv.weight", (block_in, block_in, 3, 3)), (f"up.{lv}.upsample.conv.bias", (block_in,))]
+            res *= 2
+        ups[lv] = lvl
+    for lv in range(nres):                         # `self.up.insert(0, up)`: state_dict lists up.0 first
+        out += ups[lv]
+    out += [("norm_out.weight", (block_in,)), ("norm_out.bias", (block_in,)),
+            ("conv_out.weight", (cfg.out_ch, block_in, 3, 3)), ("conv_out.bias", (cfg.out_ch,))]
+    return out
+
+
+def fill_param(name: str, shape: Sequence[int], u: np.ndarray) -> np.ndarray:
+    """U(-1,1) draw -> test parameter: conv / linear weights / sqrt(fan_in), GroupNorm gains 1 + 0.2u, the rest 0.1u."""
+    if name.endswith(".weight") and len(shape) >= 2:
+        return u / math.sqrt(int(np.prod(shape[1:])))
+    if ".norm" in name or name.startswith("norm_out"):
+        return (1.0 + 0.2 * u) if name.endswith(".weight") else 0.1 * u
+    return 0.1 * u
+
+
+def make_params(cfg: DdpmConfig, seed: int = 0) -> Dict[str, Tensor]:
+    rng = np.random.default_rng(seed)
+    P = {}
+    for name, shape in param_shapes(cfg):
+        u = rng.random(size=shape, dtype=np.float64) * 2.0 - 1.0
+        P[name] = torch.from_numpy(fill_param(name, shape, u).astype(np.float32))
+    return P
+
+
+# --------------------------------------------------------------------------- #
+# network
+# --------------------------------------------------------------------------- #
+def timestep_freqs(ch: int) -> Tensor:
+    """ddim_blocks.py:22-24: exp(arange(half) * -(ln 10000 / (half - 1))) in fp32."""
+    half = ch // 2
+    emb = math.log(10000) / (half - 1)
+    return torch.exp(torch.arange(half, dtype=torch.float32) * -emb)
+
+
+def timestep_embedding(t: Tensor, ch: int) -> Tensor:
+    """get_timestep_embedding, ddim_blocks.py:12-30: [sin | cos] (sin FIRST)."""
+    e = t.float()[:, None] * timestep_freqs(ch)[None, :]
+    return torch.cat([torch.sin(e), torch.cos(e)], dim=1)
+
+
+def _swish(x):
+    """nonlinearity, ddim_blocks.py:33-35 (x * sigmoid(x); F.silu differs in the last bit)."""
+    return x * torch.sigmoid(x)
+
+
+def _norm(x, P, k):
+    return F.group_norm(x, 32, P[f"{k}.weight"], P[f"{k}.bias"], eps=1e-6)          # Normalize, ddim_blocks.py:62-63
+
+
+def resnet_block(P, k, x, temb):
+    """ddim_blocks.py:144-164 (dropout 0)."""
+    h = F.conv2d(_swish(_norm(x, P, f"{k}.norm1")), P[f"{k}.conv1.weight"], P[f"{k}.conv1.bias"], padding=1)
+    h = h + F.linear(_swish(temb), P[f"{k}.temb_proj.weight"], P[f"{k}.temb_proj.bias"])[:, :, None, None]
+    h = F.conv2d(_swish(_norm(h, P, f"{k}.norm2")), P[f"{k}.conv2.weight"], P[f"{k}.conv2.bias"], padding=1)
+    if f"{k}.nin_shortcut.weight" in P:
+        x = F.conv2d(x, P[f"{k}.nin_shortcut.weight"], P[f"{k}.nin_shortcut.bias"])
+    return x + h
+
+
+def attn_block(P, k, x):
+    """ddim_blocks.py:194-219: single head over all C channels, scale C^-0.5."""
+    h_ = _norm(x, P, f"{k}.norm")
+    q = F.conv2d(h_, P[f"{k}.q.weight"], P[f"{k}.q.bias"])
+    kk = F.conv2d(h_, P[f"{k}.k.weight"], P[f"{k}.k.bias"])
+    v = F.conv2d(h_, P[f"{k}.v.weight"], P[f"{k}.v.bias"])
+    b, c, hh, ww = q.shape
+    w_ = torch.bmm(q.reshape(b, c, hh * ww).permute(0, 2, 1), kk.reshape(b, c, hh * ww)) * (int(c) ** (-0.5))
+    w_ = F.softmax(w_, dim=2)
+    h_ = torch.bmm(v.reshape(b, c, hh * ww), w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + F.conv2d(h_, P[f"{k}.proj_out.weight"], P[f"{k}.proj_out.bias"])
+
+
+def downsample(P, k, x):
+    """ddim_blocks.py:97-101: pad (0,1,0,1) then 3x3 stride 2."""
+    return F.conv2d(F.pad(x, (0, 1, 0, 1)), P[f"{k}.conv.weight"], P[f"{k}.conv.bias"], stride=2)
+
+
+def upsample(P, k, x):
+    """ddim_blocks.py:77-82: nearest 2x then 3x3."""
+    return F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), P[f"{k}.conv.weight"], P[f"{k}.conv.bias"], padding=1)
+
+
+def model_forward(P, cfg: DdpmConfig, x: Tensor, t: Tensor, x_self_cond: Optional[Tensor] = None) -> Tensor:
+    """Model.forward, ddim_blocks.py:410-470 with cond None, dx None."""
+    assert x.shape[2] == x.shape[3] == cfg.resolution
+    temb = timestep_embedding(t, cfg.ch)
+    temb = F.linear(_swish(F.linear(temb, P["temb.dense.0.weight"], P["temb.dense.0.bias"])),
+                    P["temb.dense.1.weight"], P["temb.dense.1.bias"])
+    if cfg.self_cond:
+        x = torch.cat((torch.zeros_like(x) if x_self_cond is None else x_self_cond, x), dim=1)
+    nres = len(cfg.ch_mult)
+    hs = [F.conv2d(x, P["conv_in.weight"], P["conv_in.bias"], padding=1)]
+    for lv in range(nres):
+        for j in range(cfg.num_res_blocks):
+            h = resnet_block(P, f"down.{lv}.block.{j}", hs[-1], temb)
+            if f"down.{lv}.attn.{j}.norm.weight" in P:
+                h = attn_block(P, f"down.{lv}.attn.{j}", h)
+            hs.append(h)
+        if lv != nres - 1:
+            hs.append(downsample(P, f"down.{lv}.downsample", hs[-1]))
+    h = hs[-1]
+    h = resnet_block(P, "mid.block_1", h, temb)
+    h = attn_block(P, "mid.attn_1", h)
+    h = resnet_block(P, "mid.block_2", h, temb)
+    for lv in reversed(range(nres)):
+        for j in range(cfg.num_res_blocks + 1):
+            h = resnet_block(P, f"up.{lv}.block.{j}", torch.cat([h, hs.pop()], dim=1), temb)
+            if f"up.{lv}.attn.{j}.norm.weight" in P:
+                h = attn_block(P, f"up.{lv}.attn.{j}", h)
+        if lv != 0:
+            h = upsample(P, f"up.{lv}.upsample", h)
+    return F.conv2d(_swish(_norm(h, P, "norm_out")), P["conv_out.weight"], P["conv_out.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------- #
+# diffusion schedule, VP preconditioning, RePaint-style Heun sampler (models/ddim.py)
+# --------------------------------------------------------------------------- #
+def betas_of(cfg: DdpmConfig) -> Tensor:
+    """get_beta_schedule('linear'), ddim_blocks.py:487-490: float64 linspace -> float32."""
+    return torch.from_numpy(np.linspace(cfg.beta_start, cfg.beta_end, cfg.num_timesteps, dtype=np.float64)).float()
+
+
+def edm_steps_of(betas: Tensor) -> Tensor:
+    """get_edm_steps, ddim.py:131-137: sigma_t = sqrt((1 - abar_t) / abar_t), largest first."""
+    ab = (1.0 - betas).cumprod(dim=0)
+    return ((1 - ab) / ab).sqrt().flip(dims=(0,))
+
+
+def alphas_ext_of(betas: Tensor) -> Tensor:
+    """the table compute_alpha indexes with t + 1 (ddim.py:700-704)."""
+    return (1 - torch.cat([torch.zeros(1), betas], dim=0)).cumprod(dim=0)
+
+
+def round_sigma(steps: Tensor, sigma: Tensor, return_index: bool = False) -> Tensor:
+    """ddim.py:949-957."""
+    s32 = sigma.to(torch.float32)
+    index = torch.cdist(s32.reshape(1, -1, 1), steps.reshape(1, -1, 1)).argmin(2)
+    result = index if return_index else steps[index.flatten()]
+    return result.type_as(sigma).reshape(sigma.shape)
+
+
+def get_denoised(P, cfg: DdpmConfig, steps: Tensor, xt: Tensor, t: Tensor):
+    """PlDdim.get_denoised, ddim.py:915-947 with cond None, x_self_cond None, dx None."""
+    xt = xt.to(torch.float32)
+    sigma = t.to(torch.float32).reshape(-1, 1, 1, 1)
+    c_out = -sigma
+    c_in = 1 / (sigma ** 2 + 1).sqrt()
+    c_noise = cfg.num_timesteps - 1 - round_sigma(steps, sigma, return_index=True).to(torch.float32)
+    F_x = model_forward(P, cfg, c_in * xt, c_noise.flatten())
+    return 1 * xt + c_out * F_x, F_x
+
+
+@dataclass
+class RepaintParams:
+    """configs/diff_sampler/edm_sampler_inv.yaml (fields PlDdim.sample_edm reads)."""
+    timesteps: int = 18
+    sigma_min: float = 0.002
+    sigma_max: float = 80.0
+    rho: float = 7.0
+    S_churn: float = 0.0
+    S_min: float = 0.0
+    S_max: float = float("inf")
+    S_noise: float = 1.0
+    n_repeat: int = 2
+    n_time_h: int = 0
+    n_time_u: int = 64
+    w: float = 0.0
+
+
+def sample_edm_repaint(P, cfg: DdpmConfig, hu: Tensor, sp: RepaintParams, init_noise: Tensor,
+                       step_noise: Sequence[Tensor], repeat_noise: Sequence[Sequence[Tensor]], h_ch: int = 1,
+                       u_ch: int = 1, return_last: bool = True) -> Tensor:
+    """PlDdim.sample_edm, ddim.py:959-1051, guide_dx False.  ``hu`` [B, C, H, W] is the normalised joint state (the
+    reference builds it from h, u in 'b h w c'); hu_mask = 1 marks KNOWN entries (rows < n_time_* of each field).
+    ``init_noise`` replaces randn_like(hu) (:969), ``step_noise[i]`` the per-step draw (:1004) and
+    ``repeat_noise[i][k]`` the re-noising draw between inner repeats (:1037).  Returns [B, T, H, W, C] float64."""
+    betas = betas_of(cfg)
+    steps = edm_steps_of(betas)
+    aext = alphas_ext_of(betas)
+    N = sp.timesteps
+    hu_noise = init_noise
+    mask = torch.ones_like(hu)
+    mask[:, 0:h_ch, sp.n_time_h:, :] = 0.0
+    mask[:, h_ch:h_ch + u_ch, sp.n_time_u:, :] = 0.0
+    sigma_min = max(sp.sigma_min, float(steps[cfg.num_timesteps - 1]))
+    sigma_max = min(sp.sigma_max, float(steps[0]))
+    idx = torch.arange(N, dtype=torch.float64)
+    t_steps = (sigma_max ** (1 / sp.rho) + idx / (N - 1) * (sigma_min ** (1 / sp.rho) - sigma_max ** (1 / sp.rho))) ** sp.rho
+    t_steps = torch.cat([round_sigma(steps, t_steps), torch.zeros_like(t_steps[:1])])
+
+    def alpha(t):
+        return aext.index_select(0, t.long().reshape(1) + 1).view(-1, 1, 1, 1)
+
+    aT = alpha(t_steps[0])
+    x = (hu * aT.sqrt() + hu_noise * (1.0 - aT).sqrt()) * mask + hu_noise * (1.0 - mask)
+    x_next = x.to(torch.float64) * t_steps[0]
+    xs = [x_next]
+    for i in range(N):
+        t_cur, t_next = t_steps[i], t_steps[i + 1]
+        x_cur = x_next
+        gamma = min(sp.S_churn / N, math.sqrt(2) - 1) if sp.S_min <= float(t_cur) <= float(sp.S_max) else 0
+        t_hat = round_sigma(steps, t_cur + gamma * t_cur)
+        x_hat = x_cur + (t_hat ** 2 - t_cur ** 2).sqrt() * sp.S_noise * step_noise[i]
+        for k in range(sp.n_repeat):
+            denoised = get_denoised(P, cfg, steps, x_hat, t_hat)[0].to(torch.float64)
+            d_cur = (x_hat - denoised) / t_hat
+            x_next = x_hat + (t_next - t_hat) * d_cur
+            if i < N - 1:
+                denoised = get_denoised(P, cfg, steps, x_next, t_next)[0].to(torch.float64)
+                d_prime = (x_next - denoised) / t_next
+                x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
+            at = alpha(t_next)
+            known = at.sqrt() * hu + (1 - at).sqrt() * hu_noise
+            x_next = known * mask + x_next * (1.0 - mask)
+            if k < sp.n_repeat - 1:
+                t_hat = round_sigma(steps, t_next + (math.sqrt(2) - 1) * t_next)
+                x_hat = x_next + (t_hat ** 2 - t_next ** 2).sqrt() * sp.S_noise * repeat_noise[i][k]
+        if i == N - 1:
+            x_next = hu * mask + x_next * (1.0 - mask)
+        xs = [x_next] if return_last else xs + [x_next]
+    return torch.stack(xs, dim=0).permute(1, 0, 3, 4, 2).contiguous()

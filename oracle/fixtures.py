@@ -221,3 +221,28 @@ def step_inputs(tag: str):
 
 
 CFG_SAMPLER_W = 0.5       # classifier-free guidance weight of the 'cfg_u' sampler case (mcedm.py:453-458)
+
+
+# ---- RePaint-style EDM sampling on the DDPM U-Net (PlDdim, configs/model/ddim_res32.yaml) --------
+from . import ddpm_oracle as dorc  # noqa: E402
+
+# the reference asserts input size == hparams.model.resolution (ddim_blocks.py:411): tests run the res-32 variant of
+# ddim_res32.yaml (levels 32 / 16 / 8, attention at 8^2 = 64 tokens and in the middle block)
+CFG_D = dorc.DdpmConfig(resolution=32, attn_resolutions=(8,))
+DDPM_T = torch.tensor([937.0])                     # a late timestep: large sin/cos arguments in the embedding
+DDPM_SIGMAS = (0.0123, 0.9, 78.5)
+# tag -> (timesteps, n_repeat, S_churn, n_time_h, n_time_u)
+REPAINT_CASES = {"det_r2": (6, 2, 0.0, 0, 16), "churn_r3": (5, 3, 15.0, 8, 0)}
+REPAINT_B = 2
+
+
+def repaint_inputs(tag: str):
+    """h, u in the reference's 'b h w c' layout, initial noise (NCHW), per-step and per-repeat noise (fp32-representable)."""
+    N, R, _, _, _ = REPAINT_CASES[tag]
+    B, S = REPAINT_B, CFG_D.resolution
+    h = randn(f"repaint/{tag}/h", B, S, S, 1)
+    u = randn(f"repaint/{tag}/u", B, S, S, 1)
+    init = randn(f"repaint/{tag}/init", B, 2, S, S)
+    steps = [randn(f"repaint/{tag}/step{i}", B, 2, S, S).double() for i in range(N)]
+    reps = [[randn(f"repaint/{tag}/rep{i}_{k}", B, 2, S, S).double() for k in range(R - 1)] for i in range(N)]
+    return h, u, init, steps, reps

@@ -78,3 +78,30 @@ def test_host_side_argument_validation():
         L.edm_t_steps(sd)
     with pytest.raises(RuntimeError, match="CPU tensor"):
         plan.forward(torch.zeros(8), torch.zeros(1, 2, 32, 32), torch.zeros(1))
+
+
+def test_repaint_schedule_and_ddpm_plan_host_side():
+    """f1 host pieces: the DDPM parameter table in Model.state_dict() order and the rounded sigma schedule
+    (round_sigma of models/ddim.py:949-957 restated as an exact nearest-neighbour search) against the oracle's torch.cdist."""
+    from oracle import ddpm_oracle as dorc
+    from oracle import fixtures as fx
+    cfg = dorc.DdpmConfig()                      # configs/model/ddim_res32.yaml: resolution 128, attention at 32
+    plan = L.DdpmPlan(cfg.in_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks, cfg.attn_resolutions, cfg.resolution)
+    ref = dorc.param_shapes(cfg)
+    assert plan.param_names == [n for n, _ in ref] and plan.param_shapes == [tuple(s) for _, s in ref]
+    assert plan.repaint_workspace_bytes(2) > plan.workspace_bytes(2) > 0
+    betas = dorc.betas_of(cfg)
+    steps, aext = dorc.edm_steps_of(betas), dorc.alphas_ext_of(betas)
+    for N, churn in ((18, 0.0), (50, 15.0), (5, 0.0)):
+        sp = dorc.RepaintParams(timesteps=N, S_churn=churn)
+        rd, keep = L.repaint_desc(sp, steps, aext, 1, 1)
+        t = torch.tensor(L.repaint_schedule(rd), dtype=torch.float64)
+        smin, smax = max(sp.sigma_min, float(steps[-1])), min(sp.sigma_max, float(steps[0]))
+        idx = torch.arange(N, dtype=torch.float64)
+        ts = (smax ** (1 / sp.rho) + idx / (N - 1) * (smin ** (1 / sp.rho) - smax ** (1 / sp.rho))) ** sp.rho
+        want = torch.cat([dorc.round_sigma(steps, ts), torch.zeros(1, dtype=torch.float64)])
+        assert torch.equal(t, want), (N, (t - want).abs().max())
+    with pytest.raises(RuntimeError, match="only 64 is built"):
+        L.DdpmPlan(2, 2, 64, (1, 2), 1, (), 32)
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        L.DdpmPlan(2, 2, 48, (1,), 1, (), 32)

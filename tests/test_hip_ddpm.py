@@ -1,0 +1,150 @@
+"""GPU: SURVEY.md section 8 f1 -- the DDPM U-Net (models/ddim_blocks.py Model) and PlDdim's RePaint-style EDM sampler
+(models/ddim.py:915-1051) through the C ABI and through the drop-in classes, against the reference's own outputs
+(tests/golden/ddpm.npz, written by oracle/make_golden_ddpm.py) and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddpm_oracle as dorc
+from oracle import fixtures as fx
+from tests.test_hip_module import wrap
+
+pytestmark = pytest.mark.gpu
+CFG = fx.CFG_D
+
+
+@pytest.fixture(scope="module")
+def net():
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd import lib as L
+    assert torch.cuda.is_available()
+    plan = L.DdpmPlan(CFG.in_channels, CFG.out_ch, CFG.ch, CFG.ch_mult, CFG.num_res_blocks, CFG.attn_resolutions, CFG.resolution)
+    P = dorc.make_params(CFG, 21)
+    assert plan.param_names == [n for n, _ in dorc.param_shapes(CFG)]
+    packed = plan.pack({k: v.cuda() for k, v in P.items()}, dorc.timestep_freqs(CFG.ch).cuda())
+    return L, plan, packed, P
+
+
+def close(got, ref, rtol=1e-4, atol=1e-5, what=""):
+    got, ref = torch.as_tensor(got).detach().cpu(), torch.as_tensor(ref)
+    assert got.shape == ref.shape and got.dtype == ref.dtype, (what, got.shape, ref.shape, got.dtype, ref.dtype)
+    err = float((got.double() - ref.double()).abs().max())
+    torch.testing.assert_close(got, ref, rtol=rtol, atol=atol, msg=lambda m: f"{what} (max|d| {err:.3e}): {m}")
+
+
+def test_model_forward_golden(net, golden):
+    L, plan, packed, P = net
+    g = golden("ddpm.npz")
+    x = fx.randn("ddpm/x", 3, 2, CFG.resolution, CFG.resolution).cuda()
+    close(plan.forward(packed, x, float(fx.DDPM_T)), g["F_t937"], what="Model.forward t=937")
+    close(plan.forward(packed, x, 0.0), g["F_t0"], what="Model.forward t=0")
+    for i, t in enumerate((3.0, 500.0, 999.0)):          # the reference's per-sample timesteps, one call per level
+        close(plan.forward(packed, x, t)[i], g["F_tB"][i], what=f"Model.forward t={t}")
+    with pytest.raises(RuntimeError, match="resolution"):
+        plan.forward(packed, torch.zeros(1, 2, 16, 16, device="cuda"), 1.0)
+
+
+def test_get_denoised_golden(net, golden):
+    L, plan, packed, P = net
+    g = golden("ddpm.npz")
+    x = fx.randn("ddpm/x", 3, 2, CFG.resolution, CFG.resolution)
+    for i, s in enumerate(fx.DDPM_SIGMAS):
+        ref = torch.as_tensor(g[f"D_sigma{i}"])
+        D = plan.denoise(packed, (x * (1 + s)).cuda(), s, float(g[f"cnoise_sigma{i}"][0]))
+        close(D, ref, atol=1e-5 * float(ref.abs().max()), what=f"get_denoised sigma={s}")
+
+
+def repaint_desc(L, tag):
+    N, R, churn, nth, ntu = fx.REPAINT_CASES[tag]
+    sp = dorc.RepaintParams(timesteps=N, n_repeat=R, S_churn=churn, n_time_h=nth, n_time_u=ntu)
+    betas = dorc.betas_of(CFG)
+    return L.repaint_desc(sp, dorc.edm_steps_of(betas), dorc.alphas_ext_of(betas), 1, 1)
+
+
+@pytest.mark.parametrize("tag", list(fx.REPAINT_CASES))
+def test_repaint_sample_golden(net, golden, tag):
+    """mcedm_repaint_sample: n_repeat inner Heun updates per step, known region re-noised in between."""
+    L, plan, packed, P = net
+    g = golden("ddpm.npz")
+    N, R, churn, nth, ntu = fx.REPAINT_CASES[tag]
+    h, u, init, steps, reps = fx.repaint_inputs(tag)
+    hu = torch.cat([h, u], dim=-1).permute(0, 3, 1, 2).contiguous()
+    rd, keep = repaint_desc(L, tag)
+    step_noise = torch.stack(steps).cuda() if churn > 0 else None
+    repeat_noise = torch.stack([torch.stack(r) for r in reps]).cuda()
+    xs = plan.repaint_sample(packed, rd, hu.cuda(), init.cuda(), step_noise, repeat_noise, return_last=False)
+    ref = torch.as_tensor(g[f"{tag}_xs"])
+    scale = float(ref.abs().max())
+    print(f"repaint {tag}: max|d| = {float((xs.cpu() - ref).abs().max()):.3e} on max|x| = {scale:.1f}")
+    close(xs, ref, atol=1e-5 * scale, what=f"repaint {tag}")
+    last = plan.repaint_sample(packed, rd, hu.cuda(), init.cuda(), step_noise, repeat_noise, return_last=True)
+    assert tuple(last.shape) == (fx.REPAINT_B, 1, CFG.resolution, CFG.resolution, 2) and torch.equal(last[:, 0], xs[:, -1])
+    known = torch.ones(fx.REPAINT_B, CFG.resolution, CFG.resolution, 2, dtype=torch.bool)
+    known[:, nth:, :, 0] = False
+    known[:, ntu:, :, 1] = False
+    assert torch.equal(last[:, 0].cpu()[known], torch.cat([h, u], dim=-1).double()[known]), "known entries must be the clean data"
+    if R > 1:
+        with pytest.raises(RuntimeError, match="repeat_noise"):
+            plan.repaint_sample(packed, rd, hu.cuda(), init.cuda(), step_noise, None)
+
+
+def hparams(sampler):
+    return wrap(dict(
+        name="ddim",
+        model=dict(type="simple", in_channels=CFG.in_channels, cond_channels=0, cat_cond=False, out_ch=CFG.out_ch, ch=CFG.ch,
+                   ch_mult=list(CFG.ch_mult), num_res_blocks=CFG.num_res_blocks, attn_resolutions=list(CFG.attn_resolutions),
+                   dropout=0.0, var_type="fixedsmall", ema_rate=0.999, ema=True, resamp_with_conv=True,
+                   resolution=CFG.resolution, self_cond=True, dx_cond=False, cat_dx=False, dx_norm="l2", dx_detach=False),
+        data=dict(normalization="gauss", uniform_dequantization=False, gaussian_dequantization=False, rescaled=False),
+        diffusion=dict(beta_schedule="linear", beta_start=CFG.beta_start, beta_end=CFG.beta_end,
+                       num_diffusion_timesteps=CFG.num_timesteps),
+        optimization=dict(optimizer="Adam", lr=0.0002, weight_decay=0.0, beta1=0.9, amsgrad=False, eps=1e-8),
+        sampler=sampler))
+
+
+def test_plddim_module_golden(golden, monkeypatch):
+    """The drop-in PlDdim: state_dict layout, schedule tables, get_denoised and sample_edm by their reference names."""
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd.ddim import PlDdim
+    g = golden("ddpm.npz")
+    tag = "churn_r3"
+    N, R, churn, nth, ntu = fx.REPAINT_CASES[tag]
+    sp = wrap(dict(name="edm", type="edm", timesteps=N, sigma_min=0.002, sigma_max=80, rho=7, S_churn=churn, S_min=0, S_max="inf",
+                   S_noise=1, n_samples=1, n_repeat=R, n_time_h=nth, n_time_u=ntu, return_last=True, guide_dx=False, w=0.0))
+    m = PlDdim(hparams(sp)).cuda()
+    P = dorc.make_params(CFG, 21)
+    sd = m.state_dict()
+    for n, s in dorc.param_shapes(CFG):
+        assert tuple(sd[f"model.{n}"].shape) == tuple(s) and f"ema_model.ma_model.{n}" in sd
+    assert "betas" in sd and "logvar" in sd
+    with torch.no_grad():
+        for n, p in m.model.named_parameters():
+            p.copy_(P[n])
+        for n, p in m.ema_model.ma_model.named_parameters():
+            p.copy_(P[n])
+    m.set_test_sampler_params(sp)
+    assert torch.equal(m.edm_steps, torch.as_tensor(g["edm_steps"]))
+    assert torch.equal(m.compute_alpha(torch.tensor([0, 80, 999])).flatten(), torch.as_tensor(g["alphas_ext"])[[1, 81, 1000]])
+    x = fx.randn("ddpm/x", 3, 2, CFG.resolution, CFG.resolution)
+    s = fx.DDPM_SIGMAS[1]
+    D, F = m.get_denoised(m.ema_model, (x * (1 + s)).double().cuda(), torch.tensor(s, dtype=torch.float64), w=0.0)
+    ref = torch.as_tensor(g["D_sigma1"])
+    close(D, ref, atol=1e-5 * float(ref.abs().max()), what="PlDdim.get_denoised")
+    h, u, init, steps, reps = fx.repaint_inputs(tag)
+    real_randn = torch.randn
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: init.to(t.device))
+
+    def fake_randn(*a, **k):
+        shape = a[0] if len(a) == 1 and isinstance(a[0], (tuple, list)) else a
+        if k.get("dtype") == torch.float64 and len(shape) == 5:
+            return torch.stack(steps).cuda()
+        if k.get("dtype") == torch.float64 and len(shape) == 6:
+            return torch.stack([torch.stack(r) for r in reps]).cuda()
+        return real_randn(*a, **k)
+    monkeypatch.setattr(torch, "randn", fake_randn)
+    xs = m.sample_edm(h.cuda(), u.cuda(), sp, return_last=False)
+    monkeypatch.undo()
+    ref = torch.as_tensor(g[f"{tag}_xs"])
+    close(xs, ref, atol=1e-5 * float(ref.abs().max()), what="PlDdim.sample_edm")
+    with pytest.raises(NotImplementedError):
+        m.training_step(None, 0)

@@ -133,6 +133,31 @@ def test_conv_fused_vs_oracle(lib, shape):
     close(y, ref, what=tag)
 
 
+@pytest.mark.parametrize("shape", [
+    # (B, Cin, Cout, Hs, Ws, with_transform): 8x32 / 8x16 / 8x8 pixel tiles, channel tile 64 and 32, ragged edges
+    (2, 64, 64, 128, 128, 0), (2, 64, 64, 64, 64, 0), (3, 64, 64, 16, 16, 0), (2, 40, 24, 20, 12, 1), (1, 128, 128, 48, 40, 1),
+    (2, 64, 64, 104, 72, 0),
+])
+def test_conv_stride2_ddpm_downsample(lib, shape):
+    """Downsample of the DDPM U-Net (models/ddim_blocks.py:85-104): pad (0, 1, 0, 1) then 3x3 stride 2, on the 4-phase
+    LDS tile of conv_s2_mfma_kernel; optionally with the fused input transform."""
+    B, Cin, Cout, Hs, Ws, tr = shape
+    tag = "t/s2/" + "_".join(map(str, shape))
+    x = fx.randn(tag + "/x", B, Cin, Hs, Ws)
+    w, b = fx.param(tag, "conv.weight", (Cout, Cin, 3, 3)), fx.param(tag, "conv.bias", (Cout,))
+    coef = None
+    xin = x
+    if tr:
+        coef = torch.stack([fx.randn(tag + "/mean", B, Cin) * 0.3, 1 + 0.3 * fx.randn(tag + "/scale", B, Cin),
+                            0.2 * fx.randn(tag + "/off", B, Cin), torch.zeros(B, Cin)], dim=-1)
+        xin = apply_coef(x, coef, True)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(xin, (0, 1, 0, 1)), w, b, stride=2)
+    wpk, bpk = lib.op_pack_conv(dev(w), dev(b))
+    y = lib.op_conv(dev(x), None, wpk, bpk, Cout, 3, coef=dev(coef) if tr else None, act=tr, resample=lib.RS_S2)
+    assert tuple(y.shape) == tuple(ref.shape)
+    close(y, ref, what=tag)
+
+
 TILES = [(128, 8, 32), (64, 8, 32), (32, 8, 32), (128, 16, 16), (64, 16, 16), (32, 16, 16), (128, 8, 16), (64, 8, 16),
          (128, 8, 8), (64, 8, 8), (32, 8, 8), (128, 16, 32)]
 

@@ -216,3 +216,36 @@ def test_sample_edm_classifier_free(golden):
     scale = float(np.abs(g["cfg_u_xs_last"]).max())
     close(xs[:, -1:], g["cfg_u_xs_last"], rtol=1e-4, atol=1e-5 * scale)
     close(xs[:, ::6], g["cfg_u_xs_traj"], rtol=1e-4, atol=1e-5 * scale)
+
+
+# ---- RePaint-style EDM sampler on the DDPM U-Net (tests/golden/ddpm.npz, oracle/make_golden_ddpm.py) --------------------
+def test_ddpm_forward_and_denoised(golden):
+    from oracle import ddpm_oracle as dorc
+    g = golden("ddpm.npz")
+    cfg = fx.CFG_D
+    P = dorc.make_params(cfg, int(g["seed"]))
+    steps = dorc.edm_steps_of(dorc.betas_of(cfg))
+    assert torch.equal(steps, torch.as_tensor(g["edm_steps"]))
+    assert torch.equal(dorc.alphas_ext_of(dorc.betas_of(cfg)), torch.as_tensor(g["alphas_ext"]))
+    x = fx.randn("ddpm/x", 3, 2, cfg.resolution, cfg.resolution)
+    with torch.no_grad():
+        close(dorc.model_forward(P, cfg, x, fx.DDPM_T), g["F_t937"], rtol=1e-5, atol=1e-6)
+        close(dorc.model_forward(P, cfg, x, torch.tensor([3.0, 500.0, 999.0])), g["F_tB"], rtol=1e-5, atol=1e-6)
+        for i, s in enumerate(fx.DDPM_SIGMAS):
+            D, _ = dorc.get_denoised(P, cfg, steps, (x * (1 + s)).double(), torch.tensor(s, dtype=torch.float64))
+            close(D, g[f"D_sigma{i}"], rtol=1e-5, atol=1e-6 * float(np.abs(g[f"D_sigma{i}"]).max()))
+
+
+@pytest.mark.parametrize("tag", list(fx.REPAINT_CASES))
+def test_ddpm_repaint_sampler(golden, tag):
+    from oracle import ddpm_oracle as dorc
+    g = golden("ddpm.npz")
+    cfg = fx.CFG_D
+    P = dorc.make_params(cfg, int(g["seed"]))
+    N, R, churn, nth, ntu = fx.REPAINT_CASES[tag]
+    h, u, init, stp, reps = fx.repaint_inputs(tag)
+    hu = torch.cat([h, u], dim=-1).permute(0, 3, 1, 2)
+    sp = dorc.RepaintParams(timesteps=N, n_repeat=R, S_churn=churn, n_time_h=nth, n_time_u=ntu)
+    with torch.no_grad():
+        xs = dorc.sample_edm_repaint(P, cfg, hu, sp, init, stp, reps, return_last=False)
+    close(xs, g[f"{tag}_xs"], rtol=1e-5, atol=1e-6 * float(np.abs(g[f"{tag}_xs"]).max()))
