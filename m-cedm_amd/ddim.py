@@ -27,6 +27,14 @@ from .adm_blocks import DhariwalUNet, EmaModel
 from .mcedm import DotDict, Normalizer, _Base, _EdmTrainLoss, _nchw
 
 
+def _opt(cfg, name, default):
+    """cfg.<name> if present (DictConfig, attribute dicts whose __getattr__ raises KeyError, plain objects)."""
+    try:
+        return getattr(cfg, name)
+    except (AttributeError, KeyError):
+        return default
+
+
 def _beta_schedule(kind, beta_start, beta_end, n):
     """models/ddim_blocks.py:473-505."""
     if kind == "quad":
@@ -274,7 +282,7 @@ class PlDdim(_Base):
         self.save_hyperparameters()
         m, o, d, df = hparams.model, hparams.optimization, hparams.data, hparams.diffusion
         for flag in ("dx_cond", "node_type"):
-            if hasattr(m, flag) and getattr(m, flag):
+            if _opt(m, flag, False):
                 raise NotImplementedError(f"hparams.model.{flag}=True is outside the built path")
         if str(hparams.name).startswith("adm"):
             raise NotImplementedError("PlDdim with the ADM U-Net is not built; use PlMcedm / PlCondEdm for ADM networks")

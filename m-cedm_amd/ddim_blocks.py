@@ -21,7 +21,10 @@ from .adm_blocks import EmaModel  # noqa: F401  (re-exported like the reference 
 
 
 def _get(hp, name, default):
-    return getattr(hp, name) if hasattr(hp, name) else default
+    try:
+        return getattr(hp, name)
+    except (AttributeError, KeyError):
+        return default
 
 
 def Normalize(in_channels):
