@@ -52,6 +52,12 @@ WORKLOADS = {
     "ref128": dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32,
                    name="SWE-periodic 128x128, reference adm_edm_mcedm_res32 U-Net ch=64"),
 }
+# BASELINE config 5: RePaint-style EDM sampling of the joint DDPM (PlDdim.sample_edm, models/ddim.py:959-1051) with
+# configs/model/ddim_res32.yaml (DDPM U-Net ch=64, attention at 32^2) on 128x128 fields: u known for the first 64 time
+# rows, h unknown (n_time_h=0, n_time_u=64), 32 resampling loops per step -> 18*32*2 - 32 = 1120 U-Net evaluations / state
+REPAINT = dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=16, n_repeat=32, n_time_h=0, n_time_u=64,
+               name="SWE dam-break 128x128 RePaint (n_time_h=0, n_time_u=64, 32 resample loops/step), DDPM U-Net ch=64 "
+                    "(BASELINE config 5)")
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
 STEPS = 18                      # Heun steps -> 2*18 - 1 = 35 U-Net evaluations per state
@@ -62,7 +68,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="s128", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="s128", choices=sorted(WORKLOADS) + ["repaint128"])
     ap.add_argument("--batch", type=int, default=0, help="states per GPU (default: the workload's)")
     ap.add_argument("--no-graph", action="store_true", help="launch the sampler's kernels eagerly instead of one HIP graph")
     ap.add_argument("--profile-steps", type=int, default=1, help="sampler calls in the separate event-timed pass")
@@ -267,6 +273,58 @@ class Runner:
         return e0.elapsed_time(e1) / reps
 
 
+class RepaintRunner:
+    """BASELINE config 5 on this rank's GPU (same interface as Runner; launches are eager: one call is ~80k kernels)."""
+
+    def __init__(self, B, device, rank):
+        import torch
+        from mcedm_amd import lib
+        self.lib, self.torch = lib, torch
+        wl = REPAINT
+        self.wl, self.B, self.H, self.W = wl, B or wl["batch"], wl["H"], wl["W"]
+        self.plan = lib.DdpmPlan(2, 2, wl["ch"], wl["ch_mult"], 1, wl["attn"], wl["H"])
+        self.params = synth_params(self.plan, 7, device)
+        half = wl["ch"] // 2
+        freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))   # ddim_blocks.py:22-24
+        self.packed = self.plan.pack(self.params, freqs.to(device))
+        g = torch.Generator(device="cpu").manual_seed(2000 + rank)
+        self.hu = torch.randn(self.B, 2, self.H, self.W, generator=g).to(device)
+        self.init = torch.randn(self.B, 2, self.H, self.W, generator=g).to(device)
+        betas = torch.linspace(1e-4, 0.02, 1000, dtype=torch.float64).float()                             # ddim_res32.yaml diffusion
+        ab = (1.0 - betas).cumprod(dim=0)
+        steps = ((1 - ab) / ab).sqrt().flip(dims=(0,))
+        aext = (1 - torch.cat([torch.zeros(1), betas])).cumprod(dim=0)
+
+        class SP:      # configs/diff_sampler/edm_sampler_inv.yaml with the benchmark's 18 deterministic steps
+            timesteps, sigma_min, sigma_max, rho, S_churn, S_min, S_max, S_noise, w = STEPS, 0.002, 80.0, 7.0, 0.0, 0.0, float("inf"), 1.0, 0.0
+            n_repeat, n_time_h, n_time_u = wl["n_repeat"], wl["n_time_h"], wl["n_time_u"]
+        self.rd, self._keep = lib.repaint_desc(SP, steps, aext, 1, 1)
+        self.rep = torch.randn((STEPS, wl["n_repeat"] - 1, self.B, 2, self.H, self.W), dtype=torch.float64, device=device)
+        self.ws = lib.Workspace()
+        self.nfe = STEPS * wl["n_repeat"] * 2 - wl["n_repeat"]
+        self.graph = None
+
+    def step(self):
+        return self.eager()
+
+    def eager(self):
+        return self.plan.repaint_sample(self.packed, self.rd, self.hu, self.init, None, self.rep, return_last=True, ws=self.ws)
+
+    profile = Runner.profile
+
+    def fwd_ms(self, reps=5):
+        torch = self.torch
+        self.plan.denoise(self.packed, self.init, 1.5, 500.0, ws=self.ws)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self.plan.denoise(self.packed, self.init, 1.5, 500.0, ws=self.ws)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+
 def kernel_table(prof):
     rows = sorted(({"name": r["name"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
                     "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 2),
@@ -311,8 +369,11 @@ def main():
     import mcedm_amd  # noqa: F401
     from mcedm_amd import lib
 
-    run = Runner(args.workload, args.batch, device, rank, not args.no_graph)
+    repaint = args.workload == "repaint128"
+    run = RepaintRunner(args.batch, device, rank) if repaint else Runner(args.workload, args.batch, device, rank, not args.no_graph)
     wl, B, H, W = run.wl, run.B, run.H, run.W
+    if repaint:
+        args.no_train = True
 
     def barrier():
         if world > 1:
@@ -369,9 +430,11 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "states_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
-                   "sampler": "EDM Heun, 18 steps, 35 NFE/state, S_churn=0, w=0, fp64 state / fp32 net",
+                   "sampler": (f"EDM Heun + RePaint, 18 steps x {wl['n_repeat']} resampling loops, {run.nfe} NFE/state, S_churn=0, "
+                               "fp64 state / fp32 net") if repaint else
+                              "EDM Heun, 18 steps, 35 NFE/state, S_churn=0, w=0, fp64 state / fp32 net",
                    "parallelism": f"batch-sharded x{world}, no data-path collective",
-                   "launch": "eager" if args.no_graph else "one HIP graph per sampler call"},
+                   "launch": "eager" if (args.no_graph or repaint) else "one HIP graph per sampler call"},
         "timed_with_profiler": False, "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B, "train_step_ms": train_ms,
         "train_samples_per_sec": (B * world / (train_ms * 1e-3)) if train_ms else None,
         "roofline": roofline_of(prof), "kernels": kernel_table(prof)[:8], "csrc_digest": csrc_digest(),
@@ -404,7 +467,22 @@ def main():
             del r2
             torch.cuda.empty_cache()
 
+        # BASELINE config 5 (RePaint on the DDPM U-Net): one call of 8 states = 8960 U-Net evaluations
+        r5 = RepaintRunner(8, device, 0)
+        t5 = time.perf_counter()
+        r5.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t5
+        line["secondary"]["repaint128"] = {"workload": r5.wl["name"], "states_per_gpu": r5.B, "value": r5.B / dt, "unit": "states/s",
+                                           "ms_per_step": dt * 1e3, "steps": 1, "nfe_per_state": r5.nfe,
+                                           "unet_evals_per_s": r5.B * r5.nfe / dt, "unet_fwd_ms": r5.fwd_ms(),
+                                           "note": "one un-warmed eager call (includes first-launch overheads)"}
+        del r5
+        torch.cuda.empty_cache()
+
     line["cpu_baseline"] = None          # timed on rank 0 of the 1-GPU run only
+    if repaint:
+        args.no_cpu_baseline = True      # the CPU leg is defined on the headline workloads
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(wl, {k: v.cpu() for k, v in run.params.items()})
         line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
