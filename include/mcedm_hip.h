@@ -125,6 +125,24 @@ int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, const mcedm_sa
                       const float* cond, const float* mask, const float* init_noise,
                       const double* step_noise, double* out, int return_last, void* workspace,
                       size_t workspace_bytes, int B, int H, int W, void* stream);
+/* PDE guidance inside the single-task sampler (PlCondEdm.sample_edm with guide_dx=True, models/ddim.py:1532-1601:
+ * get_dx_log_prob :641-650 -> get_dx_pde :1424-1450, used at :1577-1579 and :1589-1591): after every denoiser call
+ * dx = mean over the two fields of d residual(x_unnorm) / d x_unnorm, x_unnorm = (h from cond[:, 0], u = denoised state),
+ * and d = (x - D) / t - weight * dx / t_hat.  system 1 = SweFvLoss (FORCE finite-volume residual along W), system 2 =
+ * DarcyLoss in its log-probability form (calc_prob=True).  sub_* / div_* are the normalisers' statistics (scalars):
+ * x_unnorm = x * div + sub.  mask must be NULL, in_channels 1, cond_channels >= 1.  (The joint model's hook,
+ * models/mcedm.py:500-518, slices the wrong axis and raises in the reference; it is not built.) */
+typedef struct {
+  int32_t system;
+  float half_dt, dx;         /* SWE: (float)(0.5 * Tn / n_times) and x[1] - x[0] of SweFvLoss.gen_x (fp32), as for mcedm_swe_fv_residual */
+  float two_dx;              /* Darcy: (float)(2 * D / s), as for mcedm_darcy_residual */
+  float sub_h, div_h, sub_u, div_u;
+  double weight;             /* 5.0 (mcedm.py:616) */
+} mcedm_guidance_desc;
+int mcedm_heun_sample_guided(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                             const mcedm_guidance_desc* gd, const float* cond, const float* mask,
+                             const float* init_noise, const double* step_noise, double* out, int return_last,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 /* Host helper: the float64 sigma schedule of mcedm.py:584-588 (timesteps+1 values, last = 0). */
 int mcedm_edm_t_steps(const mcedm_sampler_desc* sp, double* t_steps);
 
@@ -335,6 +353,14 @@ int mcedm_repaint_sample(const mcedm_ddpm_plan* plan, const void* packed, const 
  * mcedm_darcy_residual   DarcyLoss.calculate_loss models/pde_loss.py:30-54 and the division / clamp of forward
  *                        (:80-86): two_dx = (float)(2 * D / s), denom = (s-4)^2; out (b, s-4, s-4) */
 int mcedm_swe_fv_step(const float* s, float* out, int B, int T, int X, float half_dt, float dx, void* stream);
+/* The return_d=True branches (the guidance gradients; analytic adjoints of the stencils, models/pde_loss.py:231-242 and
+ * :60-75): mcedm_swe_fv_guidance = d mean(calculate_loss(pred, gt)) / d pred, out (b, t, x, 2);
+ * mcedm_darcy_guidance = d mean(L) / d pred or, calc_prob != 0, d mean(log(2 (1 - sigmoid(1e5 L)) + 1e-12)) / d pred,
+ * out (b, s, s, 2), scratch holds b * (s-4)^2 floats.  NaNs of the gradient are returned as 0 like the reference's. */
+int mcedm_swe_fv_guidance(const float* pred, const float* gt, float* out, int B, int T, int X, float half_dt, float dx,
+                          float scale2_h, float scale2_u, void* stream);
+int mcedm_darcy_guidance(const float* pred, float* out, float* scratch, int B, int S, float two_dx, int calc_prob,
+                         void* stream);
 int mcedm_swe_fv_residual(const float* pred, const float* gt, float* out, int B, int T, int X, float half_dt, float dx,
                           float scale2_h, float scale2_u, int clamp, void* stream);
 int mcedm_darcy_residual(const float* pred, float* out, int B, int S, float two_dx, float denom, int clamp, void* stream);

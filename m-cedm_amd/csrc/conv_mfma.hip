@@ -27,9 +27,14 @@
 
 namespace mcedm {
 
-template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_, int NT_ = 256>
+// KC = input channels per PACKED weight chunk (8 for 3x3, 16 for 1x1); CPI = packed chunks staged and consumed per
+// iteration of the K loop (one load -> barrier -> MFMA -> barrier round trip per KC * CPI channels).  The small tiles
+// that serve <= 16 x 16 images run on grids of 64-256 workgroups, one per CU, whose duration is a chain of memory
+// latencies, not matrix time: CPI > 1 shortens that chain.
+template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_, int NT_ = 256, int CPI_ = 1>
 struct ConvCfg {
   static constexpr int MT = MT_, PH = PH_, PW = PW_, WM = WM_, WN = WN_, TAPS = TAPS_, KC = KC_;
+  static constexpr int CPI = CPI_, KCI = KC_ * CPI_;   // channels per iteration
   static constexpr int NT = NT_;              // threads per workgroup
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
   static constexpr int PITCH = PW + 2 * HALO;
@@ -38,8 +43,8 @@ struct ConvCfg {
   static constexpr int NPIX = PH * PW;
   static constexpr int TM = MT / WM / 32;    // 32x32 accumulator tiles per wave along M
   static constexpr int TN = NPIX / WN / 32;  // ... along N
-  static constexpr int XL = KC * PLANE;      // floats of the input tile
-  static constexpr int WL = TAPS * KC * MT;  // floats of the weight slab
+  static constexpr int XL = KCI * PLANE;     // floats of the input tile
+  static constexpr int WL = TAPS * KCI * MT; // floats of the weight slab: [cpi][tap][ci_local][MT]
   static constexpr int NWAVE = WM * WN;       // waves that own accumulators (the rest only help staging)
   // resident workgroups per CU the kernel is compiled for: <= 64 accumulator registers leave room for a third wave
   // per SIMD (<= 168 VGPRs), which hides more of the staging phases (+5 % on the MT = 64 tiles)
@@ -177,8 +182,8 @@ __device__ __forceinline__ void stage_coef_rows(const ConvArgs& p, int n, Coef* 
 
 template <class C, int RS>
 struct InputRegs {
-  float raw[C::KC][TileGeom<C, RS>::SUB][TileGeom<C, RS>::NL];
-  Coef cf[C::KC];      // unused (and optimised away) when the transform rows are read from LDS at commit
+  float raw[C::KCI][TileGeom<C, RS>::SUB][TileGeom<C, RS>::NL];
+  Coef cf[C::KCI];      // unused (and optimised away) when the transform rows are read from LDS at commit
 };
 
 template <class C, int RS, bool COEF_REGS = true>
@@ -188,7 +193,7 @@ __device__ __forceinline__ void load_input(const ConvArgs& p, const TileGeom<C, 
   const size_t src_plane = (size_t)p.Hs * p.Ws;
   const float* safe = p.xa ? p.xa : p.xb;     // any valid plane for padded channels (values are discarded)
 #pragma unroll
-  for (int cil = 0; cil < C::KC; ++cil) {
+  for (int cil = 0; cil < C::KCI; ++cil) {
     const int ci = c0 + cil;
     const bool in_a = ci < p.Ca;
     const float* src = in_a ? p.xa : p.xb;
@@ -210,14 +215,13 @@ template <class C, int RS>
 __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C, RS>& G, float* xl,
                                             const InputRegs<C, RS>& R0, int c0, int tid, const Coef* cfl = nullptr) {
   const int Cin = p.Ca + p.Cb;
-  InputRegs<C, RS> R = R0;
-  if (cfl) {      // rows of this sample staged in LDS by the caller (wave-uniform broadcast reads)
+  const InputRegs<C, RS>& R = R0;
 #pragma unroll
-    for (int cil = 0; cil < C::KC; ++cil) R.cf[cil] = cfl[c0 + cil < Cin ? c0 + cil : Cin - 1];
-  }
-#pragma unroll
-  for (int cil = 0; cil < C::KC; ++cil) {
+  for (int cil = 0; cil < C::KCI; ++cil) {
     const int ci = c0 + cil;
+    // this channel's transform row: staged in LDS by the caller (wave-uniform broadcast read, one row live at a time:
+    // preloading all KCI rows costs 3 * KCI registers) or carried in the staging registers
+    const Coef cfr = cfl ? cfl[ci < Cin ? ci : Cin - 1] : R0.cf[cil];
     const bool chan_ok = (ci < Cin) && ((ci < p.Ca ? p.xa : p.xb) != nullptr);
     const unsigned ckeep = chan_ok ? 0xffffffffu : 0u;
 #pragma unroll
@@ -226,7 +230,7 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
         // the four phases go to four planes of the (4x larger) LDS tile: [ci_local][phase][ROWS][PITCH]
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float vq = apply_coef(R.raw[cil][sub][q], R.cf[cil], p.act);
+          float vq = apply_coef(R.raw[cil][sub][q], cfr, p.act);
           vq = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, vq) & (G.keep[sub] & ckeep));
           if ((sub + 1) * C::NT <= C::PLANE || tid + sub * C::NT < C::PLANE) xl[(cil * 4 + q) * C::PLANE + tid + sub * C::NT] = vq;
         }
@@ -235,10 +239,10 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
       float v;
       if constexpr (RS == RS_DOWN) {
         // 2x2 box filter of the ACTIVATED source (adm_blocks.py:75-77 runs after silu(norm(x)))
-        v = 0.25f * ((apply_coef(R.raw[cil][sub][0], R.cf[cil], p.act) + apply_coef(R.raw[cil][sub][1], R.cf[cil], p.act)) +
-                     (apply_coef(R.raw[cil][sub][2], R.cf[cil], p.act) + apply_coef(R.raw[cil][sub][3], R.cf[cil], p.act)));
+        v = 0.25f * ((apply_coef(R.raw[cil][sub][0], cfr, p.act) + apply_coef(R.raw[cil][sub][1], cfr, p.act)) +
+                     (apply_coef(R.raw[cil][sub][2], cfr, p.act) + apply_coef(R.raw[cil][sub][3], cfr, p.act)));
       } else {
-        v = apply_coef(R.raw[cil][sub][0], R.cf[cil], p.act);
+        v = apply_coef(R.raw[cil][sub][0], cfr, p.act);
       }
       // zero padding / padded channels as a bit mask: straight-line code (a select makes the compiler branch
       // around the SiLU, ~30 tiny basic blocks per chunk)
@@ -246,8 +250,9 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
       if ((sub + 1) * C::NT <= C::PLANE || tid + sub * C::NT < C::PLANE) xl[cil * C::PLANE + tid + sub * C::NT] = v;
     }
     // one channel at a time: left alone, the scheduler interleaves all KC SiLU chains of this straight-line code
-    // and pays for the extra live values with accumulator spills
-    __builtin_amdgcn_sched_barrier(0);
+    // and pays for the extra live values with accumulator spills.  Small tiles (few accumulators, one element per
+    // thread) have the registers to overlap the channels' LDS reads and transcendental chains instead.
+    if constexpr (C::TM * C::TN > 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -280,6 +285,7 @@ __device__ __forceinline__ void make_wgeom(const float* wpk, WeightGeom<C>& G, i
   if (il >= NV4) il = NV4 - 1;
   const int rl = il / V4 - (IT - 1) * WeightGeom<C>::ROWS_IT, cl = il % V4;
   G.voff_last = 4u * (unsigned)(rl * coutp + cl * 4);
+  // nchunks = PACKED chunks: a partial last iteration (CPI > 1) reads past the table and gets zeros from the range check
   G.rs = make_rsrc(wpk + m0, 4u * (unsigned)((size_t)nchunks * C::TAPS * C::KC * coutp - m0));
 }
 
@@ -288,7 +294,7 @@ __device__ __forceinline__ void load_weights(const WeightGeom<C>& G, WeightRegs<
   constexpr int IT = WeightRegs<C>::IT;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
-    const unsigned soff = 4u * (unsigned)((ch * (C::TAPS * C::KC) + it * WeightGeom<C>::ROWS_IT) * coutp);
+    const unsigned soff = 4u * (unsigned)((ch * (C::TAPS * C::KCI) + it * WeightGeom<C>::ROWS_IT) * coutp);
     const unsigned voff = (it == IT - 1) ? G.voff_last : G.voff;
     R.v[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(G.rs, voff, soff, 0));
   }
@@ -529,7 +535,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   InputRegs<C, RS> xin;
   WeightRegs<C> win;
   WeightGeom<C> wgeom;
-  make_wgeom<C>(p.wpk, wgeom, m0, coutp, nchunks, tid);
+  make_wgeom<C>(p.wpk, wgeom, m0, coutp, (p.Ca + p.Cb + C::KC - 1) / C::KC, tid);
   load_weights<C>(wgeom, win, 0, coutp);
   load_input<C, RS, false>(p, geom, xin, n, 0);
   stage_coef_rows<C::NT>(p, n, cfl, tid);
@@ -556,7 +562,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   __syncthreads();            // transform rows visible to every wave
   for (int ch = 0; ch < nchunks; ++ch) {
     store_weights<C>(wl, win, tid);
-    store_input<C, RS>(p, geom, xl, xin, ch * C::KC, tid, cfl);
+    store_input<C, RS>(p, geom, xl, xin, ch * C::KCI, tid, cfl);
     MCEDM_STAMP(0)
     __syncthreads();
     MCEDM_STAMP(1)
@@ -565,10 +571,15 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
         // resolves with a vmcnt(0) + register copies right here, in front of the MFMA loop.
       const int chn = ch + 1 < nchunks ? ch + 1 : ch;
       load_weights<C>(wgeom, win, chn, coutp);
-      load_input<C, RS, false>(p, geom, xin, n, chn * C::KC);
+      load_input<C, RS, false>(p, geom, xin, n, chn * C::KCI);
     }
     MCEDM_STAMP(2)
-    if (wave < C::NWAVE) mfma_chunk<C, true, RS == RS_S2>(xl, wl, acc, aoff, boff);
+    if (wave < C::NWAVE) {
+#pragma unroll
+      for (int sc = 0; sc < C::CPI; ++sc)      // the packed chunks of this iteration, back to back
+        mfma_chunk<C, true, RS == RS_S2>(xl + sc * C::KC * (RS == RS_S2 ? 4 * C::PLANE : C::PLANE), wl + sc * C::TAPS * C::KC * C::MT,
+                                         acc, aoff, boff);
+    }
     MCEDM_STAMP(3)
     __syncthreads();
     MCEDM_STAMP(4)
@@ -974,7 +985,7 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   }
   const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
   const int mtiles = ceil_div(a.Cout, C::MT);
-  const int nchunks = ceil_div(a.Ca + a.Cb, C::KC);
+  const int nchunks = ceil_div(a.Ca + a.Cb, C::KCI);      // iterations of the K loop
   const long long blocks = (long long)a.B * tiles_x * tiles_y * mtiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) {
     set_error("conv grid out of range (%lld blocks)", blocks);
@@ -983,8 +994,8 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
   // algorithmic cost of this launch: 2*MAC flops; bytes = input read once + output written once + weights + residual
   char name[96] = "";
   if (prof_enabled())
-    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d>, %d>", C::MT, C::PH, C::PW,
-             C::WM, C::WN, C::TAPS, C::KC, C::NT, (int)a.resample);   // = rocprofv3's name
+    snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %d>, %d>", C::MT, C::PH, C::PW,
+             C::WM, C::WN, C::TAPS, C::KC, C::NT, C::CPI, (int)a.resample);   // = rocprofv3's name
   const double px = (double)a.B * a.H * a.W;
   const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
   const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
@@ -1024,7 +1035,7 @@ static int launch_cfg_s2(const ConvArgs& a_in, hipStream_t stream) {
   }
   const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
   const int mtiles = ceil_div(a.Cout, C::MT);
-  const int nchunks = ceil_div(a.Ca + a.Cb, C::KC);
+  const int nchunks = ceil_div(a.Ca + a.Cb, C::KCI);
   const long long blocks = (long long)a.B * tiles_x * tiles_y * mtiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv grid out of range (%lld blocks)", blocks); return MCEDM_ERR_INVALID; }
   char name[96] = "";
@@ -1141,6 +1152,12 @@ void set_conv_tile_override(int mt, int ph, int pw) { g_force_mt = mt; g_force_p
 template <int TAPS, int KC>
 static int dispatch(const ConvArgs& a, hipStream_t stream) {
   const int coutp = cout_padded(a.Cout);
+  // 8 x 8-pixel tiles (<= 16 x 16 images): 16 (3x3) / 64 (1x1) channels per K-loop iteration, see ConvCfg::CPI
+  // measured (tools/conv_small_timeline.py): CPI = 2 / 4 made these launches SLOWER (8x8 3x3: 31 -> 38 us, 1x1: 20 -> 30 us,
+  // 8x16: 67 -> 75 us): the K loop of the small tiles is not a chain of memory latencies but per-channel staging work
+  // done by the few threads that own a tile element, so doubling the channels per iteration doubles that serial phase
+  constexpr int SMALL_CPI = 1;
+  constexpr int MID_CPI = 1;
 #ifdef MCEDM_CONV_ONE   // compile-time probe builds: only the dominant configuration
   return launch_cfg<ConvCfg<128, 8, 32, 1, 4, 9, 8>>(a, stream);
 #else
@@ -1153,15 +1170,15 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
         return launch_conv8(a, stream);
       case 1280832: return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);
       case 1280816: return launch_cfg<ConvCfg<128, 8, 16, 1, 4, TAPS, KC>>(a, stream);
-      case 640816: return launch_cfg<ConvCfg<64, 8, 16, 1, 4, TAPS, KC>>(a, stream);
+      case 640816: return launch_cfg<ConvCfg<64, 8, 16, 1, 4, TAPS, KC, 256, MID_CPI>>(a, stream);
       case 1280808: return launch_cfg<ConvCfg<128, 8, 8, 2, 2, TAPS, KC>>(a, stream);
       case 640832: return launch_cfg<ConvCfg<64, 8, 32, 1, 4, TAPS, KC>>(a, stream);
       case 320832: return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);
       case 1281616: return launch_cfg<ConvCfg<128, 16, 16, 1, 4, TAPS, KC>>(a, stream);
       case 641616: return launch_cfg<ConvCfg<64, 16, 16, 1, 4, TAPS, KC>>(a, stream);
       case 321616: return launch_cfg<ConvCfg<32, 16, 16, 1, 4, TAPS, KC>>(a, stream);
-      case 640808: return launch_cfg<ConvCfg<64, 8, 8, 2, 2, TAPS, KC>>(a, stream);
-      case 320808: return launch_cfg<ConvCfg<32, 8, 8, 1, 2, TAPS, KC>>(a, stream);
+      case 640808: return launch_cfg<ConvCfg<64, 8, 8, 2, 2, TAPS, KC, 256, SMALL_CPI>>(a, stream);
+      case 320808: return launch_cfg<ConvCfg<32, 8, 8, 1, 2, TAPS, KC, 256, SMALL_CPI>>(a, stream);
       default: set_error("conv: no such tile configuration (%d, %d, %d)", g_force_mt, g_force_ph, g_force_pw); return MCEDM_ERR_INVALID;
     }
   }
@@ -1173,12 +1190,12 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
   };
   const long long want = 512;
   if ((long long)a.H * a.W <= 256 || a.W < 12) {          // <= 16x16 images: 8x8-pixel tiles
-    if (coutp % 64 == 0) return launch_cfg<ConvCfg<64, 8, 8, 2, 2, TAPS, KC>>(a, stream);
-    return launch_cfg<ConvCfg<32, 8, 8, 1, 2, TAPS, KC>>(a, stream);
+    if (coutp % 64 == 0) return launch_cfg<ConvCfg<64, 8, 8, 2, 2, TAPS, KC, 256, SMALL_CPI>>(a, stream);
+    return launch_cfg<ConvCfg<32, 8, 8, 1, 2, TAPS, KC, 256, SMALL_CPI>>(a, stream);
   }
   if (TAPS == 9 && a.W >= 24 && (long long)a.H * a.W <= 1024) {   // 3x3 on ~32x32 images: half-width tiles, 3 workgroups/CU
     if (coutp % 128 == 0 && blocks_for(128, 8, 16) >= want) return launch_cfg<ConvCfg<128, 8, 16, 1, 4, TAPS, KC>>(a, stream);
-    if (coutp % 64 == 0) return launch_cfg<ConvCfg<64, 8, 16, 1, 4, TAPS, KC>>(a, stream);
+    if (coutp % 64 == 0) return launch_cfg<ConvCfg<64, 8, 16, 1, 4, TAPS, KC, 256, MID_CPI>>(a, stream);
     return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);
   }
   if (a.W >= 24) {

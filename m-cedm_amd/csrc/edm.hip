@@ -98,12 +98,16 @@ __global__ void heun_churn_kernel(double* __restrict__ x, const double* __restri
 }
 
 // d = (x_hat - D)/t_hat ; x_next = x_hat + ((t_next - t_hat)*d)*mask    (mcedm.py:617-618)
+// dxg != NULL: PDE guidance of the single-task sampler, d = (x_hat - D)/t_hat - weight * dx / t_hat with the guidance
+// term formed in fp32 (models/ddim.py:1577-1579)
 __global__ void heun_euler_kernel(const double* __restrict__ x_hat, const float* __restrict__ D,
                                   const float* __restrict__ mask, double t_hat, double dt, size_t total,
-                                  double* __restrict__ d_cur, double* __restrict__ x_next, float* __restrict__ x32) {
+                                  double* __restrict__ d_cur, double* __restrict__ x_next, float* __restrict__ x32,
+                                  const float* __restrict__ dxg, float wgt, float gdiv) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const double xh = x_hat[i];
-    const double d = (xh - (double)D[i]) / t_hat;
+    double d = (xh - (double)D[i]) / t_hat;
+    if (dxg) d = d - (double)((wgt * dxg[i]) / gdiv);
     const double v = xh + (dt * d) * (mask ? (double)mask[i] : 1.0);
     d_cur[i] = d;
     x_next[i] = v;
@@ -114,9 +118,11 @@ __global__ void heun_euler_kernel(const double* __restrict__ x_hat, const float*
 // d' = (x_next - D')/t_next ; x_next = x_hat + (dt*(0.5 d + 0.5 d'))*mask   (mcedm.py:627-628)
 __global__ void heun_correct_kernel(const double* __restrict__ x_hat, const double* __restrict__ d_cur,
                                     const float* __restrict__ D, const float* __restrict__ mask, double t_next, double dt,
-                                    size_t total, double* __restrict__ x_next, float* __restrict__ x32) {
+                                    size_t total, double* __restrict__ x_next, float* __restrict__ x32,
+                                    const float* __restrict__ dxg, float wgt, float gdiv) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const double dp = (x_next[i] - (double)D[i]) / t_next;
+    double dp = (x_next[i] - (double)D[i]) / t_next;
+    if (dxg) dp = dp - (double)((wgt * dxg[i]) / gdiv);                 // models/ddim.py:1590-1591 (divides by t_hat here too)
     const double v = x_hat[i] + (dt * (0.5 * d_cur[i] + 0.5 * dp)) * (mask ? (double)mask[i] : 1.0);
     x_next[i] = v;
     x32[i] = (float)v;
@@ -148,16 +154,17 @@ int launch_heun_churn(double* x, const double* eps, const float* mask, double c,
   return MCEDM_OK;
 }
 int launch_heun_euler(const double* x_hat, const float* D, const float* mask, double t_hat, double dt, size_t total,
-                      double* d_cur, double* x_next, float* x32, hipStream_t s) {
+                      double* d_cur, double* x_next, float* x32, hipStream_t s, const float* dxg, float wgt, float gdiv) {
   hipLaunchKernelGGL(heun_euler_kernel, dim3(grid_for(total)), dim3(256), 0, s, x_hat, D, mask, t_hat, dt, total, d_cur,
-                     x_next, x32);
+                     x_next, x32, dxg, wgt, gdiv);
   MCEDM_LAUNCH_CHECK("heun_euler_kernel");
   return MCEDM_OK;
 }
 int launch_heun_correct(const double* x_hat, const double* d_cur, const float* D, const float* mask, double t_next,
-                        double dt, size_t total, double* x_next, float* x32, hipStream_t s) {
+                        double dt, size_t total, double* x_next, float* x32, hipStream_t s, const float* dxg, float wgt,
+                        float gdiv) {
   hipLaunchKernelGGL(heun_correct_kernel, dim3(grid_for(total)), dim3(256), 0, s, x_hat, d_cur, D, mask, t_next, dt,
-                     total, x_next, x32);
+                     total, x_next, x32, dxg, wgt, gdiv);
   MCEDM_LAUNCH_CHECK("heun_correct_kernel");
   return MCEDM_OK;
 }

@@ -13,11 +13,29 @@ int launch_heun_init(const float* cond, int cond_ch, int in_ch, size_t hw, const
                      double t0, size_t total, double* x, float* x32, hipStream_t s);
 int launch_heun_churn(double* x, const double* eps, const float* mask, double c, size_t total, float* x32,
                       hipStream_t s);
+// dxg / wgt / gdiv: optional PDE-guidance term of the single-task sampler, d -= (double)((wgt * dxg) / gdiv) formed in fp32
+// (models/ddim.py:1577-1579, 1590-1591: `weight * dx / t_hat`, with t_hat in BOTH stages)
 int launch_heun_euler(const double* x_hat, const float* D, const float* mask, double t_hat, double dt, size_t total,
-                      double* d_cur, double* x_next, float* x32, hipStream_t s);
+                      double* d_cur, double* x_next, float* x32, hipStream_t s, const float* dxg = nullptr, float wgt = 0.f,
+                      float gdiv = 1.f);
 int launch_heun_correct(const double* x_hat, const double* d_cur, const float* D, const float* mask, double t_next,
-                        double dt, size_t total, double* x_next, float* x32, hipStream_t s);
+                        double dt, size_t total, double* x_next, float* x32, hipStream_t s, const float* dxg = nullptr,
+                        float wgt = 0.f, float gdiv = 1.f);
 int launch_heun_store(const double* x, int C, size_t hw, int t, int T, size_t total, double* out, hipStream_t s);
+
+// PDE guidance gradients (pde.hip): analytic adjoints of the residual stencils.  The two fields of the state may live in
+// different tensors (the single-task models take h from the conditioning and u from the denoised state), so every field
+// has its own base pointer and batch stride; row / column strides are shared.
+struct GuideIO {
+  const float* in[2]; const float* gt[2];     // state fields and the residual's target (SWE; usually the same tensors)
+  long in_sb[2], st, sx;
+  float* out[2]; long out_sb[2], out_st, out_sx;
+  float sub[2], div[2];                       // un-normalisation x * div + sub applied while reading
+  int mean;                                   // 1: write the mean of the two field gradients to out[0] only
+};
+int launch_swe_guidance(const GuideIO& io, int B, int T, int X, float half_dt, float dx, float scale2_h, float scale2_u,
+                        hipStream_t s);
+int launch_darcy_guidance(const GuideIO& io, float* scratch, int B, int S, float two_dx, int calc_prob, hipStream_t s);
 
 // ---- RePaint-style sampler on the DDPM U-Net (models/ddim.py:915-1051): VP preconditioning and known-region kernels
 // D = x + (-sigma) * F                                                   (get_denoised, ddim.py:923-946: c_skip 1, c_out -sigma)

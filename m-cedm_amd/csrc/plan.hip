@@ -708,13 +708,14 @@ extern "C" int mcedm_edm_t_steps(const mcedm_sampler_desc* sp, double* t) {
 }
 
 namespace mcedm {
-struct SamplerBufs { size_t x, xn, d, x32, D, total; };
+struct SamplerBufs { size_t x, xn, d, x32, D, dx, g, total; };
 static SamplerBufs sampler_bufs(const mcedm_plan& P, int B, int H, int W) {
   SamplerBufs s;
   size_t cur = 0;
   auto take = [&](size_t bytes) { size_t o = cur; cur += align_up(bytes, 256); return o; };
   const size_t n = (size_t)B * P.desc.in_channels * H * W;
   s.x = take(n * 8); s.xn = take(n * 8); s.d = take(n * 8); s.x32 = take(n * 4); s.D = take(n * 4);
+  s.dx = take(n * 4); s.g = take(n * 4);          // PDE guidance: gradient and the Darcy interior scratch
   s.total = cur;
   return s;
 }
@@ -729,10 +730,55 @@ extern "C" int mcedm_sampler_workspace_bytes(const mcedm_plan* plan, int B, int 
   return MCEDM_OK;
 }
 
+namespace mcedm {
+// dx = get_dx_log_prob(h, denoised, guide_dx) of the single-task models (models/ddim.py:641-650 -> get_dx_pde :1424-1450):
+// the residual of x_unnorm = (h from the conditioning, u = the denoised state), differentiated w.r.t. x_unnorm, then the
+// MEAN over the two field gradients (calc_prob=True) -> [B, 1, H, W]
+static int guidance_dx(const mcedm_plan& P, const mcedm_guidance_desc& g, const float* cond, const float* D, float* dx,
+                       float* scratch, int B, int H, int W, hipStream_t s) {
+  GuideIO io{};
+  const long hw = (long)H * W;
+  io.in[0] = cond; io.in[1] = D; io.gt[0] = cond; io.gt[1] = D;
+  io.in_sb[0] = (long)P.desc.cond_channels * hw; io.in_sb[1] = hw; io.st = W; io.sx = 1;
+  io.out[0] = dx; io.out[1] = nullptr; io.out_sb[0] = hw; io.out_sb[1] = 0; io.out_st = W; io.out_sx = 1;
+  io.sub[0] = g.sub_h; io.sub[1] = g.sub_u; io.div[0] = g.div_h; io.div[1] = g.div_u;
+  io.mean = 1;
+  if (g.system == 1)      // SweFvLoss: half_dt = 0.5 * Tn / n_times, dx = x[1] - x[0] of gen_x, both formed by the caller in fp32
+    return launch_swe_guidance(io, B, H, W, g.half_dt, g.dx, g.div_h * g.div_h, g.div_u * g.div_u, s);
+  MCEDM_REQUIRE(H == W && H > 4, "guidance: the Darcy residual needs a square grid larger than 4 x 4 (got %d x %d)", H, W);
+  return launch_darcy_guidance(io, scratch, B, H, g.two_dx, /*calc_prob=*/1, s);
+}
+}  // namespace mcedm
+
+static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                            const float* cond, const float* mask, const float* init_noise,
+                            const double* step_noise, double* out, int return_last, void* workspace,
+                            size_t workspace_bytes, int B, int H, int W, const mcedm_guidance_desc* gd, void* stream);
+
 extern "C" int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
                                  const float* cond, const float* mask, const float* init_noise,
                                  const double* step_noise, double* out, int return_last, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, void* stream) {
+  return heun_sample_impl(plan, packed, sp, cond, mask, init_noise, step_noise, out, return_last, workspace, workspace_bytes,
+                          B, H, W, nullptr, stream);
+}
+
+extern "C" int mcedm_heun_sample_guided(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                                        const mcedm_guidance_desc* gd, const float* cond, const float* mask,
+                                        const float* init_noise, const double* step_noise, double* out, int return_last,
+                                        void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  MCEDM_REQUIRE(gd != nullptr && (gd->system == 1 || gd->system == 2), "heun_sample_guided: guidance system must be 1 (SWE) or 2 (Darcy)");
+  MCEDM_REQUIRE(plan && plan->desc.in_channels == 1 && plan->desc.cond_channels >= 1 && cond != nullptr && mask == nullptr,
+                "heun_sample_guided: PDE guidance is defined for the single-task sampler (state u, conditioning h in cond[:, 0]; "
+                "mask NULL), models/ddim.py:1532-1601; the joint model's hook fails in the reference (models/mcedm.py:500-518)");
+  return heun_sample_impl(plan, packed, sp, cond, mask, init_noise, step_noise, out, return_last, workspace, workspace_bytes,
+                          B, H, W, gd, stream);
+}
+
+static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                            const float* cond, const float* mask, const float* init_noise,
+                            const double* step_noise, double* out, int return_last, void* workspace,
+                            size_t workspace_bytes, int B, int H, int W, const mcedm_guidance_desc* gd, void* stream) {
   MCEDM_REQUIRE(plan && packed && sp && init_noise && out && workspace, "heun_sample: null argument");
   const mcedm_plan& P = *plan;
   MCEDM_REQUIRE(P.desc.in_channels == P.desc.out_channels, "heun_sample: in_channels != out_channels");
@@ -782,11 +828,18 @@ extern "C" int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, con
     }
     // Euler step (mcedm.py:611-618)
     if ((rc = denoise_impl(P, L, hd, pk, x32, nullptr, (float)t_hat, 1, 1, cond, w, D, nullptr, uws, B, H, W, sd, s))) return rc;
-    if ((rc = launch_heun_euler(x, D, mask, t_hat, t_next - t_hat, total, dcur, xn, x32, s))) return rc;
+    const float* dxg = nullptr;
+    const float wgt = gd ? (float)gd->weight : 0.f;
+    if (gd) {
+      if ((rc = guidance_dx(P, *gd, cond, D, at<float>(workspace, sb.dx), at<float>(workspace, sb.g), B, H, W, s))) return rc;
+      dxg = at<float>(workspace, sb.dx);
+    }
+    if ((rc = launch_heun_euler(x, D, mask, t_hat, t_next - t_hat, total, dcur, xn, x32, s, dxg, wgt, (float)t_hat))) return rc;
     // 2nd-order correction (mcedm.py:621-628)
     if (i < N - 1) {
       if ((rc = denoise_impl(P, L, hd, pk, x32, nullptr, (float)t_next, 1, 1, cond, w, D, nullptr, uws, B, H, W, sd, s))) return rc;
-      if ((rc = launch_heun_correct(x, dcur, D, mask, t_next, t_next - t_hat, total, xn, x32, s))) return rc;
+      if (gd && (rc = guidance_dx(P, *gd, cond, D, at<float>(workspace, sb.dx), at<float>(workspace, sb.g), B, H, W, s))) return rc;
+      if ((rc = launch_heun_correct(x, dcur, D, mask, t_next, t_next - t_hat, total, xn, x32, s, dxg, wgt, (float)t_hat))) return rc;
     }
     std::swap(x, xn);
     if (!return_last && (rc = launch_heun_store(x, C, hw, i + 1, Tout, total, out, s))) return rc;

@@ -85,7 +85,8 @@ class PlCondEdm(_Base):
         self.beta1, self.amsgrad, self.eps = o.beta1, o.amsgrad, o.eps
         if hasattr(o, "pde_loss_lambda") and o.pde_loss_lambda:
             raise NotImplementedError("pde_loss_lambda != 0 is outside the hot path")
-        self.pde_loss = self.pde_loss_simulator = None
+        from .pde_loss import get_pde_loss_function
+        self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system="swe", flip_xy=False)    # models/ddim.py:76-78
         self.P_mean, self.P_std, self.sigma_data = -1.2, 1.2, 1.0
         self.sigma_min, self.sigma_max = 0.002, 80
         self.sparams = hparams.sampler if hparams.get("sampler", None) is not None else self.get_edm_sampler_params()
@@ -109,11 +110,9 @@ class PlCondEdm(_Base):
         self.test_sparams = params
 
     def set_pde_loss_function(self, system, flip_xy):
-        try:
-            from models.loss_helper import get_pde_loss_function      # the host repository's, if importable
-            self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system, flip_xy)
-        except Exception:
-            self.pde_loss = self.pde_loss_simulator = None
+        """models/ddim.py:97-101; the residuals and their guidance gradients run on the device (m-cedm_amd/pde_loss.py)."""
+        from .pde_loss import get_pde_loss_function
+        self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system, flip_xy)
 
     def setup(self, stage: str = None) -> None:
         if stage == "fit":
@@ -223,10 +222,34 @@ class PlCondEdm(_Base):
         self.log("train_loss", loss, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
         return loss
 
+    def get_dx_pde(self, cond, x_denoised, calc_prob=False):
+        """models/ddim.py:1424-1450: gradient of the PDE residual of (h from cond, u = x_denoised), un-normalised, w.r.t. that
+        state; mean (calc_prob) or sum over the two field gradients."""
+        h = cond[:, :self.h_ch].to(torch.float32).permute(0, 2, 3, 1)
+        u = x_denoised.to(torch.float32).permute(0, 2, 3, 1)
+        h_un = self.normalizer_input((h + 1.0) / 2.0 if self.rescaled else h, inverse=True)
+        u_un = self.inverse_data_transform_u(u)
+        x_un = torch.cat([h_un, u_un], dim=-1).contiguous()
+        d = self.pde_loss(x_un, x_un, self.normalizer_input, self.normalizer_target, True, calc_prob).permute(0, 3, 1, 2)
+        return torch.mean(d, dim=1, keepdim=True) if calc_prob else torch.sum(d, dim=1)
+
+    def get_dx_log_prob(self, cond, x_denoised, guide_dx):
+        """models/ddim.py:641-650 (the residual classes already zero the NaNs of the gradient)."""
+        if not guide_dx:
+            return torch.zeros_like(x_denoised)
+        return self.get_dx_pde(cond, x_denoised, calc_prob=True)
+
     def sample_edm(self, h, u_noise, sparams, return_last=True, guide_dx=False):
-        """h, u_noise in the reference's 'b h w c' layout; returns [b, t, h, w, c] float64 (models/ddim.py:1532-1601)."""
+        """h, u_noise in the reference's 'b h w c' layout; returns [b, t, h, w, c] float64 (models/ddim.py:1532-1601).
+        guide_dx=True: after every denoiser call d -= 5 * dx / t_hat with dx the PDE-residual gradient, evaluated on the
+        device by the stencils' analytic adjoints (csrc/pde.hip) instead of torch.autograd."""
+        guidance = None
         if guide_dx:
-            raise NotImplementedError("guide_dx=True (PDE guidance) is outside the hot path")
+            if self.pde_loss is None or not hasattr(self.pde_loss, "guidance_desc"):
+                raise NotImplementedError("guide_dx=True needs set_pde_loss_function('swe' | 'swe_per' | 'darcy')")
+            if self.rescaled or self.normalization == "min_max" or self.h_ch != 1 or self.u_ch != 1:
+                raise NotImplementedError("guide_dx=True is built for scalar gauss-normalised fields h, u")
+            guidance = self.pde_loss.guidance_desc(self.normalizer_input, self.normalizer_target, h.shape[1], h.shape[2])
         net = self._net(self.ema_model if self.ema_model is not None else self.model)
         h, init = _nchw(h).float(), _nchw(u_noise).float()
         sd = _lib.sampler_desc(sparams, self.sigma_data, self.sigma_min, self.sigma_max)
@@ -235,7 +258,7 @@ class PlCondEdm(_Base):
         step_noise = torch.randn((N,) + tuple(init.shape), dtype=torch.float64, device=init.device) if churn else None
         with torch.no_grad():
             return net.plan.sample(net.packed_weights(), sd, h, None, init, step_noise, return_last=return_last,
-                                   ws=self._sample_ws)
+                                   ws=self._sample_ws, guidance=guidance)
 
     # ---- evaluation bookkeeping (models/ddim.py:1154-1330; scaled-MAE / correlation / PDE extras are host metrics)
     def _eval(self, batch, sp, n):

@@ -23,7 +23,8 @@ EXPORTS = [
     "mcedm_heun_sample", "mcedm_edm_t_steps", "mcedm_edm_loss", "mcedm_edm_noise_inputs",
     "mcedm_edm_denoise_backward", "mcedm_edm_denoise_backward_bucketed", "mcedm_unet_grad_buckets", "mcedm_sqnorm",
     "mcedm_adam_ema_step",
-    "mcedm_swe_fv_step", "mcedm_swe_fv_residual", "mcedm_darcy_residual",
+    "mcedm_swe_fv_step", "mcedm_swe_fv_residual", "mcedm_darcy_residual", "mcedm_swe_fv_guidance", "mcedm_darcy_guidance",
+    "mcedm_heun_sample_guided",
     "mcedm_ddpm_plan_create", "mcedm_ddpm_plan_destroy", "mcedm_ddpm_param_count", "mcedm_ddpm_param_info",
     "mcedm_ddpm_packed_bytes", "mcedm_ddpm_pack_weights", "mcedm_ddpm_workspace_bytes", "mcedm_ddpm_forward",
     "mcedm_ddpm_denoise", "mcedm_repaint_schedule", "mcedm_repaint_workspace_bytes", "mcedm_repaint_sample",
@@ -42,6 +43,11 @@ class SamplerDesc(C.Structure):
                 ("S_churn", C.c_double), ("S_min", C.c_double), ("S_max", C.c_double), ("S_noise", C.c_double),
                 ("w", C.c_double), ("sigma_data", C.c_double), ("net_sigma_min", C.c_double),
                 ("net_sigma_max", C.c_double)]
+
+
+class GuidanceDesc(C.Structure):
+    _fields_ = [("system", C.c_int32), ("half_dt", C.c_float), ("dx", C.c_float), ("two_dx", C.c_float), ("sub_h", C.c_float),
+                ("div_h", C.c_float), ("sub_u", C.c_float), ("div_u", C.c_float), ("weight", C.c_double)]
 
 
 class DdpmDesc(C.Structure):
@@ -106,6 +112,10 @@ def load() -> C.CDLL:
     lib.mcedm_swe_fv_residual.argtypes = [f32p, f32p, f32p, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float,
                                           i32, vp]
     lib.mcedm_darcy_residual.argtypes = [f32p, f32p, i32, i32, C.c_float, C.c_float, i32, vp]
+    lib.mcedm_swe_fv_guidance.argtypes = [f32p, f32p, f32p, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    lib.mcedm_darcy_guidance.argtypes = [f32p, f32p, f32p, i32, i32, C.c_float, i32, vp]
+    lib.mcedm_heun_sample_guided.argtypes = [vp, vp, C.POINTER(SamplerDesc), C.POINTER(GuidanceDesc), f32p, f32p, f32p, f64p,
+                                             f64p, i32, vp, sz, i32, i32, i32, vp]
     lib.mcedm_ddpm_plan_create.argtypes = [C.POINTER(DdpmDesc), C.POINTER(vp)]
     lib.mcedm_ddpm_plan_destroy.argtypes = [vp]
     lib.mcedm_ddpm_plan_destroy.restype = None
@@ -305,7 +315,8 @@ class Plan:
                                                             _stream()), "edm_denoise_backward_bucketed")
 
     def sample(self, packed, sd: SamplerDesc, cond, mask, init_noise, step_noise=None, return_last: bool = True,
-               ws: Optional[Workspace] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               ws: Optional[Workspace] = None, out: Optional[torch.Tensor] = None,
+               guidance: Optional["GuidanceDesc"] = None) -> torch.Tensor:
         B, _, H, W = init_noise.shape
         ws = ws or Workspace()
         buf = ws.get(self.sampler_workspace_bytes(B, H, W), init_noise.device)
@@ -314,6 +325,12 @@ class Plan:
             out = torch.empty((B, T, H, W, self.in_channels), dtype=torch.float64, device=init_noise.device)
         elif tuple(out.shape) != (B, T, H, W, self.in_channels):
             raise RuntimeError(f"sample: out has shape {tuple(out.shape)}, expected {(B, T, H, W, self.in_channels)}")
+        if guidance is not None:
+            check(self._lib.mcedm_heun_sample_guided(self._h, packed.data_ptr(), C.byref(sd), C.byref(guidance), _ptr(cond),
+                                                     _ptr(mask), _ptr(init_noise), _ptr(step_noise, torch.float64),
+                                                     _ptr(out, torch.float64), int(return_last), buf.data_ptr(), buf.numel(),
+                                                     B, H, W, _stream()), "heun_sample_guided")
+            return out
         check(self._lib.mcedm_heun_sample(self._h, packed.data_ptr(), C.byref(sd), _ptr(cond), _ptr(mask),
                                           _ptr(init_noise), _ptr(step_noise, torch.float64), _ptr(out, torch.float64),
                                           int(return_last), buf.data_ptr(), buf.numel(), B, H, W, _stream()),
@@ -529,6 +546,24 @@ def swe_fv_residual(pred, gt, half_dt: float, dx: float, scale2_h: float, scale2
     out = torch.empty_like(pred)
     check(load().mcedm_swe_fv_residual(_ptr(pred), _ptr(gt), _ptr(out), B, T, X, half_dt, dx, scale2_h, scale2_u, int(clamp),
                                        _stream()), "swe_fv_residual")
+    return out
+
+
+def swe_fv_guidance(pred, gt, half_dt: float, dx: float, scale2_h: float, scale2_u: float) -> torch.Tensor:
+    """SweFvLoss.forward(return_d=True): d mean(residual) / d pred on (b, t, x, 2) fp32 states."""
+    B, T, X, _ = pred.shape
+    out = torch.empty_like(pred)
+    check(load().mcedm_swe_fv_guidance(_ptr(pred), _ptr(gt), _ptr(out), B, T, X, half_dt, dx, scale2_h, scale2_u, _stream()),
+          "swe_fv_guidance")
+    return out
+
+
+def darcy_guidance(pred, two_dx: float, calc_prob: bool) -> torch.Tensor:
+    B, S = pred.shape[0], pred.shape[1]
+    out = torch.empty_like(pred)
+    scratch = torch.empty(B * (S - 4) * (S - 4), dtype=torch.float32, device=pred.device)
+    check(load().mcedm_darcy_guidance(_ptr(pred), _ptr(out), _ptr(scratch), B, S, two_dx, int(calc_prob), _stream()),
+          "darcy_guidance")
     return out
 
 

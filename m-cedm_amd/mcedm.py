@@ -10,7 +10,8 @@ callbacks) stays in Python like the reference's.
 Deliberate differences, all documented in INTEGRATION.md:
   * sample_edm draws the per-step churn noise only for steps with gamma > 0 (the reference draws and
     multiplies by zero otherwise, mcedm.py:608), so device RNG streams differ for S_churn = 0;
-  * PDE guidance (guide_dx / dx_cond) is outside the hot path and raises NotImplementedError.
+  * guide_dx=True raises: the reference's joint-model guidance hook itself raises (models/mcedm.py:500-518 slices the
+    wrong axis); PDE guidance runs on the device for the single-task sampler (mcedm_amd.ddim.PlCondEdm).  dx_cond is not built.
 """
 from __future__ import annotations
 
@@ -299,7 +300,12 @@ class PlMcedm(_Base):
     # ---- sampling -------------------------------------------------------------------------------------
     def sample_edm(self, hu, cond, hu_mask, sparams, return_last=True, guide_dx=False):
         if guide_dx:
-            raise NotImplementedError("guide_dx=True (PDE guidance) is outside the hot path")
+            # The reference's own hook for the JOINT model fails: get_dx_pde (models/mcedm.py:500-518) slices the last axis
+            # of the NCHW state (`x_denoised[..., 0:h_ch]`) and SweFvLoss then raises "Sizes of tensors must match"
+            # (pinned in tests/golden/guided.npz: joint_model_guidance_raises).  Device-side PDE guidance is built where the
+            # reference's works: the single-task sampler, mcedm_amd.ddim.PlCondEdm.sample_edm(guide_dx=True).
+            raise NotImplementedError("guide_dx=True: the joint model's guidance hook raises in the reference "
+                                      "(models/mcedm.py:500-518); use PlCondEdm.sample_edm(guide_dx=True)")
         model = self.ema_model if self.ema_model is not None else self.model
         net = self._net(model)
         n_state = self.h_ch + self.u_ch

@@ -2,8 +2,8 @@
 
 ``SweFvLoss`` / ``DarcyLoss`` keep the reference's constructor and ``forward(pred, gt, normalizer_h, normalizer_u,
 return_d=False, calc_prob=False, clamp_loss=False)`` signature and return bit-identical tensors; the stencil work runs
-in ``libmcedm_hip.so`` (csrc/pde.hip).  ``return_d=True`` (the guidance gradient) is not built
-yet and raises.  ``get_pde_loss_function`` mirrors ``models/loss_helper.py:16-38``.
+in ``libmcedm_hip.so`` (csrc/pde.hip).  ``return_d=True`` (the guidance gradient) runs the stencils' analytic adjoints
+(csrc/pde.hip) and agrees with the reference's autograd result to rounding.  ``get_pde_loss_function`` mirrors ``models/loss_helper.py:16-38``.
 """
 import numpy as np
 import torch
@@ -71,11 +71,29 @@ class SweFvLoss(nn.Module):
         return lib.swe_fv_residual(pred, gt, float(np.float32(0.5 * dt)), self._dx(pred.shape[2]), float(scale[0]),
                                    float(scale[1]), clamp_loss)
 
+    def _scales(self, normalizer_h, normalizer_u):
+        scale = self.get_scaling(normalizer_h, normalizer_u).to(torch.float32).reshape(-1).cpu()
+        if scale.numel() != 2:
+            raise NotImplementedError("per-channel normaliser statistics with more than one channel per field")
+        return float(scale[0]), float(scale[1])
+
+    def guidance_desc(self, normalizer_h, normalizer_u, n_times: int, nx: int, weight: float = 5.0):
+        """C description of this residual for the guided sampler (mcedm_heun_sample_guided)."""
+        if self.flip_xy:
+            raise NotImplementedError("flip_xy with device-side guidance")
+        sub = [float(normalizer_h.subtract), float(normalizer_u.subtract)]
+        div = [float(normalizer_h.divide), float(normalizer_u.divide)]
+        return lib.GuidanceDesc(1, float(np.float32(0.5 * (self.Tn / n_times))), self._dx(nx), 0.0, sub[0], div[0], sub[1], div[1],
+                                float(weight))
+
     def forward(self, pred, gt, normalizer_h, normalizer_u, return_d=False, calc_prob=False, clamp_loss=False):
-        if return_d:
-            raise NotImplementedError("the guidance gradient of the PDE residual (return_d=True) is outside the built path")
         if self.flip_xy:
             pred, gt = flip_state(pred, gt, normalizer_h, normalizer_u)
+        if return_d:           # the guidance gradient (models/pde_loss.py:231-242); calc_prob is ignored by the reference here
+            pred, gt = _f32(pred), _f32(gt)
+            s2h, s2u = self._scales(normalizer_h, normalizer_u)
+            dt = self.Tn / pred.shape[1]
+            return lib.swe_fv_guidance(pred, gt, float(np.float32(0.5 * dt)), self._dx(pred.shape[2]), s2h, s2u)
         return self.calculate_loss(pred, gt, normalizer_h, normalizer_u, clamp_loss)
 
 
@@ -92,15 +110,24 @@ class DarcyLoss(nn.Module):
         self.D = 1.0
         self.eps = 1e-8
 
+    def guidance_desc(self, normalizer_h, normalizer_u, n_times: int, nx: int, weight: float = 5.0):
+        if self.flip_xy:
+            raise NotImplementedError("flip_xy with device-side guidance")
+        if n_times != nx:
+            raise ValueError("DarcyLoss expects a square grid")
+        sub = [float(normalizer_h.subtract), float(normalizer_u.subtract)]
+        div = [float(normalizer_h.divide), float(normalizer_u.divide)]
+        return lib.GuidanceDesc(2, 0.0, 0.0, float(np.float32(2 * (self.D / nx))), sub[0], div[0], sub[1], div[1], float(weight))
+
     def forward(self, pred, gt, normalizer_h, normalizer_u, return_d=False, calc_prob=False, clamp_loss=False):
-        if return_d:
-            raise NotImplementedError("the guidance gradient of the PDE residual (return_d=True) is outside the built path")
         if self.flip_xy:
             pred, gt = flip_state(pred, gt, normalizer_h, normalizer_u)
         pred = _f32(pred)
         size = pred.shape[1]
         if pred.shape[2] != size or pred.shape[-1] != 2:
             raise ValueError("DarcyLoss expects (b, s, s, 2) = (a, u)")
+        if return_d:           # the guidance gradient (models/pde_loss.py:60-75)
+            return lib.darcy_guidance(pred, float(np.float32(2 * (self.D / size))), bool(calc_prob))
         n = size - 4
         return lib.darcy_residual(pred, float(np.float32(2 * (self.D / size))), float(n * n), clamp_loss)
 

@@ -169,7 +169,7 @@ def cond_training_inputs(B: int = 3, T: int = 32, X: int = 32):
 
 # ---- PDE residuals: (b, t, x) sizes, Tn, x range -----------------------------------
 PDE_SWE_CASES = {"per32": (3, 32, 32, 0.128, -0.5, 0.5), "dam128": (2, 128, 128, 1.28, -2.5, 2.5), "ragged": (2, 5, 37, 0.128, -0.5, 0.5)}
-PDE_DARCY_CASES = {"d32": (3, 32), "d128": (2, 128), "d7": (2, 7)}
+PDE_DARCY_CASES = {"d32": (3, 32), "d128": (2, 128), "d7": (2, 7), "d32fit": (2, 32)}
 
 
 def pde_swe_inputs(name):
@@ -187,6 +187,13 @@ def pde_swe_inputs(name):
 
 def pde_darcy_inputs(name):
     B, S = PDE_DARCY_CASES[name]
+    if name == "d32fit":
+        # a nearly exact solution (a = 1, u = -x^2/2 + small ripple: -div(a grad u) = 1 + O(3e-3)), so that the log-probability
+        # form of the guidance (sigmoid(1e5 * residual^2), models/pde_loss.py:68-70) is in its non-saturated range
+        xs = (torch.arange(S, dtype=torch.float64) + 0.5) / S
+        X, Y = torch.meshgrid(xs, xs, indexing="ij")
+        u = torch.stack([-(X ** 2) / 2 + a * 1e-4 * torch.sin(2 * np.pi * X) * torch.sin(2 * np.pi * Y) for a in (1.0, -0.7)][:B])
+        return torch.stack((torch.ones(B, S, S, dtype=torch.float64), u), dim=-1).float()
     a = 1.0 + 0.5 * torch.from_numpy(uniform(f"pde/darcy/{name}/a", B, S, S).astype(np.float32))
     u = 0.1 * randn(f"pde/darcy/{name}/u", B, S, S)
     return torch.stack((a, u), dim=-1)

@@ -41,5 +41,25 @@ for name, (B, S) in fx.PDE_DARCY_CASES.items():
         o = po.darcy_residual(pred, clamp)
         assert torch.equal(r, o), (name, clamp)
         out[f"darcy_{name}_clamp{int(clamp)}"] = r.numpy()
+# ---- guidance gradients: forward(..., return_d=True) (models/pde_loss.py:231-242, 60-75) ---------------------------------
+for name, (B, T, X, Tn, xmin, xmax) in fx.PDE_SWE_CASES.items():
+    pred, gt, sh, su = fx.pde_swe_inputs(name)
+    ref = SweFvLoss(Tn=Tn, x_min=xmin, x_max=xmax)
+    nh, nu = Normalizer(0.0, sh), Normalizer(0.0, su)
+    for tag, target in (("self", pred), ("gt", gt)):          # the sampler passes the state as its own target
+        r = ref(pred.clone(), target.clone(), nh, nu, return_d=True, calc_prob=True)
+        o = po.swe_fv_guidance(pred, target, sh, su, Tn, xmin, xmax, 2)
+        assert torch.equal(r, o), (name, tag, float((r - o).abs().max()))
+        out[f"swe_{name}_d_{tag}"] = r.numpy()
+for name, (B, S) in fx.PDE_DARCY_CASES.items():
+    if S < 8:
+        continue
+    pred = fx.pde_darcy_inputs(name)
+    ref = DarcyLoss()
+    for prob in (False, True):
+        r = ref(pred.clone(), pred.clone(), None, None, return_d=True, calc_prob=prob)
+        o = po.darcy_guidance(pred, prob)
+        assert torch.equal(r, o), (name, prob, float((r - o).abs().max()))
+        out[f"darcy_{name}_d_prob{int(prob)}"] = r.numpy()
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pde.npz"), **out)
 print("wrote tests/golden/pde.npz:", {k: v.shape for k, v in out.items()})

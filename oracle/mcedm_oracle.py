@@ -383,10 +383,28 @@ class SamplerParams:
     w: float = 0.0
 
 
+def guidance_dx_cond(system: str, h: Tensor, denoised: Tensor, norm_stats) -> Tensor:
+    """get_dx_log_prob(h, denoised, guide_dx=True) of the single-task models (models/ddim.py:641-650 -> get_dx_pde
+    :1424-1450 with calc_prob=True): gradient of the PDE residual of x_unnorm = (h, u = denoised) w.r.t. x_unnorm, then the
+    mean over the two field gradients -> [B, 1, H, W] fp32.  norm_stats = (input mean, std, target mean, std)."""
+    from . import pde_oracle as po
+    st = [torch.as_tensor(s, dtype=torch.float32) for s in norm_stats]
+    hh = h[:, :1].to(torch.float32).permute(0, 2, 3, 1)
+    uu = denoised.to(torch.float32).permute(0, 2, 3, 1)
+    x_un = torch.cat([hh * st[1] + st[0], uu * st[3] + st[2]], dim=-1)
+    if system == "darcy":
+        d = po.darcy_guidance(x_un, calc_prob=True)
+    else:
+        Tn, lo, hi = (0.128, -0.5, 0.5) if system == "swe_per" else (1.28, -2.5, 2.5)
+        d = po.swe_fv_guidance(x_un, x_un, st[1], st[3], Tn, lo, hi, 2)
+    return torch.mean(d.permute(0, 3, 1, 2), dim=1, keepdim=True)
+
+
 def sample_edm_cond(P, cfg, h: Tensor, sp: SamplerParams, init_noise: Tensor,
-                    step_noise: Optional[Sequence[Tensor]] = None, return_last: bool = True) -> Tensor:
+                    step_noise: Optional[Sequence[Tensor]] = None, return_last: bool = True, guidance=None) -> Tensor:
     """PlCondEdm.sample_edm, models/ddim.py:1532-1601 (guide_dx False, no self-conditioning): the unmasked Heun
-    sampler; ``h`` [B, cond_ch, H, W] is pure conditioning, ``init_noise`` [B, out_ch, H, W]."""
+    sampler; ``h`` [B, cond_ch, H, W] is pure conditioning, ``init_noise`` [B, out_ch, H, W].
+    ``guidance`` (guide_dx=True): callable (h, denoised[f64]) -> dx [B, 1, H, W] fp32, see guidance_dx_cond."""
     N = sp.timesteps
     t_steps = edm_t_steps(N, sp.sigma_min, sp.sigma_max, sp.rho)
     x_next = init_noise.to(torch.float64) * t_steps[0]
@@ -399,10 +417,14 @@ def sample_edm_cond(P, cfg, h: Tensor, sp: SamplerParams, init_noise: Tensor,
         x_hat = x_next + (t_hat ** 2 - t_cur ** 2).sqrt() * sp.S_noise * eps_i
         denoised = get_denoised(P, cfg, x_hat, t_hat, cond=h, w=sp.w)[0].to(torch.float64)
         d_cur = (x_hat - denoised) / t_hat
+        if guidance is not None:                 # guide_dx: - weight * dx / t_hat, weight = 5 (ddim.py:1577-1579)
+            d_cur = d_cur - 5. * guidance(h, denoised) / t_hat
         x_next = x_hat + (t_next - t_hat) * d_cur
         if i < N - 1:
             denoised = get_denoised(P, cfg, x_next, t_next, cond=h, w=sp.w)[0].to(torch.float64)
             d_prime = (x_next - denoised) / t_next
+            if guidance is not None:             # the reference divides by t_hat here too (ddim.py:1590-1591)
+                d_prime = d_prime - 5. * guidance(h, denoised) / t_hat
             x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
         xs = [x_next] if return_last else xs + [x_next]
     return torch.stack(xs, dim=0).permute(1, 0, 3, 4, 2).contiguous()

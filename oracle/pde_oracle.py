@@ -79,3 +79,40 @@ def darcy_residual(pred, clamp_loss=False, D=1.0):
     if clamp_loss:
         loss = torch.clamp(loss, max=1.0)
     return loss
+
+
+# --------------------------------------------------------------------------- #
+# guidance gradients: the return_d=True branches
+# --------------------------------------------------------------------------- #
+def swe_fv_guidance(pred, gt, scale_h, scale_u, Tn=0.128, x_min=-2.5, x_max=2.5, n_ghosts=2):
+    """SweFvLoss.forward(return_d=True), models/pde_loss.py:231-242: d mean(calculate_loss(pred, gt)) / d pred with NaNs
+    of the gradient set to zero.  `gt` carries no gradient (the caller passes the same values as a separate tensor)."""
+    with torch.enable_grad():
+        p = pred.detach().clone().requires_grad_(True)
+        loss = swe_fv_residual(p, gt.detach(), scale_h, scale_u, Tn, x_min, x_max, n_ghosts, clamp_loss=False).mean()
+        d = torch.autograd.grad(loss, p)[0]
+    d[torch.isnan(d)] = 0.0
+    return d
+
+
+def darcy_guidance(pred, calc_prob=False, D=1.0):
+    """DarcyLoss.forward(return_d=True), models/pde_loss.py:60-75: gradient of mean(L) or, with calc_prob, of
+    mean(log(2 (1 - sigmoid(1e5 L)) + 1e-12)), L = (Du - 1)^2 (NOT divided by the number of locations)."""
+    with torch.enable_grad():
+        p = pred.detach().clone().requires_grad_(True)
+        b, size = p.shape[0], p.shape[1]
+        a = p[..., 0].reshape(b, size, size)
+        u = p[..., 1].reshape(b, size, size)
+        dx = D / size
+        ux = (u[:, 2:, 1:-1] - u[:, :-2, 1:-1]) / (2 * dx)
+        uy = (u[:, 1:-1, 2:] - u[:, 1:-1, :-2]) / (2 * dx)
+        ai = a[:, 1:-1, 1:-1]
+        aux, auy = ai * ux, ai * uy
+        auxx = (aux[:, 2:, 1:-1] - aux[:, :-2, 1:-1]) / (2 * dx)
+        auyy = (auy[:, 1:-1, 2:] - auy[:, 1:-1, :-2]) / (2 * dx)
+        L = (-(auxx + auyy) - 1.0) ** 2
+        if calc_prob:
+            L = torch.log(2 * (1.0 - torch.sigmoid(1e5 * L)) + 1e-12)
+        d = torch.autograd.grad(L.mean(), p)[0]
+    d[torch.isnan(d)] = 0.0
+    return d

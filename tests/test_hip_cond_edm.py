@@ -76,3 +76,43 @@ def test_training_step_golden(module, golden, monkeypatch):
     for n in fx.COND_GRAD_NAMES:
         ref = torch.as_tensor(g[f"grad::{n}"])
         close(grads[n].grad, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("system", ["swe_per", "darcy"])
+def test_sample_edm_pde_guidance_golden(module, golden, monkeypatch, system):
+    """guide_dx=True in the single-task sampler (models/ddim.py:1577-1579, 1589-1591): the PDE-residual
+    gradient is evaluated on the device after every denoiser call.  Golden = the reference's own guided trajectories."""
+    m = module
+    g = golden("guided.npz")
+    st = fx.STEP_NORM_STATS
+    m.normalizer_input.set_stats(torch.tensor(st[0]), torch.tensor(st[1]))
+    m.normalizer_target.set_stats(torch.tensor(st[2]), torch.tensor(st[3]))
+    m.set_pde_loss_function(system, False)
+    h, u_noise, steps = fx.cond_sampler_inputs("det")
+    sp = cond_hparams(guide_dx=True).sampler
+    xs = m.sample_edm(h.cuda(), u_noise.cuda(), sp, return_last=False, guide_dx=True)
+    ref = torch.as_tensor(g[f"{system}_xs_last"])
+    scale = float(ref.abs().max())
+    err = float((xs[:, -1:].cpu() - ref).abs().max())
+    x0 = m.sample_edm(h.cuda(), u_noise.cuda(), sp, return_last=True, guide_dx=False)
+    moved = float((x0.cpu() - ref).abs().max())
+    print(f"guided sampler {system}: max|d| = {err:.3e}, max|x| = {scale:.1f}, guidance moved the sample by {moved:.3e}")
+    # the Darcy log-probability gradient is a near-step function of the residual (sigmoid(1e5 L)): trajectories are compared
+    # at 1e-3 of the state scale there, at the north_star tolerance for the smooth SWE residual
+    tol = dict(rtol=1e-3, atol=1e-3 * scale) if system == "darcy" else dict(rtol=1e-4, atol=1e-5 * scale)
+    close(xs[:, -1:], ref, **tol)
+    close(xs[:, ::6], g[f"{system}_xs_traj"], **tol)
+    assert moved > 10 * err, "the guided and unguided samples must differ by far more than the parity error"
+
+
+def test_joint_model_guidance_is_rejected_like_the_reference(golden):
+    """PlMcedm.sample_edm(guide_dx=True) raises in the reference (models/mcedm.py:500-518 slices the wrong axis); the
+    drop-in refuses it too instead of inventing semantics."""
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd.mcedm import PlMcedm
+    from tests.test_hip_module import hparams as joint_hparams
+    assert int(golden("guided.npz")["joint_model_guidance_raises"]) == 1
+    m = PlMcedm(joint_hparams(fx.CFG_P)).cuda()
+    z = torch.zeros(2, 2, 32, 32, device="cuda")
+    with pytest.raises(NotImplementedError, match="raises in the reference"):
+        m.sample_edm(z, z, z, joint_hparams(fx.CFG_P).sampler, guide_dx=True)

@@ -123,8 +123,12 @@ def test_plddim_module_golden(golden, monkeypatch):
         for n, p in m.ema_model.ma_model.named_parameters():
             p.copy_(P[n])
     m.set_test_sampler_params(sp)
-    assert torch.equal(m.edm_steps, torch.as_tensor(g["edm_steps"]))
-    assert torch.equal(m.compute_alpha(torch.tensor([0, 80, 999])).flatten(), torch.as_tensor(g["alphas_ext"])[[1, 81, 1000]])
+    # the schedule tables are CPU tensor arithmetic of the host (like the reference's): same expression, last-bit
+    # differences between hosts are possible, so they are compared to 2 ulp, not bitwise
+    es, ae = torch.as_tensor(g["edm_steps"]), torch.as_tensor(g["alphas_ext"])
+    print(f"edm_steps max rel diff vs golden: {float(((m.edm_steps - es).abs() / es).max()):.2e}")
+    torch.testing.assert_close(m.edm_steps, es, rtol=3e-7, atol=0)
+    torch.testing.assert_close(m.compute_alpha(torch.tensor([0, 80, 999])).flatten(), ae[[1, 81, 1000]], rtol=3e-7, atol=0)
     x = fx.randn("ddpm/x", 3, 2, CFG.resolution, CFG.resolution)
     s = fx.DDPM_SIGMAS[1]
     D, F = m.get_denoised(m.ema_model, (x * (1 + s)).double().cuda(), torch.tensor(s, dtype=torch.float64), w=0.0)
