@@ -216,12 +216,19 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
                                             const InputRegs<C, RS>& R0, int c0, int tid, const Coef* cfl = nullptr) {
   const int Cin = p.Ca + p.Cb;
   const InputRegs<C, RS>& R = R0;
+  // The transform rows of this sample were staged in LDS by the caller (wave-uniform broadcast reads).  All KCI rows are
+  // fetched up front (their LDS latencies overlap; fetched channel by channel behind the per-channel scheduling barrier
+  // below, each read's latency is exposed: measured -15 % on the small tiles) unless KCI is large (3 registers per row).
+  constexpr bool PRELOAD = C::KCI <= 16;
+  Coef rows[PRELOAD ? C::KCI : 1];
+  if (PRELOAD && cfl) {
+#pragma unroll
+    for (int cil = 0; cil < C::KCI; ++cil) rows[cil] = cfl[c0 + cil < Cin ? c0 + cil : Cin - 1];
+  }
 #pragma unroll
   for (int cil = 0; cil < C::KCI; ++cil) {
     const int ci = c0 + cil;
-    // this channel's transform row: staged in LDS by the caller (wave-uniform broadcast read, one row live at a time:
-    // preloading all KCI rows costs 3 * KCI registers) or carried in the staging registers
-    const Coef cfr = cfl ? cfl[ci < Cin ? ci : Cin - 1] : R0.cf[cil];
+    const Coef cfr = cfl ? (PRELOAD ? rows[PRELOAD ? cil : 0] : cfl[ci < Cin ? ci : Cin - 1]) : R0.cf[cil];
     const bool chan_ok = (ci < Cin) && ((ci < p.Ca ? p.xa : p.xb) != nullptr);
     const unsigned ckeep = chan_ok ? 0xffffffffu : 0u;
 #pragma unroll
@@ -250,9 +257,8 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
       if ((sub + 1) * C::NT <= C::PLANE || tid + sub * C::NT < C::PLANE) xl[cil * C::PLANE + tid + sub * C::NT] = v;
     }
     // one channel at a time: left alone, the scheduler interleaves all KC SiLU chains of this straight-line code
-    // and pays for the extra live values with accumulator spills.  Small tiles (few accumulators, one element per
-    // thread) have the registers to overlap the channels' LDS reads and transcendental chains instead.
-    if constexpr (C::TM * C::TN > 1) __builtin_amdgcn_sched_barrier(0);
+    // and pays for the extra live values with accumulator spills
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

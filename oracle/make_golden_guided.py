@@ -40,10 +40,15 @@ def main():
             xo = orc.sample_edm_cond(P, cfg, hc, orc.SamplerParams(), u_noise.permute(0, 3, 1, 2), steps, return_last=False,
                                      guidance=lambda hh, d: orc.guidance_dx_cond(system, hh, d, st))
             x0 = orc.sample_edm_cond(P, cfg, hc, orc.SamplerParams(), u_noise.permute(0, 3, 1, 2), steps)
+            x0_all = orc.sample_edm_cond(P, cfg, hc, orc.SamplerParams(), u_noise.permute(0, 3, 1, 2), steps, return_last=False)
         mg.check(f"PlCondEdm.sample_edm guide_dx {system}", xo, xs, rtol=1e-4, atol=1e-5 * float(xs.abs().max()))
         print(f"  guidance moves the sample by max {float((xs[:, -1:] - x0).abs().max()):.3e} (max|x| {float(xs.abs().max()):.2f})")
         out[f"{system}_xs_last"] = xs[:, -1:].contiguous()
         out[f"{system}_xs_traj"] = xs[:, ::6].contiguous()
+        out[f"{system}_xs_head"] = xs[:, :3].contiguous()
+        first = next((k for k in range(xs.shape[1]) if float((xs[:, k] - torch.as_tensor(x0_all[:, k])).abs().max()) > 0), -1)
+        print(f"  first trajectory entry the guidance changes: {first}")
+        out[f"{system}_first_guided_entry"] = torch.tensor(first)
     # the joint model's hook fails in the reference: record that fact (not a vector)
     pl = mg.build_reference(fx.CFG_P, seed=7, sampler=mg.sampler_dict(guide_dx=True))
     pl.set_pde_loss_function("swe_per", False)

@@ -88,8 +88,9 @@ def test_hip_swe_flip_and_full_size_properties(pde):
     ff = pde.SweFvLoss(Tn=0.128, x_min=-0.5, x_max=0.5, flip_xy=True)
     r2 = ff(s.flip(-1), gt.flip(-1), Norm(torch.tensor(1.0).cuda()), Norm(torch.tensor(1.0).cuda()))
     assert float(r2.abs().max()) == 0.0
-    with pytest.raises(NotImplementedError):
-        f(s, gt, Norm(torch.tensor(1.0).cuda()), Norm(torch.tensor(1.0).cuda()), return_d=True)
+    # at an exact fixed point of the residual (gt = one FORCE step of the state) the guidance gradient vanishes
+    d = f(s, gt, Norm(torch.tensor(1.0).cuda()), Norm(torch.tensor(1.0).cuda()), return_d=True)
+    assert tuple(d.shape) == tuple(s.shape) and float(d.abs().max()) == 0.0
 
 
 # ---- guidance gradients: forward(..., return_d=True) ---------------------------------------------
