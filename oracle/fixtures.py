@@ -253,3 +253,52 @@ def repaint_inputs(tag: str):
     steps = [randn(f"repaint/{tag}/step{i}", B, 2, S, S).double() for i in range(N)]
     reps = [[randn(f"repaint/{tag}/rep{i}_{k}", B, 2, S, S).double() for k in range(R - 1)] for i in range(N)]
     return h, u, init, steps, reps
+
+
+# ---- on-disk formats: a synthetic sample tree in the reference's HDF5 layout -------------------
+DATA_SEED = 1234
+# tag -> (reference dataset class, constructor keywords)
+DATA_CASES = {
+    "plain": ("HDF5Dataset", dict(return_abs_coords=False, return_grid=False)),
+    "grid_flip": ("HDF5Dataset", dict(return_abs_coords=True, return_grid=True, flip_xy=True, norm_x=True, norm_t=True)),
+    "theta_ic": ("HDF5Dataset", dict(return_abs_coords=True, return_grid=False, use_theta=True, use_tar_ic=True)),
+    "down_interp": ("HDF5Dataset", dict(return_abs_coords=False, return_grid=False, down_factor=2, down_interp=True)),
+    "down_small": ("HDF5Dataset", dict(return_abs_coords=True, return_grid=False, down_factor=2, down_interp=False)),
+    "mask_train": ("HDF5MaskDataset", dict(return_abs_coords=True, return_grid=True, is_train=True)),
+    "mask_eval": ("HDF5MaskDataset", dict(return_abs_coords=True, return_grid=True, is_train=False)),
+    "time_train": ("HDF5TimeMaskDataset", dict(return_abs_coords=True, return_grid=True, is_train=True)),
+    "time_eval": ("HDF5TimeMaskDataset", dict(return_abs_coords=True, return_grid=True, is_train=False, add_time_masks=True)),
+    "sparse_train": ("HDF5SparseMaskDataset", dict(return_abs_coords=True, return_grid=True, is_train=True)),
+    "sparse_eval": ("HDF5SparseMaskDataset", dict(return_abs_coords=True, return_grid=True, is_train=False, add_res_masks=True)),
+}
+
+
+def data_tree(n: int = 5, T: int = 16, X: int = 16):
+    """{seed: {"data": {"input", "target"}, "grid": {"x", "t"}, "const": {...}}} + the file attributes, as numpy arrays
+    (float64 on disk like the reference's generator writes them; t carries the extra final step some simulators store)."""
+    tree = {}
+    for i in range(n):
+        seed = f"{1000 + 7 * i}"
+        inp = 1.4 + 0.2 * randn(f"data/{seed}/inp", T, X, 1).double().numpy()
+        tar = 0.5 * randn(f"data/{seed}/tar", T, X, 1).double().numpy()
+        tree[seed] = {"data": {"input": inp, "target": tar},
+                      "grid": {"x": np.linspace(-0.5, 0.5, X, endpoint=False) + 0.5 / X, "t": np.linspace(0.0, 0.128, T + 1)},
+                      "const": {"g": np.array([1.0 + 0.1 * i]), "nu": np.array([0.01 * (i + 1)])}}
+    allin = np.stack([v["data"]["input"] for v in tree.values()])
+    alltar = np.stack([v["data"]["target"] for v in tree.values()])
+    attrs = {"inp_mean": allin.mean(), "inp_std": allin.std(), "tar_mean": alltar.mean(), "tar_std": alltar.std(),
+             "inp_min": allin.min(), "inp_max": allin.max(), "tar_min": alltar.min(), "tar_max": alltar.max()}
+    return tree, attrs
+
+
+def data_tree_flat():
+    """The same tree in the flattened form mcedm_amd.data.NpzStore reads."""
+    tree, attrs = data_tree()
+    flat = {}
+    for seed, grp in tree.items():
+        for a, sub in grp.items():
+            for b, arr in sub.items():
+                flat[f"{seed}/{a}/{b}"] = np.asarray(arr)
+    for k, v in attrs.items():
+        flat[f"__attrs__/{k}"] = np.asarray(v)
+    return flat
