@@ -116,6 +116,12 @@ struct ConvArgs {
   SumTiles* gsum_tiles;   // host out: the tiling the launcher used (rows of gsum per sample, tile shape)
   // gn_on: the kernel derives this sample's transform rows itself from the producers' per-tile (sum, sumsq) tables
   // (gn.suma / gn.sumb ...; gn.coef / gn.stats / gn.xa / gn.xb are not used), so no GroupNorm kernel runs at all
+  // Optional second GEMM onto the same output tile: a 1x1 projection of another (un-transformed) tensor, folded into this
+  // conv as extra K chunks at the centre tap.  Used for the decoder blocks' skip projection (adm_blocks.py:150-151, 171:
+  // x = conv1(...) + skip(orig)): the projected tensor is never written or read back and one launch disappears.
+  // 3x3, un-resampled convs only.  sk_wpk: packed 1x1 weights (rows [Cin padded to 16][CoutP]); sk_bias: [Cout] or null.
+  const float* sk_xa; const float* sk_xb; int sk_Ca, sk_Cb;
+  const float* sk_wpk; const float* sk_bias;
   GnArgs gn; int gn_on;
   int coef_rows;     // set by the launcher: 1 = coef holds Ca+Cb rows (per sample if coef_batch), 0 = a single identity row
   unsigned long long* dbg;   // diagnostics only (mcedm_op_set_conv_debug): 4 timestamps (10 ns) + CU id per workgroup

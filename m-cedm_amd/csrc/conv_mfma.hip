@@ -332,13 +332,15 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[C
   __amdgpu_buffer_rsrc_t rs;
   if (MODE != 0) rs = make_rsrc(p.res + (size_t)n * p.Cout * HWr, 4u * (unsigned)p.Cout * HWr);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.bias, p.bias ? 4u * (unsigned)p.Cout : 0u);   // no bias: zero records
+  const __amdgpu_buffer_rsrc_t rb2 = make_rsrc(p.sk_bias, p.sk_bias ? 4u * (unsigned)p.Cout : 0u);   // folded skip projection's bias
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) {
     const int cbase = m0 + (wm * C::TM + i) * 32 + 4 * (lane >> 5);     // + (r&3) + 8*(r>>2)
     float bv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r)   // channels past Cout are out of the descriptor's range and read as 0
-      bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, 4u * (unsigned)(cbase + (r & 3) + 8 * (r >> 2)), 0, 0));
+      bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, 4u * (unsigned)(cbase + (r & 3) + 8 * (r >> 2)), 0, 0)) +
+              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2, 4u * (unsigned)(cbase + (r & 3) + 8 * (r >> 2)), 0, 0));
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
       const int pix = (wn * C::TN + j) * 32 + (lane & 31);
@@ -508,6 +510,82 @@ __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32
   }
 }
 
+// Folded 1x1 projection (ConvArgs::sk_*): K chunks of 8 channels of cat(sk_xa, sk_xb) at the centre tap, accumulated onto
+// the same tiles after the 3x3 loop.  The halo'd tile geometry of the 3x3 staging is reused as it is (the halo elements are
+// loaded and never read: 1.3x the loads of a dedicated 1x1 tile, on a phase that is ~20 % of the launch).
+template <class C>
+__device__ __forceinline__ void conv_skip_phase(const ConvArgs& p, const TileGeom<C, RS_NONE>& G, float* xl, float* wl,
+                                                f32x16 (&acc)[C::TM][C::TN], int n, int m0, int coutp, int aoff,
+                                                const int (&boff)[C::TN], int tid, int wave) {
+  static_assert(C::TAPS == 9, "the folded projection rides on a 3x3 conv");
+  constexpr int SUB = TileGeom<C, RS_NONE>::SUB;
+  constexpr int KS = 8;                                  // channels per iteration (xl holds KC = 8 planes)
+  constexpr int V4 = C::MT / 4;                          // float4 per weight row
+  constexpr int NV4 = KS * V4;                           // float4 of one iteration's weight rows: <= 256
+  static_assert(NV4 <= C::NT && C::KC == KS, "one float4 of the skip slab per thread");
+  const int Cin = p.sk_Ca + p.sk_Cb;
+  const int iters = (Cin + KS - 1) / KS;
+  const size_t plane = (size_t)p.H * p.W;
+  const float* safe = p.sk_xa ? p.sk_xa : p.sk_xb;
+  // the packed 1x1 table has ceil(Cin / 16) * 16 rows of coutp floats
+  const __amdgpu_buffer_rsrc_t ws = make_rsrc(p.sk_wpk + m0, 4u * (unsigned)((size_t)((Cin + 15) / 16 * 16) * coutp - m0));
+  const int wrow = tid / V4, wc4 = tid - wrow * V4;
+  const unsigned wvoff = 4u * (unsigned)((tid < NV4 ? wrow : 0) * coutp + (tid < NV4 ? wc4 : 0) * 4);
+  float raw[KS][SUB];
+  f32x4 wv;
+  auto issue = [&](int it) {
+    const int c0 = it * KS;
+#pragma unroll
+    for (int cil = 0; cil < KS; ++cil) {
+      const int ci = c0 + cil;
+      const bool in_a = ci < p.sk_Ca;
+      const float* src = in_a ? p.sk_xa : p.sk_xb;
+      const int cc = in_a ? ci : ci - p.sk_Ca;
+      const int CC = in_a ? p.sk_Ca : p.sk_Cb;
+      const bool ok = (ci < Cin) && (src != nullptr);
+      const float* pl = ok ? src + ((size_t)n * CC + cc) * plane : safe;
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub)
+        raw[cil][sub] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pl) + G.boff[sub][0]);
+    }
+    wv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, wvoff, 4u * (unsigned)(c0 * coutp), 0));
+  };
+  issue(0);
+  for (int it = 0; it < iters; ++it) {
+    const int c0 = it * KS;
+#pragma unroll
+    for (int cil = 0; cil < KS; ++cil) {
+      const int ci = c0 + cil;
+      const bool ok = (ci < Cin) && ((ci < p.sk_Ca ? p.sk_xa : p.sk_xb) != nullptr);
+      const unsigned ckeep = ok ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) {
+        const float v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, raw[cil][sub]) & (G.keep[sub] & ckeep));
+        if ((sub + 1) * C::NT <= C::PLANE || tid + sub * C::NT < C::PLANE) xl[cil * C::PLANE + tid + sub * C::NT] = v;
+      }
+    }
+    if (tid < NV4) reinterpret_cast<f32x4*>(wl)[tid] = wv;
+    __syncthreads();
+    issue(it + 1 < iters ? it + 1 : it);                  // unconditional prefetch (the last one is dropped)
+    if (wave < C::NWAVE) {
+      constexpr int CENTRE = C::PITCH * C::HALO + C::HALO;
+#pragma unroll
+      for (int kk = 0; kk < KS / 2; ++kk) {
+        float fa[C::TM], fb[C::TN];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) fa[i] = wl[aoff + 2 * kk * C::MT + i * 32];
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) fb[j] = xl[boff[j] + CENTRE + 2 * kk * C::PLANE];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <class C, int RS>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* wl, Coef* cfl, int tiles_x, int tiles_y,
                                           int mtiles, int nchunks, int coutp) {
@@ -593,6 +671,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
 #ifdef MCEDM_CONV_TIMELINE
   if (p.dbg && tid == 0) { for (int k = 0; k < 5; ++k) p.dbg[blockIdx.x * 16 + 8 + k] = seg[k]; }
 #endif
+  if constexpr (C::TAPS == 9 && RS == RS_NONE && C::CPI == 1) {
+    if (p.sk_wpk) conv_skip_phase<C>(p, geom, xl, wl, acc, n, m0, coutp, aoff, boff, tid, wave);
+  }
   // ---- epilogue: store NCHW (+ the fused GroupNorm partial sums); bias and residual are already in acc
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
   const bool full = (m0 + C::MT <= p.Cout);
@@ -1003,9 +1084,10 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
     snprintf(name, sizeof(name), "conv_mfma_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %d>, %d>", C::MT, C::PH, C::PW,
              C::WM, C::WN, C::TAPS, C::KC, C::NT, C::CPI, (int)a.resample);   // = rocprofv3's name
   const double px = (double)a.B * a.H * a.W;
-  const double flops = 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * C::TAPS;
-  const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) +
-                              (double)a.Cout * (a.Ca + a.Cb) * C::TAPS);
+  const double skc = a.sk_wpk ? (double)(a.sk_Ca + a.sk_Cb) : 0.0;      // folded 1x1 projection: its own flops and input read
+  const double flops = 2.0 * px * a.Cout * ((double)(a.Ca + a.Cb) * C::TAPS + skc);
+  const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * skc + px * a.Cout * (a.res ? 2 : 1) +
+                              (double)a.Cout * ((a.Ca + a.Cb) * C::TAPS + skc));
   ProfScope ps(name, flops, bytes, stream);
   static int extra_lds = -1;     // diagnostics: MCEDM_CONV_EXTRA_LDS bytes of unused dynamic LDS lower the occupancy
   if (extra_lds < 0) { const char* e = getenv("MCEDM_CONV_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
@@ -1172,7 +1254,7 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
     MCEDM_REQUIRE(coutp % g_force_mt == 0, "conv: forced MT=%d does not divide padded Cout=%d", g_force_mt, coutp);
     switch (id) {
       case 1281632:
-        MCEDM_REQUIRE(TAPS == 9 && a.resample == RS_NONE && a.Ca + a.Cb <= 2048, "conv: the 8-wave kernel is 3x3, not resampled");
+        MCEDM_REQUIRE(TAPS == 9 && a.resample == RS_NONE && a.Ca + a.Cb <= 2048 && !a.sk_wpk, "conv: the 8-wave kernel is 3x3, not resampled, without a folded projection");
         return launch_conv8(a, stream);
       case 1280832: return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);
       case 1280816: return launch_cfg<ConvCfg<128, 8, 16, 1, 4, TAPS, KC>>(a, stream);
@@ -1207,7 +1289,7 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
   if (a.W >= 24) {
     if (g_conv8 < 0) { const char* e = getenv("MCEDM_CONV8"); g_conv8 = e ? atoi(e) : 0; }
     // experimental 8-wave kernel (needs about one workgroup per CU); results are bit-identical to <128, 8, 32>
-    if (g_conv8 && TAPS == 9 && a.resample == RS_NONE && coutp % 128 == 0 && a.Ca + a.Cb <= 2048 &&
+    if (g_conv8 && !a.sk_wpk && TAPS == 9 && a.resample == RS_NONE && coutp % 128 == 0 && a.Ca + a.Cb <= 2048 &&
         blocks_for(128, 16, 32) >= 224)
       return launch_conv8(a, stream);
     if (coutp % 128 == 0 && blocks_for(128, 8, 32) >= want) return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);
@@ -1230,6 +1312,8 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {
                                               "conv: the stride-2 conv is 3x3 on an even-sized source, without residual");
   else MCEDM_REQUIRE(a.Hs == a.H && a.Ws == a.W, "conv: source size mismatch");
   if (a.res && a.res_mode == RS_UP) MCEDM_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0, "conv: up residual needs even size");
+  if (a.sk_wpk) MCEDM_REQUIRE(taps == 9 && a.resample == RS_NONE && a.sk_Ca + a.sk_Cb > 0 && (a.sk_xa || a.sk_xb) && a.Cout > 4,
+                              "conv: a folded 1x1 projection rides on an un-resampled 3x3 conv with more than 4 output channels");
   // 32-bit buffer offsets: one channel plane and the packed weight table must each stay below 4 GiB
   MCEDM_REQUIRE((unsigned long long)a.Hs * a.Ws * 4ull < (1ull << 32) &&
                 (unsigned long long)cout_padded(a.Cout) * (a.Ca + a.Cb + 16) * taps * 4ull < (1ull << 32),

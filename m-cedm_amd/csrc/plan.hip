@@ -405,7 +405,8 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
     lb.drop(bl.coef0); lb.drop(bl.xd);
     bl.coef1 = lb.coef(b.cout);
     if (training) bl.stats1 = lb.stats(b.norm1.groups);
-    if (b.skip_kernel == 1) bl.sk = lb.act(b.cout, bl.H, bl.W);
+    // inference folds the 1x1 skip projection into conv1 (ConvArgs::sk_*): the projected tensor exists in training only
+    if (b.skip_kernel == 1 && (training || b.up || b.down)) bl.sk = lb.act(b.cout, bl.H, bl.W);
     bl.y = lb.act(b.cout, bl.H, bl.W);
     give_sums(bl.y);
     lb.drop(bl.h); lb.drop(bl.coef1); lb.drop(bl.sk);
@@ -525,7 +526,8 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   // skip path
   const float* res = xa;
   int res_mode = RS_NONE;
-  if (b.skip_kernel == 1) {
+  const bool fold_skip = b.skip_kernel == 1 && bl.sk < 0;      // see build_layout
+  if (b.skip_kernel == 1 && !fold_skip) {
     ConvArgs cs{};
     cs.xa = xa; cs.xb = xb; cs.Ca = Ca; cs.Cb = Cb;
     cs.resample = rs; cs.Hs = bl.Hin; cs.Ws = bl.Win; cs.H = bl.H; cs.W = bl.W;
@@ -543,6 +545,11 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   c1.Hs = bl.H; c1.Ws = bl.W; c1.H = bl.H; c1.W = bl.W;
   c1.wpk = pk + b.conv1.wpk; c1.bias = pk + b.conv1.bias;
   c1.res = res; c1.res_mode = res_mode;
+  if (fold_skip) {            // y = conv1(...) + skip(orig): the projection rides on conv1 as extra K chunks
+    c1.res = nullptr; c1.res_mode = RS_NONE;
+    c1.sk_xa = xa; c1.sk_xb = xb; c1.sk_Ca = Ca; c1.sk_Cb = Cb;
+    c1.sk_wpk = pk + b.skip.wpk; c1.sk_bias = pk + b.skip.bias;
+  }
   c1.out = T(bl.y); c1.Cout = b.cout; c1.B = B; c1.gsum = SUMS(bl.y); c1.gsum_tiles = &st[bl.y];
   if ((rc = gn_for_conv(g1, c1, false, s))) return rc;
   if ((rc = launch_conv(c1, 9, s))) return rc;
