@@ -251,6 +251,8 @@ class Runner:
         lib, torch = self.lib, self.torch
         self.eager()
         torch.cuda.synchronize()
+        if steps <= 0:
+            return []
         lib.prof_enable(True)
         for _ in range(steps):
             self.eager()
@@ -334,6 +336,8 @@ def kernel_table(prof):
 
 
 def roofline_of(prof):
+    if not prof:
+        return None
     total_ms = sum(r["total_ms"] for r in prof) or 1.0
     dom = max(prof, key=lambda r: r["total_ms"])
     avg_ms = dom["total_ms"] / dom["launches"]
@@ -439,8 +443,9 @@ def main():
         "train_samples_per_sec": (B * world / (train_ms * 1e-3)) if train_ms else None,
         "roofline": roofline_of(prof), "kernels": kernel_table(prof)[:8], "csrc_digest": csrc_digest(),
     }
-    flops_state = sum(r["flops"] for r in prof) / (args.profile_steps * B)
-    line["forward_fp32_frac"] = flops_state * B * world * args.steps / elapsed / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world)
+    if prof and args.profile_steps > 0:
+        flops_state = sum(r["flops"] for r in prof) / (args.profile_steps * B)
+        line["forward_fp32_frac"] = flops_state * B * world * args.steps / elapsed / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world)
 
     # the other workloads, briefly (driver-timed numbers for BASELINE config 2 and the reference's own network)
     line["secondary"] = {}

@@ -913,68 +913,140 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
 
 // ---- output convolution (Cout <= 4) -------------------------------------------------------------------
 // The network's last 3x3 conv maps ch -> out_channels (2): on the matrix path it would fill 2 of the 32 rows of an MFMA
-// tile.  Here each thread owns one pixel of a 16 x 16 tile and CO accumulators; the staged (transformed) halo tile is
-// the B operand as above, the chunk's weights sit in LDS and are read as wave-uniform broadcasts (scalar loads
-// interleaved with the LDS reads forced an lgkmcnt(0) every few instructions: 4x slower).  fmaf chain over (channel, tap): deterministic, batch independent.
+// tile, so it is a direct fp32 kernel, and the one HBM-bound convolution of the network (268 MB in, 4 MB out at S128).
+// Workgroup = 16 x 64 output pixels of one sample; each thread owns 4 consecutive pixels of a row and CO accumulators
+// each, so one staged input value feeds up to 3 taps x 4 pixels from registers and a weight is read once per 4 pixels:
+// 4.5x fewer LDS instructions than one pixel per thread (which ran at 1.6 TB/s, LDS-issue bound).  The transformed
+// (GroupNorm + SiLU) halo tile is staged at a pitch of 72 floats with the tile's column -1 at LDS column 3, which puts
+// every thread's middle four values on a 16-byte boundary: one ds_read_b128 + two ds_read_b32 per (channel, row),
+// bank-conflict free.  fmaf chain over (channel, tap): deterministic, batch independent.
 template <int CO>
 __global__ __launch_bounds__(256) void conv_small_cout_kernel(ConvArgs p, const float* __restrict__ wpk,
                                                               const float* __restrict__ bias, int tiles_x, int tiles_y,
                                                               int nchunks, int coutp) {
-  typedef ConvCfg<32, 16, 16, 1, 4, 9, 8> C;      // geometry only (16 x 16 pixels + halo, 8 channels per chunk)
-  constexpr int NW = 9 * C::KC;                    // (tap, channel) pairs per chunk
-  __shared__ __attribute__((aligned(16))) float xl[C::XL];
+  constexpr int KC = 8, TH = 16, TW = 64, ROWS = TH + 2, COLS = TW + 2, PITCH = 72, CPLANE = ROWS * PITCH;
+  constexpr int NE = ROWS * COLS;                      // staged elements per channel
+  constexpr int SUB = (NE + 255) / 256;                // ... per thread
+  constexpr int NW = 9 * KC;
+  __shared__ __attribute__((aligned(16))) float xl[KC * CPLANE];
   __shared__ __attribute__((aligned(16))) float wl[NW * CO];    // chunk weights [tap][ci_local][CO]: broadcast reads
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  Coef* cfl = reinterpret_cast<Coef*>(dyn_lds);
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y;
   const int n = bid / tiles_y;
-  const int y0 = ty * C::PH, x0 = tx * C::PW;
-  const int py = tid / C::PW, px = tid % C::PW;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int Cin = p.Ca + p.Cb;
+  const size_t plane = (size_t)p.H * p.W;
 
-  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
-  Coef* cfl = reinterpret_cast<Coef*>(dyn_lds);
-  TileGeom<C, RS_NONE> geom;
-  make_geom<C, RS_NONE>(p, geom, y0, x0, tid);
-  InputRegs<C, RS_NONE> xin;
-  load_input<C, RS_NONE, false>(p, geom, xin, n, 0);
+  // per-thread staging slots, the same for every channel and chunk: element e = tid + k * 256 of the halo tile ->
+  // clamped byte offset inside a channel plane, validity mask, LDS index inside a channel's tile
+  unsigned soff[SUB], skeep[SUB];
+  int slds[SUB];
+#pragma unroll
+  for (int k = 0; k < SUB; ++k) {
+    const int e = tid + k * 256;
+    const int r = e / COLS, c = e - r * COLS;
+    const int y = y0 + r - 1, x = x0 + c - 1;
+    const bool live = e < NE;
+    const bool inb = live && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    soff[k] = inb ? 4u * (unsigned)(y * p.W + x) : 0u;
+    skeep[k] = inb ? 0xffffffffu : 0u;
+    slds[k] = live ? r * PITCH + c + 3 : -1;
+  }
+  const float* safe = p.xa ? p.xa : p.xb;
+  float raw[KC][SUB];
+  auto issue = [&](int ch) {
+#pragma unroll
+    for (int cil = 0; cil < KC; ++cil) {
+      const int ci = ch * KC + cil;
+      const bool in_a = ci < p.Ca;
+      const float* src = in_a ? p.xa : p.xb;
+      const int cc = in_a ? ci : ci - p.Ca;
+      const int CC = in_a ? p.Ca : p.Cb;
+      const bool ok = ci < Cin && src != nullptr;
+      const float* pl = ok ? src + ((size_t)n * CC + cc) * plane : safe;
+#pragma unroll
+      for (int k = 0; k < SUB; ++k) raw[cil][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pl) + soff[k]);
+    }
+  };
+  issue(0);
   stage_coef_rows<256>(p, n, cfl, tid);
-  __syncthreads();
   const int wrow = tid < NW ? tid : NW - 1;        // threads 0..71 carry one (tap, channel) row of CO weights
   float wreg[CO];
 #pragma unroll
   for (int co = 0; co < CO; ++co) wreg[co] = wpk[(size_t)wrow * coutp + co];
-  float acc[CO];
+  const int py = tid >> 4, px4 = (tid & 15) * 4;
+  float acc[CO][4];
 #pragma unroll
-  for (int co = 0; co < CO; ++co) acc[co] = (bias && co < p.Cout) ? bias[co] : 0.f;
-  const float* xp = xl + py * C::PITCH + px;
+  for (int co = 0; co < CO; ++co)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[co][q] = (bias && co < p.Cout) ? bias[co] : 0.f;
+  __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
-    store_input<C, RS_NONE>(p, geom, xl, xin, ch * C::KC, tid, cfl);
+#pragma unroll
+    for (int cil = 0; cil < KC; ++cil) {
+      const int ci = ch * KC + cil;
+      const bool ok = ci < Cin && ((ci < p.Ca ? p.xa : p.xb) != nullptr);
+      const Coef cf = cfl[ci < Cin ? ci : Cin - 1];
+#pragma unroll
+      for (int k = 0; k < SUB; ++k) {
+        float v = apply_coef(raw[cil][k], cf, p.act);
+        v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (ok ? skeep[k] : 0u));
+        if (slds[k] >= 0) xl[cil * CPLANE + slds[k]] = v;
+      }
+    }
     if (tid < NW) {
 #pragma unroll
       for (int co = 0; co < CO; ++co) wl[tid * CO + co] = wreg[co];
     }
     __syncthreads();
     const int chn = ch + 1 < nchunks ? ch + 1 : ch;
-    load_input<C, RS_NONE, false>(p, geom, xin, n, chn * C::KC);
+    issue(chn);
 #pragma unroll
     for (int co = 0; co < CO; ++co) wreg[co] = wpk[((size_t)chn * NW + wrow) * coutp + co];
 #pragma unroll
-    for (int cil = 0; cil < C::KC; ++cil) {
+    for (int cil = 0; cil < KC; ++cil) {
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const float x = xp[cil * C::PLANE + (tap / 3) * C::PITCH + (tap % 3)];
+      for (int r = 0; r < 3; ++r) {
+        const float* row = xl + cil * CPLANE + (py + r) * PITCH + px4 + 3;      // tile column px4 - 1
+        float x6[6];
+        x6[0] = row[0];
+        const f32x4 mid = *reinterpret_cast<const f32x4*>(row + 1);             // 16-byte aligned
+        x6[1] = mid[0]; x6[2] = mid[1]; x6[3] = mid[2]; x6[4] = mid[3];
+        x6[5] = row[5];
 #pragma unroll
-        for (int co = 0; co < CO; ++co) acc[co] = fmaf(x, wl[(tap * C::KC + cil) * CO + co], acc[co]);
+        for (int b = 0; b < 3; ++b) {
+          // output channels in pairs: one v_pk_fma_f32 per (pixel, channel pair)
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int c2 = 0; c2 < CO / 2; ++c2) {
+            const f32x2 w2 = *reinterpret_cast<const f32x2*>(wl + ((r * 3 + b) * KC + cil) * CO + 2 * c2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x2 a2 = {acc[2 * c2][q], acc[2 * c2 + 1][q]};
+              const f32x2 xx = {x6[q + b], x6[q + b]};
+              a2 = __builtin_elementwise_fma(xx, w2, a2);
+              acc[2 * c2][q] = a2[0]; acc[2 * c2 + 1][q] = a2[1];
+            }
+          }
+        }
       }
     }
     __syncthreads();
   }
-  const int y = y0 + py, x = x0 + px;
-  if (y < p.H && x < p.W) {
+  const int y = y0 + py;
+  if (y < p.H) {
 #pragma unroll
-    for (int co = 0; co < CO; ++co)
-      if (co < p.Cout) p.out[((size_t)n * p.Cout + co) * ((size_t)p.H * p.W) + (size_t)y * p.W + x] = acc[co];
+    for (int co = 0; co < CO; ++co) {
+      if (co >= p.Cout) continue;
+      float* o = p.out + ((size_t)n * p.Cout + co) * plane + (size_t)y * p.W + x0 + px4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (x0 + px4 + q < p.W) o[q] = acc[co][q];
+    }
   }
 }
 
@@ -1203,7 +1275,7 @@ static int launch_conv8(const ConvArgs& a_in, hipStream_t stream) {
 void set_conv8(int enable) { g_conv8 = enable; }
 
 static int launch_small_cout(const ConvArgs& a_in, hipStream_t stream) {
-  typedef ConvCfg<32, 16, 16, 1, 4, 9, 8> C;
+  struct C { enum { PH = 16, PW = 64, KC = 8 }; };      // the kernel's pixel tile and K chunk
   ConvArgs a = a_in;
   a.dbg = nullptr;
   a.coef_rows = 1;
@@ -1223,7 +1295,7 @@ static int launch_small_cout(const ConvArgs& a_in, hipStream_t stream) {
   ProfScope ps("conv_small_cout_kernel", 2.0 * px * a.Cout * (double)(a.Ca + a.Cb) * 9,
                4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * a.Cout), stream);
   const unsigned rows_bytes = (unsigned)(a.Ca + a.Cb) * (unsigned)sizeof(Coef);
-  MCEDM_REQUIRE(rows_bytes <= 48 * 1024, "conv: %d input channels exceed the LDS row table", a.Ca + a.Cb);
+  MCEDM_REQUIRE(rows_bytes <= 20 * 1024, "conv: %d input channels exceed the LDS row table", a.Ca + a.Cb);
   if (a.Cout <= 2)
     hipLaunchKernelGGL(conv_small_cout_kernel<2>, dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, a.wpk, a.bias,
                        tiles_x, tiles_y, nchunks, cout_padded(a.Cout));

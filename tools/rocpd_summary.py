@@ -54,7 +54,13 @@ def traffic(fdb, wdb, out):
         short = k.split("(")[0].replace("void mcedm::", "").replace("mcedm::", "").strip()
         res[short] = {"launches": fetch[k][1], "read_bytes_x1": rd, "read_bytes_x2": 2 * rd, "write_bytes": wr,
                       "traffic_bytes": 2 * rd + wr}
-    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    # stamped with the digest of the kernel sources the passes were taken on: bench.py refuses a stale file
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    json.dump({"csrc_digest": bench.csrc_digest(), "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB units; "
+               "reads bracketed [x1, x2] (gfx950 counts 128-B requests at 64 B for wide streams), traffic_bytes = 2 * read + write",
+               "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes"] * kv[1]["launches"])[:8]:
         print(f"{k[:70]:70s} n={v['launches']:5d} read {v['read_bytes_x1'] / 1e6:8.1f}..{v['read_bytes_x2'] / 1e6:8.1f} MB"
               f"  write {v['write_bytes'] / 1e6:8.1f} MB")
