@@ -128,6 +128,11 @@ struct ConvArgs {
 };
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t stream);
+static inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }     // channel padding of the packed tables
+int conv_resolve_identity(ConvArgs& a);                  // points a missing transform table at the identity row
+unsigned long long* conv_debug_buffer();
+int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream);   // conv_resident.hip; -1: not served there
+void set_conv_resident(int enable);                      // 1 / 0, -1: default (env MCEDM_CONV_RESIDENT, else on)
 static inline int conv_max_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 7) / 8); }   // smallest pixel tile is 8x8
 void set_conv_tile_override(int mt, int ph, int pw);
 void set_conv8(int enable);   // 1 / 0, -1: default (env MCEDM_CONV8, else off)

@@ -120,6 +120,11 @@ extern "C" int mcedm_op_set_conv8(int enable) {
   return MCEDM_OK;
 }
 
+extern "C" int mcedm_op_set_conv_resident(int enable) {
+  set_conv_resident(enable);
+  return MCEDM_OK;
+}
+
 extern "C" int mcedm_op_set_conv_debug(unsigned long long* buf) {
   set_conv_debug(buf);
   return MCEDM_OK;

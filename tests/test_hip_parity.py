@@ -193,6 +193,70 @@ def test_conv_every_tile_configuration(lib, tile, k):
         assert torch.equal(y, y4)
 
 
+@pytest.mark.parametrize("shape", [
+    # (B, Ca, Cb, Cout, H, W, k, resample, res_mode): the shapes conv_resident_kernel serves (<= 32 x 32 images, Cout % 64 == 0)
+    (3, 64, 0, 64, 8, 8, 3, 0, 0), (2, 64, 64, 64, 8, 8, 3, 0, 0), (2, 64, 0, 64, 16, 16, 3, 0, 0), (1, 128, 128, 128, 16, 16, 3, 0, 0),
+    (2, 64, 0, 64, 16, 16, 3, 1, 1), (2, 64, 0, 64, 8, 8, 3, 0, 2), (3, 2, 2, 64, 32, 32, 3, 0, 0), (2, 64, 0, 64, 32, 32, 3, 0, 0),
+    (2, 64, 64, 64, 32, 32, 3, 0, 0), (2, 64, 0, 64, 32, 32, 3, 1, 1), (2, 64, 0, 192, 8, 8, 1, 0, 0), (1, 128, 0, 384, 16, 16, 1, 0, 0),
+    (2, 64, 0, 64, 16, 16, 1, 0, 0), (2, 24, 12, 64, 12, 10, 3, 0, 0), (1, 72, 0, 64, 28, 30, 3, 0, 0), (2, 256, 0, 128, 16, 16, 3, 0, 0),
+])
+def test_conv_resident_kernel_is_bit_identical_to_the_tiled_one(lib, shape):
+    """conv_resident.hip (whole K extent of the tile in LDS, DMA weight stream) against conv_mfma_kernel on the same tile
+    configuration: identical bits (same accumulation order), and both against the oracle.  Ragged images, padded last
+    chunks, virtual concat, 2x up-sampled input, residual at the output / half / double resolution."""
+    B, Ca, Cb, Cout, H, W, k, rs, rm = shape
+    tag = "t/resident/" + "_".join(map(str, shape))
+    Cin = Ca + Cb
+    Hs, Ws = (H // 2, W // 2) if rs == 1 else (H, W)
+    xa = fx.randn(tag + "/xa", B, Ca, Hs, Ws)
+    xb = fx.randn(tag + "/xb", B, Cb, Hs, Ws) if Cb else None
+    w, b = fx.param(tag, "conv.weight", (Cout, Cin, k, k)), fx.param(tag, "conv.bias", (Cout,))
+    coef = torch.stack([fx.randn(tag + "/mean", B, Cin) * 0.3, 1 + 0.3 * fx.randn(tag + "/scale", B, Cin),
+                        0.2 * fx.randn(tag + "/off", B, Cin), torch.zeros(B, Cin)], dim=-1)
+    Hr, Wr = (H // 2, W // 2) if rm == 1 else ((2 * H, 2 * W) if rm == 2 else (H, W))
+    res = fx.randn(tag + "/res", B, Cout, Hr, Wr)
+    wpk, bpk = lib.op_pack_conv(dev(w), dev(b))
+    args = (dev(xa), dev(xb) if Cb else None, wpk, bpk, Cout, k)
+    kw = dict(coef=dev(coef), act=1, resample=rs, res=dev(res), res_mode=rm)
+    lib.set_conv_resident(2)          # level 2 = also the (opt-in) 8 x 16-pixel tile of ~32 x 32 images
+    lib.prof_enable(True)
+    try:
+        y = lib.op_conv(*args, **kw)
+        names = [r["name"] for r in lib.prof_report()]
+    finally:
+        lib.prof_enable(False)
+        lib.set_conv_resident(-1)
+    assert any(n.startswith("conv_resident_kernel") for n in names), names
+    lib.set_conv_resident(0)
+    try:
+        y0 = lib.op_conv(*args, **kw)
+    finally:
+        lib.set_conv_resident(-1)
+    assert torch.equal(y, y0), f"{tag}: max |d| = {(y - y0).abs().max().item():.3e}"
+    x = torch.cat([xa, xb], 1) if Cb else xa
+    r = res
+    if rm == 1:
+        r = res.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    elif rm == 2:
+        r = torch.nn.functional.avg_pool2d(res, 2)
+    close(y, orc.conv2d(apply_coef(x, coef, True), w, b, up=(rs == 1)) + r, what=tag)
+
+
+def test_unet_forward_resident_on_off_identical(lib, net_P):
+    """Whole 32 x 32 U-Net (fused GroupNorm statistics, folded 1x1 skip projections, attention 1x1 convs): the forward with
+    the input-resident kernels is bit-identical to the forward with conv_mfma_kernel everywhere."""
+    plan, packed, P = net_P
+    x, cond = fx.randn("unet_P/x", 4, 2, 32, 32), fx.randn("unet_P/cond", 4, 2, 32, 32)
+    labels = dev(fx.UNET_LABELS["nB"])
+    F1 = plan.forward(packed, dev(x), labels, cond=dev(cond))
+    lib.set_conv_resident(0)
+    try:
+        F0 = plan.forward(packed, dev(x), labels, cond=dev(cond))
+    finally:
+        lib.set_conv_resident(-1)
+    assert torch.equal(F1, F0), f"max |d| = {(F1 - F0).abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("Cout", [1, 2, 3, 4])
 def test_output_conv_direct_kernel(lib, Cout):
     # ch -> out_channels 3x3 conv on a large image takes the direct (non-MFMA) kernel: ragged 72 x 88 image,

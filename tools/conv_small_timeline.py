@@ -50,8 +50,12 @@ flops = 2.0 * B * hw * hw * cout * cin * k * k
 print(f"B={B} {cin}->{cout} {hw}x{hw} k={k} res={int(use_res)}: {us:.1f} us/launch back-to-back ({flops / us / 1e6:.1f} TFLOP/s), "
       f"{len(d)} workgroups, in-kernel span {end.max():.1f} us | start spread {st.max():.1f} | prologue {np.mean(pro - st):.1f} "
       f"| K loop {np.mean(loop - pro):.1f} | epilogue {np.mean(end - loop):.1f}")
+cyc = np.median(d[:, 6] - d[:, 5])
+print(f"   K loop: {cyc:.0f} shader cycles (median), clock {np.median((d[:, 6] - d[:, 5]) / ((d[:, 2] - d[:, 1]) * 10e-9) / 1e9):.2f} GHz")
 if d[:, 8:13].max() > 0 and d[:, 8:13].max() < (1 << 40):      # MCEDM_CONV_TIMELINE build: per-phase cycle sums of wave 0
     nch = -(-cin // (8 if k == 3 else 16))
     clk = np.median((d[:, 6] - d[:, 5]) / ((d[:, 2] - d[:, 1]) * 10e-9) / 1e9)
     print(f"   shader clock {clk:.2f} GHz; per-iteration cycles ({nch} iterations): " +
-          "  ".join(f"{nm} {np.mean(d[:, 8 + j]) / nch:.0f}" for j, nm in enumerate(["commit", "barrier1", "load-issue", "mfma", "barrier2"])))
+          "  ".join(f"{nm} {np.mean(d[:, 8 + j]) / nch:.0f}" for j, nm in enumerate(["commit|dma-issue", "barrier1|mfma", "load-issue|wait", "mfma|barrier", "barrier2|-"])))
+    if d[:, 13:16].max() > 0:      # resident kernel: prologue phases
+        print("   prologue cycles: " + "  ".join(f"{nm} {np.mean(d[:, j]):.0f}" for nm, j in [("dma+issue", 13), ("init_acc+coef rows+sync", 14), ("commit", 15), ("wait+sync", 7)]))
