@@ -50,44 +50,39 @@ __device__ __forceinline__ void lds_dma4(const float* sbase, unsigned voff, unsi
                : : "s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(uniform_ptr(sbase)) : "memory");
 }
 
-// Weight slab of one K chunk ([tap][ci_local][MT] floats, rows of the packed table), global -> LDS by DMA: float4 number
-// i = tid + it * NT of the slab goes to LDS float4 i.  Every wave issues exactly IT instructions (a wave past the end of
-// the slab repeats its previous step: same data to the same place), so the K loop can wait with a counted vmcnt for the
-// slab it needs and leave the younger slab's DMA in flight.
-template <class C>
-struct SlabDma {
-  static constexpr int V4 = C::MT / 4, NV4 = C::WL / 4, IT = (NV4 + C::NT - 1) / C::NT;
-  static constexpr int ROWS_IT = C::NT / V4;        // slab rows per step
-  static_assert(NV4 % 64 == 0 && NV4 >= C::NT && C::NT % V4 == 0, "whole waves; whole rows per step");
-  unsigned voff;                                    // byte offset of this lane's float4 inside a step: (row * coutp + c4 * 4) * 4
-  __device__ __forceinline__ void init(int coutp, int tid) {
-    const int row = tid / V4, c4 = tid - row * V4;
-    voff = 4u * (unsigned)(row * coutp + c4 * 4);
-  }
-  // base = first float of the chunk's rows at column m0; wl_addr = LDS byte address of the slab
-  __device__ __forceinline__ void issue_step(int it, const float* base, unsigned wl_addr, int coutp, int wave) const {
-    int st = it;
-    if (it * C::NT + wave * 64 >= NV4) st = it - 1;                   // wave-uniform
-    lds_dma16(base + (size_t)st * ROWS_IT * coutp, voff, wl_addr + 16u * (unsigned)(st * C::NT + wave * 64));
-  }
-  __device__ __forceinline__ void issue(const float* base, unsigned wl_addr, int coutp, int wave) const {
-#pragma unroll
-    for (int it = 0; it < IT; ++it) issue_step(it, base, wl_addr, coutp, wave);
-  }
+// A weight slab = a run of whole rows of the packed table ([tap][ci_local] rows of MT floats at column m0), global -> LDS by
+// DMA: float4 number i = tid + it * NT of the slab goes to LDS float4 i.  A slab is a whole K chunk (TAPS * KC rows), or,
+// in SPLIT mode, the rows of taps [0, TSPLIT) / [TSPLIT, TAPS) of a chunk (half the LDS: two workgroups per CU).
+// Every wave issues exactly ITU instructions per slab (a wave past the end of the slab repeats its previous step: same
+// data to the same place), so the K loop can wait with a counted vmcnt for the slab it needs and leave the younger slab's
+// DMA in flight.
+template <class C, bool SPLIT>
+struct SlabGeom {
+  static constexpr int TSPLIT = 5;
+  static constexpr int V4 = C::MT / 4;                              // float4 per row
+  static constexpr int ROWS_IT = C::NT / V4;                        // slab rows per DMA step of the workgroup
+  static constexpr int ROWS_MAX = (SPLIT ? TSPLIT : C::TAPS) * C::KC;
+  static constexpr int SL = ROWS_MAX * C::MT;                       // floats of a ring slot
+  static constexpr int ITU = (ROWS_MAX * V4 + C::NT - 1) / C::NT;   // DMA instructions per wave and slab
+  static constexpr int NU = SPLIT ? 2 : 1;                          // slabs (= K-loop units) per chunk
+  static_assert(C::NT % V4 == 0 && (ROWS_MAX * V4) % 64 == 0 && ROWS_MAX * V4 >= C::NT, "whole rows per step, whole waves");
+  static_assert(!SPLIT || (C::TAPS == 9 && ((C::TAPS - TSPLIT) * C::KC * V4) % 64 == 0), "split slabs are for 3x3");
+  static_assert(ITU <= (SPLIT ? C::TAPS - TSPLIT : C::TAPS), "one DMA step per tap of a unit");
 };
 
-template <class C, int RS>
+template <class C, int RS, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles, int nchunks,
                                                               int nsk, int coutp, int nslab) {
   static_assert(RS == RS_NONE || RS == RS_UP, "resampling modes of the resident kernel");
   static_assert(C::NT == 256 && C::NWAVE == 4 && C::CPI == 1, "four compute waves");
-  static_assert(SKC * C::MT / 4 == C::NT, "the projection's weight slab is one float4 per thread");
+  static_assert(SKC * C::MT / 4 == C::NT, "the projection's weight slab is one float4 per thread (one DMA step)");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CPS = C::NT / C::PLANE;             // input channels staged per step of the workgroup
   constexpr int CPD = C::NT / C::NPIX;              // projection channels per step (a wave = 64 pixels of one channel)
   static_assert(CPS >= 1, "tile plane larger than the workgroup");
-  float* wl = lds;                                  // [nslab][WL] ring of weight slabs (nslab = 3, or 2 when LDS is short)
-  float* xl = lds + nslab * C::WL;                  // [nchunks * KC][PLANE] input tile: raw by DMA, then transformed in place
+  typedef SlabGeom<C, SPLIT> SG;
+  float* wl = lds;                                  // [nslab][SL] ring of weight slabs (nslab = 3, or 2 when LDS is short)
+  float* xl = lds + nslab * SG::SL;                 // [nchunks * KC][PLANE] input tile: raw by DMA, then transformed in place
   float* sk = xl + nchunks * C::KC * C::PLANE;      // [nsk * SKC][NPIX] raw input of the folded projection
   Coef* cfl = reinterpret_cast<Coef*>(sk + nsk * SKC * C::NPIX);
 
@@ -104,7 +99,8 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   const int y0 = ty * C::PH, x0 = tx * C::PW;
   const int m0 = mt * C::MT;
   const int Ca = p.Ca, Cin = p.Ca + p.Cb;
-  const int niter = nchunks + nsk;
+  const int nwu = SG::NU * nchunks;                 // K-loop units that stream 3x3 / 1x1 weights; then nsk projection units
+  const int nunits = nwu + nsk;
   const int dist = nslab - 1;                       // slabs in flight ahead of the one being consumed
 
   if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
@@ -115,21 +111,39 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
 #define MCEDM_PSTAMP(k)
 #endif
   // ---- phase 0: every byte this workgroup reads from HBM / L2 is requested here, by DMA, in a handful of tight loops
-  SlabDma<C> wdma;
-  wdma.init(coutp, tid);
+  const unsigned wvoff = 4u * (unsigned)((tid / SG::V4) * coutp + (tid % SG::V4) * 4);   // this lane's float4 inside a DMA step
   const unsigned wl_addr = lds_addr(wl);
   const float* wbase = p.wpk + m0;                              // + chunk * TAPS * KC * coutp
   const float* skbase = p.sk_wpk + m0;                          // + chunk * SKC * coutp (null + m0 is never dereferenced)
   const size_t wchunk = (size_t)C::TAPS * C::KC * coutp;
-  auto dma_iter = [&](int j, int slab) -> int {     // slab of K-loop iteration j; returns the DMA instructions per wave
-    if (j < nchunks) { wdma.issue(wbase + (size_t)j * wchunk, wl_addr + 4u * (unsigned)(slab * C::WL), coutp, wave); return SlabDma<C>::IT; }
-    if (j < niter) {
-      lds_dma16(skbase + (size_t)(j - nchunks) * SKC * coutp, wdma.voff, wl_addr + 4u * (unsigned)(slab * C::WL) + 16u * (unsigned)(wave * 64));
-      return 1;
+  // unit v of the K loop -> where its slab comes from; kind 2: conv weights, 1: projection weights, 0: past the end
+  auto unit_src = [&](int v, const float*& base, int& nv4) -> int {
+    if (v < nwu) {
+      const int ch = SPLIT ? v >> 1 : v, part = SPLIT ? v & 1 : 0;
+      base = wbase + (size_t)ch * wchunk + (part ? (size_t)SG::TSPLIT * C::KC * coutp : 0);
+      nv4 = (SPLIT ? (part ? C::TAPS - SG::TSPLIT : SG::TSPLIT) : C::TAPS) * C::KC * SG::V4;
+      return 2;
     }
+    if (v < nunits) { base = skbase + (size_t)(v - nwu) * SKC * coutp; nv4 = C::NT; return 1; }
     return 0;
   };
-  for (int j = 0; j < dist; ++j) dma_iter(j, j);
+  auto dma_step = [&](int it, const float* base, int nv4, int slab) {
+    int st = it;
+    if (it * C::NT + wave * 64 >= nv4) st = it - 1;                   // wave-uniform
+    lds_dma16(base + (size_t)st * SG::ROWS_IT * coutp, wvoff, wl_addr + 4u * (unsigned)(slab * SG::SL) + 16u * (unsigned)(st * C::NT + wave * 64));
+  };
+  auto dma_unit = [&](int v, int slab) -> int {     // all steps at once; returns the DMA instructions per wave
+    const float* base; int nv4;
+    const int kind = unit_src(v, base, nv4);
+    if (kind == 2) {
+#pragma unroll
+      for (int it = 0; it < SG::ITU; ++it) dma_step(it, base, nv4, slab);
+      return SG::ITU;
+    }
+    if (kind == 1) { dma_step(0, base, nv4, slab); return 1; }
+    return 0;
+  };
+  for (int j = 0; j < dist; ++j) dma_unit(j, j);
 
   // input tile: thread (chsub, pos) owns element pos of channel s * CPS + chsub in step s
   const bool active = tid < CPS * C::PLANE;
@@ -232,54 +246,11 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
 #else
 #define MCEDM_RSTAMP(k)
 #endif
-  static_assert(SlabDma<C>::IT <= C::TAPS, "one DMA step per tap of the chunk loop");
-  for (int i = 0; i < niter; ++i) {
-    const float* wc = wl + sc * C::WL;
-    int issued;
-    if (i < nchunks && i + dist < nchunks) {
-      // the common case: slab i + dist is a 3x3 chunk and its IT DMA instructions go out one per tap, in the shadow of
-      // the MFMAs (issued in a block in front of them they cost ~90 cycles each: the memory pipeline accepts them slowly)
-      const float* nb = wbase + (size_t)(i + dist) * wchunk;
-      const unsigned na = wl_addr + 4u * (unsigned)(sn * C::WL);
-      MCEDM_RSTAMP(0)
-      mfma_chunk<C, true, false>(xl + i * C::KC * C::PLANE, wc, acc, aoff, boffm, [&](int tap) {
-        if (tap < SlabDma<C>::IT) wdma.issue_step(tap, nb, na, coutp, wave);
-      });
-      issued = SlabDma<C>::IT;
-    } else if (i < nchunks) {
-      issued = dma_iter(i + dist, sn);
-      __builtin_amdgcn_sched_barrier(0);
-      MCEDM_RSTAMP(0)
-      mfma_chunk<C>(xl + i * C::KC * C::PLANE, wc, acc, aoff, boffm);
-    } else {
-      issued = dma_iter(i + dist, sn);
-      __builtin_amdgcn_sched_barrier(0);
-      MCEDM_RSTAMP(0)
-      // one chunk of the folded projection: SKC channels at the centre tap out of the raw tile; fragments double-buffered
-      const float* skc = sk + (size_t)(i - nchunks) * SKC * C::NPIX + (lane >> 5) * C::NPIX + (lane & 31);
-      float fa[2][C::TM], fb[2][C::TN];
-#pragma unroll
-      for (int ii = 0; ii < C::TM; ++ii) fa[0][ii] = wc[aoff + ii * 32];
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) fb[0][j] = skc[(wn * C::TN + j) * 32];
-#pragma unroll
-      for (int kk = 0; kk < SKC / 2; ++kk) {
-        const int cur = kk & 1, nxt = cur ^ 1, kn = kk + 1 < SKC / 2 ? kk + 1 : kk;
-#pragma unroll
-        for (int ii = 0; ii < C::TM; ++ii) fa[nxt][ii] = wc[aoff + 2 * kn * C::MT + ii * 32];
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j) fb[nxt][j] = skc[2 * kn * C::NPIX + (wn * C::TN + j) * 32];
-#pragma unroll
-        for (int ii = 0; ii < C::TM; ++ii)
-#pragma unroll
-          for (int j = 0; j < C::TN; ++j) acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ii], fb[cur][j], acc[ii][j], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
-      }
-    }
+  int u = 0;                                        // unit being consumed
+  auto finish_unit = [&](int issued) {
     __builtin_amdgcn_sched_barrier(0);
     MCEDM_RSTAMP(1)
-    if (dist >= 2 && issued == SlabDma<C>::IT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SlabDma<C>::IT) : "memory");
+    if (dist >= 2 && issued == SG::ITU) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SG::ITU) : "memory");
     else if (dist >= 2 && issued == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     MCEDM_RSTAMP(2)
@@ -288,6 +259,67 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     MCEDM_RSTAMP(3)
     sc = sc + 1 == nslab ? 0 : sc + 1;
     sn = sn + 1 == nslab ? 0 : sn + 1;
+    ++u;
+  };
+  // one weight unit: taps [T0, T1) of chunk c out of slab sc
+  auto weight_unit = [&](int c, auto t0_tag, auto t1_tag) {
+    constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
+    const float* wc = wl + sc * SG::SL;
+    const float* nb; int nv4;
+    const int kind = unit_src(u + dist, nb, nv4);
+    if (kind == 2) {
+      // the common case: the slab dist units ahead is a weight slab and its ITU DMA instructions go out one per tap, in
+      // the shadow of the MFMAs (issued in a block in front of them they cost ~90 cycles each: the memory pipeline
+      // accepts them slowly)
+      const int slab = sn;
+      MCEDM_RSTAMP(0)
+      mfma_chunk<C, true, false, T0, T1>(xl + c * C::KC * C::PLANE, wc, acc, aoff, boffm, [&](int t) {
+        if (t < SG::ITU) dma_step(t, nb, nv4, slab);
+      });
+      finish_unit(SG::ITU);
+    } else {
+      const int issued = kind == 1 ? (dma_step(0, nb, nv4, sn), 1) : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      MCEDM_RSTAMP(0)
+      mfma_chunk<C, true, false, T0, T1>(xl + c * C::KC * C::PLANE, wc, acc, aoff, boffm);
+      finish_unit(issued);
+    }
+  };
+  for (int c = 0; c < nchunks; ++c) {
+    if constexpr (SPLIT) {
+      weight_unit(c, std::integral_constant<int, 0>{}, std::integral_constant<int, SG::TSPLIT>{});
+      weight_unit(c, std::integral_constant<int, SG::TSPLIT>{}, std::integral_constant<int, C::TAPS>{});
+    } else {
+      weight_unit(c, std::integral_constant<int, 0>{}, std::integral_constant<int, C::TAPS>{});
+    }
+  }
+  for (int j = 0; j < nsk; ++j) {
+    // one chunk of the folded projection: SKC channels at the centre tap out of the raw tile; fragments double-buffered
+    const float* wc = wl + sc * SG::SL;
+    const int issued = dma_unit(u + dist, sn);
+    __builtin_amdgcn_sched_barrier(0);
+    MCEDM_RSTAMP(0)
+    const float* skc = sk + (size_t)j * SKC * C::NPIX + (lane >> 5) * C::NPIX + (lane & 31);
+    float fa[2][C::TM], fb[2][C::TN];
+#pragma unroll
+    for (int ii = 0; ii < C::TM; ++ii) fa[0][ii] = wc[aoff + ii * 32];
+#pragma unroll
+    for (int jj = 0; jj < C::TN; ++jj) fb[0][jj] = skc[(wn * C::TN + jj) * 32];
+#pragma unroll
+    for (int kk = 0; kk < SKC / 2; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1, kn = kk + 1 < SKC / 2 ? kk + 1 : kk;
+#pragma unroll
+      for (int ii = 0; ii < C::TM; ++ii) fa[nxt][ii] = wc[aoff + 2 * kn * C::MT + ii * 32];
+#pragma unroll
+      for (int jj = 0; jj < C::TN; ++jj) fb[nxt][jj] = skc[2 * kn * C::NPIX + (wn * C::TN + jj) * 32];
+#pragma unroll
+      for (int ii = 0; ii < C::TM; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < C::TN; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ii], fb[cur][jj], acc[ii][jj], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
+    }
+    finish_unit(issued);
   }
 
 #ifdef MCEDM_CONV_TIMELINE
@@ -342,17 +374,17 @@ static int resident_level() {     // 0: off, 1: the 8 x 8-pixel tile (<= 16 x 16
 
 static constexpr int LDS_MAX = 160 * 1024;
 
-template <class C>
+template <class C, bool SPLIT>
 static size_t resident_lds_bytes(const ConvArgs& a, int nslab) {
   const int Cin = a.Ca + a.Cb;
   const int nchunks = ceil_div(Cin, C::KC);
   const int nsk = a.sk_wpk ? ceil_div(a.sk_Ca + a.sk_Cb, SKC) : 0;
-  return sizeof(float) * ((size_t)nslab * C::WL + (size_t)nchunks * C::KC * C::PLANE + (size_t)nsk * SKC * C::NPIX) + sizeof(Coef) * (size_t)Cin;
+  return sizeof(float) * ((size_t)nslab * SlabGeom<C, SPLIT>::SL + (size_t)nchunks * C::KC * C::PLANE + (size_t)nsk * SKC * C::NPIX) + sizeof(Coef) * (size_t)Cin;
 }
 
-// 3 weight slabs (two in flight) when they fit, else 2; 0: this conv does not fit at all
-template <class C>
-static int resident_slabs(const ConvArgs& a) {
+// 3 weight slabs (two in flight) when they fit into `budget` bytes of LDS, else 2; 0: this conv does not fit at all
+template <class C, bool SPLIT>
+static int resident_slabs(const ConvArgs& a, size_t budget = (size_t)LDS_MAX - 1024) {
   constexpr int CPS = C::NT / C::PLANE, CPD = C::NT / C::NPIX;
   const int Cin = a.Ca + a.Cb;
   if (!a.xa || a.Ca <= 0 || (a.Cb > 0 && !a.xb) || a.Ca % CPS || Cin % CPS) return 0;
@@ -361,11 +393,11 @@ static int resident_slabs(const ConvArgs& a) {
     if (!a.sk_xa || a.sk_Ca <= 0 || (a.sk_Cb > 0 && !a.sk_xb) || Csk % SKC || a.sk_Ca % CPD) return 0;
   }
   for (int nslab = 3; nslab >= 2; --nslab)
-    if (resident_lds_bytes<C>(a, nslab) <= (size_t)LDS_MAX - 1024) return nslab;
+    if (resident_lds_bytes<C, SPLIT>(a, nslab) <= budget) return nslab;
   return 0;
 }
 
-template <class C, int RS>
+template <class C, int RS, bool SPLIT = false>
 static int launch_resident(const ConvArgs& a_in, int nslab, hipStream_t stream) {
   ConvArgs a = a_in;
   a.dbg = conv_debug_buffer();
@@ -381,20 +413,21 @@ static int launch_resident(const ConvArgs& a_in, int nslab, hipStream_t stream) 
   MCEDM_HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) { set_error("device index %d out of range", dev); return MCEDM_ERR_INVALID; }
   if (!attr_set[dev]) {
-    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_resident_kernel<C, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_resident_kernel<C, RS, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     attr_set[dev] = true;
   }
   char name[96] = "";
   if (prof_enabled())
-    snprintf(name, sizeof(name), "conv_resident_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %d>, %d>", C::MT, C::PH, C::PW, C::WM,
-             C::WN, C::TAPS, C::KC, C::NT, C::CPI, RS);
+    snprintf(name, sizeof(name), "conv_resident_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %d>, %d, %s>", C::MT, C::PH, C::PW,
+             C::WM, C::WN, C::TAPS, C::KC, C::NT, C::CPI, RS, SPLIT ? "true" : "false");
   const double px = (double)a.B * a.H * a.W;
   const double skc = a.sk_wpk ? (double)(a.sk_Ca + a.sk_Cb) : 0.0;
   const double flops = 2.0 * px * a.Cout * ((double)(a.Ca + a.Cb) * C::TAPS + skc);
   const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * skc + px * a.Cout * (a.res ? 2 : 1) +
                               (double)a.Cout * ((a.Ca + a.Cb) * C::TAPS + skc));
   ProfScope ps(name, flops, bytes, stream);
-  hipLaunchKernelGGL((conv_resident_kernel<C, RS>), dim3((unsigned)blocks), dim3(256), (unsigned)resident_lds_bytes<C>(a, nslab), stream,
+  const unsigned lds_bytes = (unsigned)resident_lds_bytes<C, SPLIT>(a, nslab);
+  hipLaunchKernelGGL((conv_resident_kernel<C, RS, SPLIT>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream,
                      a, tiles_x, tiles_y, mtiles, nchunks, nsk, cout_padded(a.Cout), nslab);
   MCEDM_LAUNCH_CHECK("conv_resident_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
@@ -412,13 +445,19 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
     typedef ConvCfg<64, 8, 8, 2, 2, 9, 8> S;
     typedef ConvCfg<64, 8, 16, 1, 4, 9, 8> M;
     if (small) {
-      const int ns = resident_slabs<S>(a);
+      const int ns = resident_slabs<S, false>(a);
       if (!ns) return -1;
       return a.resample == RS_UP ? launch_resident<S, RS_UP>(a, ns, stream) : launch_resident<S, RS_NONE>(a, ns, stream);
     }
-    // ~32 x 32 images: one workgroup per CU in two rounds there; measured slower than conv_mfma_kernel (70 vs 59 us), so opt-in
-    if (resident_level() >= 2 && a.W >= 24 && (long long)a.H * a.W <= 1024 && cout_padded(a.Cout) % 128 != 0) {
-      const int ns = resident_slabs<M>(a);
+    if (a.W >= 24 && (long long)a.H * a.W <= 1024 && cout_padded(a.Cout) % 128 != 0) {
+      // ~32 x 32 images, 512 workgroups at B = 64.  Half-chunk weight slabs when that lets TWO workgroups share a CU
+      // (<= 80 KB each: Cin <= 64 without a folded projection); otherwise one workgroup per CU in two rounds, which is
+      // slower than conv_mfma_kernel today (70 vs 59 us), so opt-in (level 2)
+      const int ns2 = resident_slabs<M, true>(a, 80 * 1024 - 512);
+      if (ns2 == 3)
+        return a.resample == RS_UP ? launch_resident<M, RS_UP, true>(a, ns2, stream) : launch_resident<M, RS_NONE, true>(a, ns2, stream);
+      if (resident_level() < 2) return -1;
+      const int ns = resident_slabs<M, false>(a);
       if (!ns) return -1;
       return a.resample == RS_UP ? launch_resident<M, RS_UP>(a, ns, stream) : launch_resident<M, RS_NONE>(a, ns, stream);
     }
@@ -426,7 +465,7 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
   }
   typedef ConvCfg<64, 8, 8, 2, 2, 1, 16> P;
   if (small && !a.sk_wpk) {
-    const int ns = resident_slabs<P>(a);
+    const int ns = resident_slabs<P, false>(a);
     if (ns) return launch_resident<P, RS_NONE>(a, ns, stream);
   }
   return -1;

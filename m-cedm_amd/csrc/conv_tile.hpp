@@ -439,11 +439,14 @@ __device__ __forceinline__ void conv_stats_combine(const float* red, int stride_
 // and bubbles in this loop are paid in matrix time): +6...18 % on the small tiles, +0.6 % on <128, 8, 32>.
 // S2: stride-2 conv on the 4-phase tile (channel stride 4 planes; tap (a, b) -> phase (a&1, b&1), offset (a/2, b/2)).
 struct NoTapHook { __device__ __forceinline__ void operator()(int) const {} };
-// HOOK: called once per tap, after the first k-step of that tap has been issued (the matrix pipe is busy for the next
-// TM * TN * 64 cycles): the input-resident kernel issues one weight-DMA instruction of a later chunk there.
-template <class C, bool UNROLL_TAPS = true, bool S2 = false, class HOOK = NoTapHook>
+// T0, T1: the taps [T0, T1) only, out of a slab that starts at tap T0 (the input-resident kernel streams a chunk's
+// weights in two halves; the order of the K sum is the same).
+// HOOK: called once per tap with (tap - T0), after the first k-step of that tap has been issued (the matrix pipe is busy
+// for the next TM * TN * 64 cycles): the input-resident kernel issues one weight-DMA instruction of a later slab there.
+template <class C, bool UNROLL_TAPS = true, bool S2 = false, int T0 = 0, int T1 = C::TAPS, class HOOK = NoTapHook>
 __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32x16 (&acc)[C::TM][C::TN], int aoff,
                                            const int (&boff)[C::TN], const HOOK& hook = HOOK()) {
+  static_assert(T0 >= 0 && T0 < T1 && T1 <= C::TAPS, "tap range");
   constexpr int CS = S2 ? 4 * C::PLANE : C::PLANE;          // floats between consecutive input channels in LDS
   auto tap_off = [](int tap) {
     if (C::TAPS != 9) return 0;
@@ -456,15 +459,15 @@ __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) fa[0][i] = wl[aoff + i * 32];
 #pragma unroll
-  for (int j = 0; j < C::TN; ++j) fb[0][j] = xl[boff[j]];
-  constexpr int TAP_UNROLL = UNROLL_TAPS ? C::TAPS : 1;
+  for (int j = 0; j < C::TN; ++j) fb[0][j] = xl[boff[j] + tap_off(T0)];
+  constexpr int TAP_UNROLL = UNROLL_TAPS ? T1 - T0 : 1;
 #pragma unroll TAP_UNROLL
-  for (int tap = 0; tap < C::TAPS; ++tap) {
+  for (int tap = T0; tap < T1; ++tap) {
     const int toff = tap_off(tap);
-    const int tn = (tap + 1 < C::TAPS) ? tap + 1 : tap;         // clamped: the last prefetch is discarded
+    const int tn = (tap + 1 < T1) ? tap + 1 : tap;              // clamped: the last prefetch is discarded
     const int toff_n = tap_off(tn);
-    const float* wt = wl + aoff + tap * C::KC * C::MT;
-    const float* wt_n = wl + aoff + tn * C::KC * C::MT;
+    const float* wt = wl + aoff + (tap - T0) * C::KC * C::MT;
+    const float* wt_n = wl + aoff + (tn - T0) * C::KC * C::MT;
 #pragma unroll
     for (int kk = 0; kk < C::KC / 2; ++kk) {
       const int cur = kk & 1, nxt = cur ^ 1;
@@ -488,7 +491,7 @@ __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32
       // latency hides under TM*TN * 64 cycles of matrix work and the wait before the MFMAs is a counted one
       __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
-      if (kk == 0) hook(tap);
+      if (kk == 0) hook(tap - T0);
     }
   }
 }
