@@ -16,6 +16,7 @@
 // statistics are the ones of conv_mfma_kernel, and K is summed in the same order (chunk, tap, channel pair; then the
 // folded projection's channel pairs), so for one tile configuration the two kernels are BIT-IDENTICAL (tested); which one
 // runs is decided by the image size and channel counts only, never by the batch size.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -26,29 +27,6 @@
 namespace mcedm {
 
 static constexpr int SKC = 16;      // channels per K chunk of the folded projection (= the packed 1x1 table's chunk)
-
-// LDS-DMA issued from inline assembly, NOT through __builtin_amdgcn_global_load_lds: with the builtin in a kernel, hipcc's
-// wait-count insertion treats every later LDS read as possibly ordered against a pending "flat" operation and degrades
-// the counted waits of the MFMA loop (ds_read x2 -> s_waitcnt lgkmcnt(2) -> MFMA) to lgkmcnt(0) after every pair of
-// k-steps.  The compiler does not see these loads at all, so: every consumer is ordered by an explicit s_waitcnt vmcnt
-// (+ barrier) below, and compiler-generated vmcnt waits around them are only ever more conservative (the hardware
-// counter includes them).  Address = scalar base + 32-bit per-lane byte offset: no per-load vector arithmetic at all.
-// M0 = LDS byte address of lane 0's element; lane i writes at M0 + i * size.  (M0 is not otherwise used by these kernels;
-// it cannot be named in the clobber list.)
-__device__ __forceinline__ unsigned lds_addr(const float* l) { return (unsigned)reinterpret_cast<size_t>((lds_ptr_t)const_cast<float*>(l)); }
-__device__ __forceinline__ const float* uniform_ptr(const float* q) {      // the wave-uniform pointer, in SGPRs
-  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ void lds_dma16(const float* sbase, unsigned voff, unsigned m0v) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-               : : "s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(uniform_ptr(sbase)) : "memory");
-}
-__device__ __forceinline__ void lds_dma4(const float* sbase, unsigned voff, unsigned m0v) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-               : : "s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(uniform_ptr(sbase)) : "memory");
-}
 
 // A weight slab = a run of whole rows of the packed table ([tap][ci_local] rows of MT floats at column m0), global -> LDS by
 // DMA: float4 number i = tid + it * NT of the slab goes to LDS float4 i.  A slab is a whole K chunk (TAPS * KC rows), or,
@@ -71,8 +49,8 @@ struct SlabGeom {
 };
 
 template <class C, int RS, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles, int nchunks,
-                                                              int nsk, int coutp, int nslab) {
+__global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles, int pass_c,
+                                                              int coutp, int nslab) {
   static_assert(RS == RS_NONE || RS == RS_UP, "resampling modes of the resident kernel");
   static_assert(C::NT == 256 && C::NWAVE == 4 && C::CPI == 1, "four compute waves");
   static_assert(SKC * C::MT / 4 == C::NT, "the projection's weight slab is one float4 per thread (one DMA step)");
@@ -82,9 +60,9 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   static_assert(CPS >= 1, "tile plane larger than the workgroup");
   typedef SlabGeom<C, SPLIT> SG;
   float* wl = lds;                                  // [nslab][SL] ring of weight slabs (nslab = 3, or 2 when LDS is short)
-  float* xl = lds + nslab * SG::SL;                 // [nchunks * KC][PLANE] input tile: raw by DMA, then transformed in place
-  float* sk = xl + nchunks * C::KC * C::PLANE;      // [nsk * SKC][NPIX] raw input of the folded projection
-  Coef* cfl = reinterpret_cast<Coef*>(sk + nsk * SKC * C::NPIX);
+  float* xl = lds + nslab * SG::SL;                 // [pass_c][PLANE] input tile of one pass: raw by DMA, then transformed in
+                                                    // place; the projection's passes reuse it as [pass_c][NPIX], raw
+  Coef* cfl = reinterpret_cast<Coef*>(xl + pass_c * C::PLANE);      // this sample's Ca + Cb transform rows
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,18 +77,15 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   const int y0 = ty * C::PH, x0 = tx * C::PW;
   const int m0 = mt * C::MT;
   const int Ca = p.Ca, Cin = p.Ca + p.Cb;
-  const int nwu = SG::NU * nchunks;                 // K-loop units that stream 3x3 / 1x1 weights; then nsk projection units
+  const int Csk = p.sk_wpk ? p.sk_Ca + p.sk_Cb : 0;
+  const int nchunks = (Cin + C::KC - 1) / C::KC;    // K chunks of the conv over all passes
+  const int nsk = Csk / SKC;                        // K chunks of the folded projection (the launcher checks Csk % SKC == 0)
+  const int nwu = SG::NU * nchunks;                 // K-loop units that stream conv weights; then nsk projection units
   const int nunits = nwu + nsk;
   const int dist = nslab - 1;                       // slabs in flight ahead of the one being consumed
 
   if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
-#ifdef MCEDM_CONV_TIMELINE
-  unsigned long long pseg[4] = {0, 0, 0, 0}, pprev = __builtin_amdgcn_s_memtime();
-#define MCEDM_PSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pseg[k] += now_ - pprev; pprev = now_; }
-#else
-#define MCEDM_PSTAMP(k)
-#endif
-  // ---- phase 0: every byte this workgroup reads from HBM / L2 is requested here, by DMA, in a handful of tight loops
+  // ---- weight stream: units of the K loop, numbered over all passes
   const unsigned wvoff = 4u * (unsigned)((tid / SG::V4) * coutp + (tid % SG::V4) * 4);   // this lane's float4 inside a DMA step
   const unsigned wl_addr = lds_addr(wl);
   const float* wbase = p.wpk + m0;                              // + chunk * TAPS * KC * coutp
@@ -145,12 +120,12 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   };
   for (int j = 0; j < dist; ++j) dma_unit(j, j);
 
-  // input tile: thread (chsub, pos) owns element pos of channel s * CPS + chsub in step s
+  // ---- input tile: thread (chsub, pos) owns element pos of channel c0 + chsub in the step that stages channels c0...
   const bool active = tid < CPS * C::PLANE;
   const int chsub = active ? tid / C::PLANE : 0;
   const int pos = active ? tid - chsub * C::PLANE : 0;
   const size_t src_plane = (size_t)p.Hs * p.Ws;
-  unsigned keep;
+  unsigned keep, boff;
   {
     const int r = pos / C::PITCH, c = pos - r * C::PITCH;
     const int y = y0 + r - C::HALO, x = x0 + c - C::HALO;
@@ -158,37 +133,94 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     keep = inb ? 0xffffffffu : 0u;
     const int yc = inb ? y : 0, xc = inb ? x : 0;     // padding reads a clamped address and is masked in the transform pass
     const unsigned o = (RS == RS_UP) ? (unsigned)((yc >> 1) * p.Ws + (xc >> 1)) : (unsigned)(yc * p.Ws + xc);
-    const unsigned boff = 4u * ((unsigned)chsub * (unsigned)src_plane + o);
-    const int nsteps = Cin / CPS;                   // the launcher checks Ca % CPS == 0 and Cin % CPS == 0
-    const unsigned xl_addr = lds_addr(xl) + 4u * (unsigned)(wave * 64);
+    boff = 4u * ((unsigned)chsub * (unsigned)src_plane + o);
+  }
+  const float* pa = p.xa + (size_t)n * Ca * src_plane;
+  const float* pb = p.xb + (size_t)n * p.Cb * src_plane - (size_t)Ca * src_plane;       // indexed by the concat channel
+  const unsigned xl_addr = lds_addr(xl) + 4u * (unsigned)(wave * 64);
+  // requests channels [cb, cb + pc) of the (concatenated, possibly up-sampled) input by DMA: raw values, halo'd layout
+  auto request_main = [&](int cb, int pc) {
+    const int cend = min(cb + pc, Cin);             // the launcher checks Ca % CPS == 0 and Cin % CPS == 0
     if (wave * 64 < CPS * C::PLANE) {               // waves that own no tile element issue nothing
-      const float* pa = p.xa + (size_t)n * Ca * src_plane;
-      const float* pb = p.xb + (size_t)n * p.Cb * src_plane - (size_t)Ca * src_plane;   // indexed by the concat channel
-      for (int s = 0; s < nsteps; ++s) {
-        const int c0 = s * CPS;
+      for (int c0 = cb; c0 < cend; c0 += CPS) {
         const float* plane = (c0 < Ca ? pa : pb) + (size_t)c0 * src_plane;
-        if (active) lds_dma4(plane, boff, xl_addr + 4u * (unsigned)(s * (CPS * C::PLANE)));
+        if (active) lds_dma4(plane, boff, xl_addr + 4u * (unsigned)((c0 - cb) * C::PLANE));
       }
     }
-  }
-  if (nsk) {                                        // raw input of the folded projection (interior pixels only)
-    const int pix = tid % C::NPIX, csub = tid / C::NPIX;
-    const int y = min(y0 + pix / C::PW, p.H - 1), x = min(x0 + pix % C::PW, p.W - 1);   // clamped: such pixels are never stored
-    const size_t plane = (size_t)p.H * p.W;
-    const unsigned poff = 4u * (unsigned)((size_t)csub * plane + (size_t)y * p.W + x);
-    const unsigned sk_addr = lds_addr(sk) + 4u * (unsigned)(wave * 64);
-    const float* pa = p.sk_xa + (size_t)n * p.sk_Ca * plane;
-    const float* pb = p.sk_xb + (size_t)n * p.sk_Cb * plane - (size_t)p.sk_Ca * plane;
-    const int steps = nsk * SKC / CPD;
-    for (int s = 0; s < steps; ++s) {
-      const int c0 = s * CPD;
-      lds_dma4((c0 < p.sk_Ca ? pa : pb) + (size_t)c0 * plane, poff, sk_addr + 4u * (unsigned)(s * C::NT));
+    // channels that pad the last chunk: zeros (their packed weights are zero too, but LDS garbage may be NaN)
+    for (int e = (cend - cb) * C::PLANE + tid; e < pc * C::PLANE; e += C::NT) xl[e] = 0.f;
+  };
+  // GroupNorm / FiLM / SiLU and the zero padding, in place: each thread the elements its own wave's DMA wrote
+  auto transform_main = [&](int cb, int pc) {
+    const int nsteps = (min(cb + pc, Cin) - cb) / CPS;
+    if (active) {
+      float* xt = xl + tid;
+      const Coef* ct = cfl + cb + chsub;
+      auto pass = [&](auto act_tag) {
+        constexpr bool ACT = decltype(act_tag)::value;
+#pragma unroll 8
+        for (int s = 0; s < nsteps; ++s) {
+          const Coef cf = ct[s * CPS];
+          float v = (xt[s * (CPS * C::PLANE)] - cf.mean) * cf.scale + cf.offset;
+          if (ACT) v = silu_f(v);
+          xt[s * (CPS * C::PLANE)] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
+        }
+      };
+      if (p.act) pass(std::true_type{}); else pass(std::false_type{});
     }
-  }
-  MCEDM_PSTAMP(0)
+  };
 
-  // ---- phase 1: accumulators = bias (+ residual); transform rows; then the in-place transform of the staged tile
+  int boffm[C::TN];
+#pragma unroll
+  for (int j = 0; j < C::TN; ++j) {
+    const int pix = (wn * C::TN + j) * 32 + (lane & 31);
+    boffm[j] = (lane >> 5) * C::PLANE + (pix / C::PW) * C::PITCH + (pix % C::PW);
+  }
+  const int aoff = (lane >> 5) * C::MT + wm * C::TM * 32 + (lane & 31);
+
+  // ---- K loop machinery.  Unit u consumes slab sc; the DMA of unit u + dist goes into slab sn, one instruction per tap
+  // under the MFMAs, and the wait that ends a unit only covers slab u + 1 (issued one unit earlier when dist == 2).
   f32x16 acc[C::TM][C::TN];
+  int u = 0, sc = 0, sn = dist % nslab;
+  auto finish_unit = [&](int issued) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (dist >= 2 && issued == SG::ITU) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SG::ITU) : "memory");
+    else if (dist >= 2 && issued == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    sc = sc + 1 == nslab ? 0 : sc + 1;
+    sn = sn + 1 == nslab ? 0 : sn + 1;
+    ++u;
+  };
+  // one weight unit: taps [T0, T1) of the pass's chunk cl out of slab sc
+  auto weight_unit = [&](int cl, auto t0_tag, auto t1_tag) {
+    constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
+    const float* wc = wl + sc * SG::SL;
+    const float* nb; int nv4;
+    const int kind = unit_src(u + dist, nb, nv4);
+    if (kind == 2) {
+      // the common case: the slab dist units ahead is a weight slab and its ITU DMA instructions go out one per tap, in
+      // the shadow of the MFMAs (issued in a block in front of them they cost ~90 cycles each: the memory pipeline
+      // accepts them slowly)
+      const int slab = sn;
+      mfma_chunk<C, true, false, T0, T1>(xl + cl * C::KC * C::PLANE, wc, acc, aoff, boffm, [&](int t) {
+        if (t < SG::ITU) dma_step(t, nb, nv4, slab);
+      });
+      finish_unit(SG::ITU);
+    } else {
+      const int issued = kind == 1 ? (dma_step(0, nb, nv4, sn), 1) : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_chunk<C, true, false, T0, T1>(xl + cl * C::KC * C::PLANE, wc, acc, aoff, boffm);
+      finish_unit(issued);
+    }
+  };
+
+  // ---- passes over the conv's input channels: pass_c channels of the tile are resident at a time (all of them when
+  // they fit).  While this workgroup re-stages, the other workgroup of the CU has the matrix pipe.
+  const int cin_pad = nchunks * C::KC;
+  request_main(0, min(pass_c, cin_pad));
+  // accumulators = bias (+ residual), transform rows: under the first pass's DMA
   if (m0 + C::MT <= p.Cout) {
     if (!p.res) conv_init_acc<C, 0, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
     else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
@@ -199,132 +231,67 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     else conv_init_acc<C, 1, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
   }
   stage_coef_rows<C::NT>(p, n, cfl, tid);
-  // channels that pad the last chunk: zeros (their packed weights are zero too, but LDS garbage may be NaN)
-  for (int e = Cin * C::PLANE + tid; e < nchunks * C::KC * C::PLANE; e += C::NT) xl[e] = 0.f;
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // every DMA of phase 0 has landed
-  __syncthreads();                                  // transform rows visible to every wave
-  MCEDM_PSTAMP(1)
-  if (active) {
-    // each thread transforms the elements its own wave's DMA wrote: read -> (x - mean) * scale + offset -> SiLU -> mask -> write
-    const int nsteps = Cin / CPS;
-    float* xt = xl + tid;
-    const Coef* ct = cfl + chsub;
-    auto pass = [&](auto act_tag) {
-      constexpr bool ACT = decltype(act_tag)::value;
-#pragma unroll 8
-      for (int s = 0; s < nsteps; ++s) {
-        const Coef cf = ct[s * CPS];
-        float v = (xt[s * (CPS * C::PLANE)] - cf.mean) * cf.scale + cf.offset;
-        if (ACT) v = silu_f(v);
-        xt[s * (CPS * C::PLANE)] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
+  for (int cb = 0; cb < cin_pad; cb += pass_c) {
+    const int pc = min(pass_c, cin_pad - cb);
+    if (cb > 0) request_main(cb, pc);               // (the barrier that ended the previous unit freed xl)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this pass's tile (and every older DMA) has landed
+    __syncthreads();                                // first pass: transform rows visible to every wave
+    transform_main(cb, pc);
+    __syncthreads();
+    if (cb == 0 && p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
+    for (int cl = 0; cl < pc / C::KC; ++cl) {
+      if constexpr (SPLIT) {
+        weight_unit(cl, std::integral_constant<int, 0>{}, std::integral_constant<int, SG::TSPLIT>{});
+        weight_unit(cl, std::integral_constant<int, SG::TSPLIT>{}, std::integral_constant<int, C::TAPS>{});
+      } else {
+        weight_unit(cl, std::integral_constant<int, 0>{}, std::integral_constant<int, C::TAPS>{});
       }
-    };
-    if (p.act) pass(std::true_type{}); else pass(std::false_type{});
-  }
-  MCEDM_PSTAMP(2)
-
-  int boffm[C::TN];
-#pragma unroll
-  for (int j = 0; j < C::TN; ++j) {
-    const int pix = (wn * C::TN + j) * 32 + (lane & 31);
-    boffm[j] = (lane >> 5) * C::PLANE + (pix / C::PW) * C::PITCH + (pix % C::PW);
-  }
-  const int aoff = (lane >> 5) * C::MT + wm * C::TM * 32 + (lane & 31);
-  __syncthreads();
-  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
-  MCEDM_PSTAMP(3)
-#ifdef MCEDM_CONV_TIMELINE
-  if (p.dbg && tid == 0) { for (int k = 0; k < 3; ++k) p.dbg[blockIdx.x * 16 + 13 + k] = pseg[k]; p.dbg[blockIdx.x * 16 + 7] = pseg[3]; }
-#endif
-
-  // ---- phase 2: K loop.  Iteration i consumes slab i % nslab; the DMA of slab i + dist is issued before its MFMAs and
-  // the wait at the end only covers slab i + 1 (issued one iteration earlier when dist == 2).
-  int sc = 0, sn = dist % nslab;                    // ring positions of iteration i and i + dist
-#ifdef MCEDM_CONV_TIMELINE   // per-phase cycle sums of wave 0 (tools/conv_small_timeline.py): DMA issue / MFMA / wait / barrier
-  unsigned long long seg[4] = {0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
-#define MCEDM_RSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg[k] += now_ - tprev; tprev = now_; }
-#else
-#define MCEDM_RSTAMP(k)
-#endif
-  int u = 0;                                        // unit being consumed
-  auto finish_unit = [&](int issued) {
-    __builtin_amdgcn_sched_barrier(0);
-    MCEDM_RSTAMP(1)
-    if (dist >= 2 && issued == SG::ITU) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SG::ITU) : "memory");
-    else if (dist >= 2 && issued == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    MCEDM_RSTAMP(2)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    MCEDM_RSTAMP(3)
-    sc = sc + 1 == nslab ? 0 : sc + 1;
-    sn = sn + 1 == nslab ? 0 : sn + 1;
-    ++u;
-  };
-  // one weight unit: taps [T0, T1) of chunk c out of slab sc
-  auto weight_unit = [&](int c, auto t0_tag, auto t1_tag) {
-    constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
-    const float* wc = wl + sc * SG::SL;
-    const float* nb; int nv4;
-    const int kind = unit_src(u + dist, nb, nv4);
-    if (kind == 2) {
-      // the common case: the slab dist units ahead is a weight slab and its ITU DMA instructions go out one per tap, in
-      // the shadow of the MFMAs (issued in a block in front of them they cost ~90 cycles each: the memory pipeline
-      // accepts them slowly)
-      const int slab = sn;
-      MCEDM_RSTAMP(0)
-      mfma_chunk<C, true, false, T0, T1>(xl + c * C::KC * C::PLANE, wc, acc, aoff, boffm, [&](int t) {
-        if (t < SG::ITU) dma_step(t, nb, nv4, slab);
-      });
-      finish_unit(SG::ITU);
-    } else {
-      const int issued = kind == 1 ? (dma_step(0, nb, nv4, sn), 1) : 0;
-      __builtin_amdgcn_sched_barrier(0);
-      MCEDM_RSTAMP(0)
-      mfma_chunk<C, true, false, T0, T1>(xl + c * C::KC * C::PLANE, wc, acc, aoff, boffm);
-      finish_unit(issued);
-    }
-  };
-  for (int c = 0; c < nchunks; ++c) {
-    if constexpr (SPLIT) {
-      weight_unit(c, std::integral_constant<int, 0>{}, std::integral_constant<int, SG::TSPLIT>{});
-      weight_unit(c, std::integral_constant<int, SG::TSPLIT>{}, std::integral_constant<int, C::TAPS>{});
-    } else {
-      weight_unit(c, std::integral_constant<int, 0>{}, std::integral_constant<int, C::TAPS>{});
     }
   }
-  for (int j = 0; j < nsk; ++j) {
-    // one chunk of the folded projection: SKC channels at the centre tap out of the raw tile; fragments double-buffered
-    const float* wc = wl + sc * SG::SL;
-    const int issued = dma_unit(u + dist, sn);
-    __builtin_amdgcn_sched_barrier(0);
-    MCEDM_RSTAMP(0)
-    const float* skc = sk + (size_t)j * SKC * C::NPIX + (lane >> 5) * C::NPIX + (lane & 31);
-    float fa[2][C::TM], fb[2][C::TN];
+  // ---- passes over the folded projection's input: raw interior pixels, [channel][NPIX]
+  if (Csk) {
+    const int pix = tid % C::NPIX, csub = tid / C::NPIX;
+    const int y = min(y0 + pix / C::PW, p.H - 1), x = min(x0 + pix % C::PW, p.W - 1);   // clamped: such pixels are never stored
+    const size_t plane = (size_t)p.H * p.W;
+    const unsigned poff = 4u * (unsigned)((size_t)csub * plane + (size_t)y * p.W + x);
+    const float* qa = p.sk_xa + (size_t)n * p.sk_Ca * plane;
+    const float* qb = p.sk_xb + (size_t)n * p.sk_Cb * plane - (size_t)p.sk_Ca * plane;
+    for (int sb = 0; sb < Csk; sb += pass_c) {
+      const int pc = min(pass_c, Csk - sb);         // multiple of SKC
+      for (int c0 = sb; c0 < sb + pc; c0 += CPD)    // the launcher checks sk_Ca % CPD == 0
+        lds_dma4((c0 < p.sk_Ca ? qa : qb) + (size_t)c0 * plane, poff, xl_addr + 4u * (unsigned)((c0 - sb) * C::NPIX));
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int j = 0; j < pc / SKC; ++j) {
+        // one chunk of the projection: SKC channels at the centre tap out of the raw tile; fragments double-buffered
+        const float* wc = wl + sc * SG::SL;
+        const int issued = dma_unit(u + dist, sn);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* skc = xl + (size_t)j * SKC * C::NPIX + (lane >> 5) * C::NPIX + (lane & 31);
+        float fa[2][C::TM], fb[2][C::TN];
 #pragma unroll
-    for (int ii = 0; ii < C::TM; ++ii) fa[0][ii] = wc[aoff + ii * 32];
+        for (int ii = 0; ii < C::TM; ++ii) fa[0][ii] = wc[aoff + ii * 32];
 #pragma unroll
-    for (int jj = 0; jj < C::TN; ++jj) fb[0][jj] = skc[(wn * C::TN + jj) * 32];
+        for (int jj = 0; jj < C::TN; ++jj) fb[0][jj] = skc[(wn * C::TN + jj) * 32];
 #pragma unroll
-    for (int kk = 0; kk < SKC / 2; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1, kn = kk + 1 < SKC / 2 ? kk + 1 : kk;
+        for (int kk = 0; kk < SKC / 2; ++kk) {
+          const int cur = kk & 1, nxt = cur ^ 1, kn = kk + 1 < SKC / 2 ? kk + 1 : kk;
 #pragma unroll
-      for (int ii = 0; ii < C::TM; ++ii) fa[nxt][ii] = wc[aoff + 2 * kn * C::MT + ii * 32];
+          for (int ii = 0; ii < C::TM; ++ii) fa[nxt][ii] = wc[aoff + 2 * kn * C::MT + ii * 32];
 #pragma unroll
-      for (int jj = 0; jj < C::TN; ++jj) fb[nxt][jj] = skc[2 * kn * C::NPIX + (wn * C::TN + jj) * 32];
+          for (int jj = 0; jj < C::TN; ++jj) fb[nxt][jj] = skc[2 * kn * C::NPIX + (wn * C::TN + jj) * 32];
 #pragma unroll
-      for (int ii = 0; ii < C::TM; ++ii)
+          for (int ii = 0; ii < C::TM; ++ii)
 #pragma unroll
-        for (int jj = 0; jj < C::TN; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ii], fb[cur][jj], acc[ii][jj], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
+            for (int jj = 0; jj < C::TN; ++jj) acc[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ii], fb[cur][jj], acc[ii][jj], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
+        }
+        finish_unit(issued);
+      }
     }
-    finish_unit(issued);
   }
 
-#ifdef MCEDM_CONV_TIMELINE
-  if (p.dbg && tid == 0) { for (int k = 0; k < 4; ++k) p.dbg[blockIdx.x * 16 + 8 + k] = seg[k]; p.dbg[blockIdx.x * 16 + 12] = 0; }
-#endif
   // ---- epilogue (as conv_mfma_kernel): store + fused GroupNorm statistics
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
   const bool full = (m0 + C::MT <= p.Cout);
@@ -374,38 +341,42 @@ static int resident_level() {     // 0: off, 1: the 8 x 8-pixel tile (<= 16 x 16
 
 static constexpr int LDS_MAX = 160 * 1024;
 
+// Launch plan of one conv: channels resident per pass (0: this conv is not served here), weight slabs in the ring.
+struct ResidentPlan { int pass_c = 0, nslab = 0; size_t lds = 0; };
+
 template <class C, bool SPLIT>
-static size_t resident_lds_bytes(const ConvArgs& a, int nslab) {
-  const int Cin = a.Ca + a.Cb;
-  const int nchunks = ceil_div(Cin, C::KC);
-  const int nsk = a.sk_wpk ? ceil_div(a.sk_Ca + a.sk_Cb, SKC) : 0;
-  return sizeof(float) * ((size_t)nslab * SlabGeom<C, SPLIT>::SL + (size_t)nchunks * C::KC * C::PLANE + (size_t)nsk * SKC * C::NPIX) + sizeof(Coef) * (size_t)Cin;
+static size_t resident_lds_bytes(const ConvArgs& a, int pass_c, int nslab) {
+  return sizeof(float) * ((size_t)nslab * SlabGeom<C, SPLIT>::SL + (size_t)pass_c * C::PLANE) + sizeof(Coef) * (size_t)(a.Ca + a.Cb);
 }
 
-// 3 weight slabs (two in flight) when they fit into `budget` bytes of LDS, else 2; 0: this conv does not fit at all
+// Everything resident in one pass with a ring of 3 slabs when that fits `budget` bytes of LDS; otherwise as many channels
+// per pass as fit (a multiple of 16: whole K chunks of the conv and of the projection), at least min_pass.
 template <class C, bool SPLIT>
-static int resident_slabs(const ConvArgs& a, size_t budget = (size_t)LDS_MAX - 1024) {
+static ResidentPlan resident_plan(const ConvArgs& a, size_t budget, int min_pass) {
   constexpr int CPS = C::NT / C::PLANE, CPD = C::NT / C::NPIX;
-  const int Cin = a.Ca + a.Cb;
-  if (!a.xa || a.Ca <= 0 || (a.Cb > 0 && !a.xb) || a.Ca % CPS || Cin % CPS) return 0;
-  if (a.sk_wpk) {
-    const int Csk = a.sk_Ca + a.sk_Cb;
-    if (!a.sk_xa || a.sk_Ca <= 0 || (a.sk_Cb > 0 && !a.sk_xb) || Csk % SKC || a.sk_Ca % CPD) return 0;
+  ResidentPlan r;
+  const int Cin = a.Ca + a.Cb, Csk = a.sk_wpk ? a.sk_Ca + a.sk_Cb : 0;
+  if (!a.xa || a.Ca <= 0 || (a.Cb > 0 && !a.xb) || a.Ca % CPS || Cin % CPS) return r;
+  if (Csk && (!a.sk_xa || a.sk_Ca <= 0 || (a.sk_Cb > 0 && !a.sk_xb) || Csk % SKC || a.sk_Ca % CPD)) return r;
+  const int need = std::max(ceil_div(Cin, C::KC) * C::KC, Csk);      // channels of the longest input (padded to chunks)
+  const int all = ceil_div(need, 16) * 16;
+  for (int nslab = 3; nslab >= 2; --nslab) {
+    const size_t fixed = resident_lds_bytes<C, SPLIT>(a, 0, nslab);
+    if (fixed >= budget) continue;
+    int pc = (int)((budget - fixed) / (sizeof(float) * C::PLANE)) / 16 * 16;
+    if (pc > all) pc = all;
+    if (pc >= std::min(min_pass, all)) { r.pass_c = pc; r.nslab = nslab; r.lds = resident_lds_bytes<C, SPLIT>(a, pc, nslab); return r; }
   }
-  for (int nslab = 3; nslab >= 2; --nslab)
-    if (resident_lds_bytes<C, SPLIT>(a, nslab) <= budget) return nslab;
-  return 0;
+  return r;
 }
 
 template <class C, int RS, bool SPLIT = false>
-static int launch_resident(const ConvArgs& a_in, int nslab, hipStream_t stream) {
+static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipStream_t stream) {
   ConvArgs a = a_in;
   a.dbg = conv_debug_buffer();
   { const int rc = conv_resolve_identity(a); if (rc != MCEDM_OK) return rc; }
   const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
   const int mtiles = ceil_div(a.Cout, C::MT);
-  const int nchunks = ceil_div(a.Ca + a.Cb, C::KC);
-  const int nsk = a.sk_wpk ? ceil_div(a.sk_Ca + a.sk_Cb, SKC) : 0;
   const long long blocks = (long long)a.B * tiles_x * tiles_y * mtiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv grid out of range (%lld blocks)", blocks); return MCEDM_ERR_INVALID; }
   static bool attr_set[64] = {};
@@ -426,9 +397,8 @@ static int launch_resident(const ConvArgs& a_in, int nslab, hipStream_t stream) 
   const double bytes = 4.0 * ((double)a.B * (a.Ca + a.Cb) * a.Hs * a.Ws + px * skc + px * a.Cout * (a.res ? 2 : 1) +
                               (double)a.Cout * ((a.Ca + a.Cb) * C::TAPS + skc));
   ProfScope ps(name, flops, bytes, stream);
-  const unsigned lds_bytes = (unsigned)resident_lds_bytes<C, SPLIT>(a, nslab);
-  hipLaunchKernelGGL((conv_resident_kernel<C, RS, SPLIT>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream,
-                     a, tiles_x, tiles_y, mtiles, nchunks, nsk, cout_padded(a.Cout), nslab);
+  hipLaunchKernelGGL((conv_resident_kernel<C, RS, SPLIT>), dim3((unsigned)blocks), dim3(256), (unsigned)plan.lds, stream, a, tiles_x,
+                     tiles_y, mtiles, plan.pass_c, cout_padded(a.Cout), plan.nslab);
   MCEDM_LAUNCH_CHECK("conv_resident_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
   return MCEDM_OK;
@@ -441,32 +411,28 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
   if (a.resample != RS_NONE && !(a.resample == RS_UP && taps == 9)) return -1;
   if (cout_padded(a.Cout) % 64 != 0) return -1;
   const bool small = (long long)a.H * a.W <= 256 || a.W < 12;          // the 8 x 8-pixel tile of dispatch()
+  const size_t whole_cu = (size_t)LDS_MAX - 1024, half_cu = 80 * 1024 - 512;
   if (taps == 9) {
     typedef ConvCfg<64, 8, 8, 2, 2, 9, 8> S;
     typedef ConvCfg<64, 8, 16, 1, 4, 9, 8> M;
-    if (small) {
-      const int ns = resident_slabs<S, false>(a);
-      if (!ns) return -1;
-      return a.resample == RS_UP ? launch_resident<S, RS_UP>(a, ns, stream) : launch_resident<S, RS_NONE>(a, ns, stream);
+    if (small) {          // <= 256 workgroups per 64 samples: one per CU, the whole LDS
+      const ResidentPlan pl = resident_plan<S, false>(a, whole_cu, 64);
+      if (!pl.pass_c) return -1;
+      return a.resample == RS_UP ? launch_resident<S, RS_UP>(a, pl, stream) : launch_resident<S, RS_NONE>(a, pl, stream);
     }
-    if (a.W >= 24 && (long long)a.H * a.W <= 1024 && cout_padded(a.Cout) % 128 != 0) {
-      // ~32 x 32 images, 512 workgroups at B = 64.  Half-chunk weight slabs when that lets TWO workgroups share a CU
-      // (<= 80 KB each: Cin <= 64 without a folded projection); otherwise one workgroup per CU in two rounds, which is
-      // slower than conv_mfma_kernel today (70 vs 59 us), so opt-in (level 2)
-      const int ns2 = resident_slabs<M, true>(a, 80 * 1024 - 512);
-      if (ns2 == 3)
-        return a.resample == RS_UP ? launch_resident<M, RS_UP, true>(a, ns2, stream) : launch_resident<M, RS_NONE, true>(a, ns2, stream);
-      if (resident_level() < 2) return -1;
-      const int ns = resident_slabs<M, false>(a);
-      if (!ns) return -1;
-      return a.resample == RS_UP ? launch_resident<M, RS_UP>(a, ns, stream) : launch_resident<M, RS_NONE>(a, ns, stream);
+    if (a.W >= 24 && (long long)a.H * a.W <= 1024) {
+      // ~32 x 32 images, 512+ workgroups: half-chunk weight slabs and <= 64 resident channels per pass keep a workgroup
+      // under 80 KB of LDS, so TWO share a CU and one computes while the other re-stages
+      const ResidentPlan pl = resident_plan<M, true>(a, half_cu, 32);
+      if (!pl.pass_c || pl.nslab != 3) return -1;
+      return a.resample == RS_UP ? launch_resident<M, RS_UP, true>(a, pl, stream) : launch_resident<M, RS_NONE, true>(a, pl, stream);
     }
     return -1;
   }
   typedef ConvCfg<64, 8, 8, 2, 2, 1, 16> P;
   if (small && !a.sk_wpk) {
-    const int ns = resident_slabs<P, false>(a);
-    if (ns) return launch_resident<P, RS_NONE>(a, ns, stream);
+    const ResidentPlan pl = resident_plan<P, false>(a, whole_cu, 64);
+    if (pl.pass_c) return launch_resident<P, RS_NONE>(a, pl, stream);
   }
   return -1;
 }

@@ -496,23 +496,57 @@ __device__ __forceinline__ void mfma_chunk(const float* xl, const float* wl, f32
   }
 }
 
-// Weight slab global -> LDS without passing through VGPRs (LDS-DMA, 16 bytes per lane): the LDS image is the linear
-// [tap][ci_local][MT] slab, float4 number i written by thread i, i.e. lane-linear per wave as the instruction needs.
+// ---- LDS-DMA (global -> LDS without passing through VGPRs) ----------------------------------------------------------
+// Issued from inline assembly, NOT through __builtin_amdgcn_global_load_lds: with the builtin in a kernel, hipcc's
+// wait-count insertion treats every later LDS read as possibly ordered against a pending "flat" operation and degrades
+// the counted waits of the MFMA loop (ds_read x2 -> s_waitcnt lgkmcnt(2) -> MFMA) to lgkmcnt(0) after every pair of
+// k-steps.  The compiler does not see these loads at all, so: every consumer must be ordered by an explicit
+// s_waitcnt vmcnt (+ barrier), and compiler-generated vmcnt waits around them are only ever more conservative (the
+// hardware counter includes them).  Address = scalar base + 32-bit per-lane byte offset: no per-load vector arithmetic.
+// M0 = LDS byte address of lane 0's element; lane i writes at M0 + i * size.  (M0 is not otherwise used by these kernels;
+// it cannot be named in the clobber list.)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ unsigned lds_addr(const float* l) { return (unsigned)reinterpret_cast<size_t>((lds_ptr_t)const_cast<float*>(l)); }
+__device__ __forceinline__ const float* uniform_ptr(const float* q) {      // the wave-uniform pointer, in SGPRs
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void lds_dma16(const float* sbase, unsigned voff, unsigned m0v) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               : : "s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(uniform_ptr(sbase)) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const float* sbase, unsigned voff, unsigned m0v) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+               : : "s"(__builtin_amdgcn_readfirstlane(m0v)), "v"(voff), "s"(uniform_ptr(sbase)) : "memory");
+}
+
+// Weight slab of chunk `ch`: the LDS image is the linear [tap][ci_local][MT] slab, float4 number i = tid + it * NT
+// written by thread tid in step it (lane-linear per wave, as the instruction needs); a wave past the end of the slab
+// issues nothing.  One step of it (for callers that spread the steps over their MFMA loop), and all of them.
+template <class C>
+struct WeightDma {
+  static constexpr int V4 = C::MT / 4, NV4 = C::WL / 4, IT = (NV4 + C::NT - 1) / C::NT, ROWS_IT = C::NT / V4;
+  static_assert(NV4 % 64 == 0 && C::NT % V4 == 0, "whole waves in the last staging step, whole rows per step");
+  unsigned voff;      // byte offset of this lane's float4 inside a step
+  int wave;
+  __device__ __forceinline__ void init(int coutp, int tid) {
+    voff = 4u * (unsigned)((tid / V4) * coutp + (tid % V4) * 4);
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  }
+  __device__ __forceinline__ void step(int it, const float* chunk_base, unsigned wl_addr, int coutp) const {
+    if (it * C::NT + wave * 64 < NV4)       // wave-uniform
+      lds_dma16(chunk_base + (size_t)it * ROWS_IT * coutp, voff, wl_addr + 16u * (unsigned)(it * C::NT + wave * 64));
+  }
+};
 template <class C>
 __device__ __forceinline__ void dma_weights(const float* wpk, float* wl, int ch, int m0, int coutp, int tid) {
-  constexpr int V4 = C::MT / 4, NV4 = C::WL / 4, IT = (NV4 + C::NT - 1) / C::NT;
-  static_assert(NV4 % 64 == 0, "whole waves in the last staging step");
-  const float* wbase = wpk + (size_t)ch * (C::TAPS * C::KC) * coutp + m0;
+  WeightDma<C> d;
+  d.init(coutp, tid);
+  const float* base = wpk + (size_t)ch * (C::TAPS * C::KC) * coutp + m0;
+  const unsigned wa = lds_addr(wl);
 #pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int i = tid + it * C::NT;
-    if (i < NV4) {      // wave-granular: a wave is either entirely inside the slab or issues nothing
-      const int row = i / V4, c4 = i - row * V4;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wbase + (size_t)row * coutp + c4 * 4), (lds_ptr_t)(wl + i * 4), 16, 0, 0);
-    }
-  }
+  for (int it = 0; it < WeightDma<C>::IT; ++it) d.step(it, base, wa, coutp);
 }
 
 }  // namespace mcedm
