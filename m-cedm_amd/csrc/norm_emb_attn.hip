@@ -190,40 +190,68 @@ __device__ __forceinline__ float wave_dot(const float* x, const float* __restric
   return s;
 }
 
-// grid (n, nsplit): every workgroup evaluates the small mapping MLP (2 x ch^2 MACs), then its slice of the
-// `rows` FiLM rows of all blocks; one wave per output row.  (One thread per row read the weight matrices with a
-// stride of ch floats between lanes and ran on a single workgroup while sampling: 137 us at ch = 512.)
-__global__ __launch_bounds__(256) void embedding_kernel(EmbArgs a) {
+// R rows at once: all R * n / 64 weight loads of a lane are issued before anything waits on them (the kernel is a chain
+// of memory latencies: one row per iteration cost ~0.5 us each, 33 us per launch at ch = 256).  Per row the arithmetic
+// is wave_dot's: the same fmaf chain per lane and the same butterfly, hence the same bits.
+template <int R>
+__device__ __forceinline__ void wave_dot_rows(const float* x, const float* __restrict__ w, int stride, int rows_left, int n,
+                                              int lane, float (&out)[R]) {
+  float s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) s[r] = 0.f;
+  for (int k = lane; k < n; k += 64) {
+    const float xv = x[k];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = fmaf(xv, w[(size_t)(r < rows_left ? r : 0) * stride + k], s[r]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], off);
+#pragma unroll
+  for (int r = 0; r < R; ++r) out[r] = s[r];
+}
+
+// grid (n, nsplit), 16 waves: every workgroup evaluates the small mapping MLP (2 x ch^2 MACs), then its slice of the
+// `rows` FiLM rows of all blocks; four output rows per wave and step.  (One thread per row read the weight matrices
+// with a stride of ch floats between lanes and ran on a single workgroup while sampling: 137 us at ch = 512.)
+constexpr int EMB_NT = 1024, EMB_R = 4;
+__global__ __launch_bounds__(EMB_NT) void embedding_kernel(EmbArgs a) {
   extern __shared__ float sm[];
   float* e0 = sm;            // [ch]
   float* e1 = sm + a.ch;     // [ch]
+  constexpr int NW = EMB_NT / 64;
   const int n = blockIdx.x, split = blockIdx.y, nsplit = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ch = a.ch, half = a.ch / 2;
   const float x = a.labels[n];
-  for (int k = tid; k < ch; k += 256) {
+  for (int k = tid; k < ch; k += EMB_NT) {
     const float arg = x * a.freqs[k < half ? k : k - half];
     e0[k] = (k < half) ? cosf(arg) : sinf(arg);
   }
   __syncthreads();
-  for (int j = wave; j < ch; j += 4) {
-    const float s = wave_dot(e0, a.w0 + (size_t)j * ch, ch, lane);
-    if (lane == 0) e1[j] = silu_e(s + a.b0[j]);
+  float s[EMB_R];
+  for (int j = wave * EMB_R; j < ch; j += NW * EMB_R) {
+    wave_dot_rows<EMB_R>(e0, a.w0 + (size_t)j * ch, ch, ch - j, ch, lane, s);
+    if (lane == 0)
+      for (int r = 0; r < EMB_R && j + r < ch; ++r) e1[j + r] = silu_e(s[r] + a.b0[j + r]);
   }
   __syncthreads();
-  for (int j = wave; j < ch; j += 4) {
-    const float s = wave_dot(e1, a.w1 + (size_t)j * ch, ch, lane);
-    if (lane == 0) {
-      const float v = silu_e(s + a.b1[j]);
-      e0[j] = v;   // e0 is free after the first barrier pair
-      if (a.emb && split == 0) a.emb[(size_t)n * ch + j] = v;
-    }
+  for (int j = wave * EMB_R; j < ch; j += NW * EMB_R) {
+    wave_dot_rows<EMB_R>(e1, a.w1 + (size_t)j * ch, ch, ch - j, ch, lane, s);
+    if (lane == 0)
+      for (int r = 0; r < EMB_R && j + r < ch; ++r) {
+        const float v = silu_e(s[r] + a.b1[j + r]);
+        e0[j + r] = v;   // e0 is free after the first barrier pair
+        if (a.emb && split == 0) a.emb[(size_t)n * ch + j + r] = v;
+      }
   }
   __syncthreads();
   const int per = (a.rows + nsplit - 1) / nsplit;
   const int r1 = min(a.rows, (split + 1) * per);
-  for (int r = split * per + wave; r < r1; r += 4) {
-    const float s = wave_dot(e0, a.waff + (size_t)r * ch, ch, lane);
-    if (lane == 0) a.film[(size_t)n * a.rows + r] = s + a.baff[r];
+  for (int r0 = split * per + wave * EMB_R; r0 < r1; r0 += NW * EMB_R) {
+    wave_dot_rows<EMB_R>(e0, a.waff + (size_t)r0 * ch, ch, r1 - r0, ch, lane, s);
+    if (lane == 0)
+      for (int r = 0; r < EMB_R && r0 + r < r1; ++r) a.film[(size_t)n * a.rows + r0 + r] = s[r] + a.baff[r0 + r];
   }
 }
 
@@ -233,7 +261,7 @@ int launch_embedding(const EmbArgs& a, hipStream_t stream) {
   int nsplit = a.rows / 64;
   if (nsplit > 512 / a.n) nsplit = 512 / a.n;
   if (nsplit < 1) nsplit = 1;
-  hipLaunchKernelGGL(embedding_kernel, dim3(a.n, nsplit), dim3(256), 2 * a.ch * sizeof(float), stream, a);
+  hipLaunchKernelGGL(embedding_kernel, dim3(a.n, nsplit), dim3(EMB_NT), 2 * a.ch * sizeof(float), stream, a);
   MCEDM_LAUNCH_CHECK("embedding_kernel");
   return MCEDM_OK;
 }
