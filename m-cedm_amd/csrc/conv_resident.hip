@@ -17,6 +17,7 @@
 // folded projection's channel pairs), so for one tile configuration the two kernels are BIT-IDENTICAL (tested); which one
 // runs is decided by the image size and channel counts only, never by the batch size.
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <type_traits>
 
@@ -27,6 +28,32 @@
 namespace mcedm {
 
 static constexpr int SKC = 16;      // channels per K chunk of the folded projection (= the packed 1x1 table's chunk)
+
+// Tile configuration of the resident kernel: ConvCfg's members (the shared device code is written against them) with an
+// LDS tile whose rows are whole 16-byte segments of the image rows: row r holds image columns x0 - 4 ... x0 + PW + 3
+// (3x3; tile column -1 at layout column XL0 = 3), so a row is fetched as PITCH / 4 aligned float4 and the tile of one
+// channel ([ROWS][PITCH] floats) is ONE lane-linear DMA instruction of ROWS * PITCH / 4 lanes.
+template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_>
+struct ResCfg {
+  static constexpr int MT = MT_, PH = PH_, PW = PW_, WM = WM_, WN = WN_, TAPS = TAPS_, KC = KC_;
+  static constexpr int CPI = 1, KCI = KC_, NT = 256;
+  static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  static constexpr int XL0 = HALO ? 3 : 0;                  // layout column of tile column -HALO
+  static constexpr int XM = HALO ? 4 : 0;                   // image columns to the left of x0 that a row holds
+  static constexpr int PITCH = HALO ? PW + 8 : PW;
+  static constexpr int ROWS = PH + 2 * HALO;
+  static constexpr int PLANE = ROWS * PITCH;
+  static constexpr int NPIX = PH * PW;
+  static constexpr int TM = MT / WM / 32, TN = NPIX / WN / 32;
+  static constexpr int XL = KCI * PLANE, WL = TAPS * KCI * MT;
+  static constexpr int NWAVE = WM * WN;
+  static constexpr int OCC = 2;
+  // wide staging: lanes per channel, channels per wave instruction
+  static constexpr int RSEG = PITCH / 4, LPC = ROWS * RSEG, CPW = 64 / LPC;
+  // transform pass on pairs of elements (packed fp32 math): pairs per row / channel, channels per workgroup step
+  static constexpr int PPR = HALO ? (PW + 4) / 2 : PW / 2, PC0 = HALO ? 2 : 0, PPC = ROWS * PPR, CPT = NT / PPC;
+  static_assert(NWAVE == 4 && TM >= 1 && TN >= 1 && PITCH % 4 == 0 && LPC <= 64 && CPW >= 1 && CPT >= 1, "tile shape");
+};
 
 // A weight slab = a run of whole rows of the packed table ([tap][ci_local] rows of MT floats at column m0), global -> LDS by
 // DMA: float4 number i = tid + it * NT of the slab goes to LDS float4 i.  A slab is a whole K chunk (TAPS * KC rows), or,
@@ -50,13 +77,13 @@ struct SlabGeom {
 
 template <class C, int RS, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles, int pass_c,
-                                                              int coutp, int nslab) {
+                                                              int coutp, int nslab, int wide) {
   static_assert(RS == RS_NONE || RS == RS_UP, "resampling modes of the resident kernel");
   static_assert(C::NT == 256 && C::NWAVE == 4 && C::CPI == 1, "four compute waves");
   static_assert(SKC * C::MT / 4 == C::NT, "the projection's weight slab is one float4 per thread (one DMA step)");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int CPS = C::NT / C::PLANE;             // input channels staged per step of the workgroup
-  constexpr int CPD = C::NT / C::NPIX;              // projection channels per step (a wave = 64 pixels of one channel)
+  constexpr int CPS = C::NT / C::PLANE;             // narrow staging: input channels per step of the workgroup
+  constexpr int CPD = C::NT / C::NPIX;              // narrow staging of the projection's input: channels per step
   static_assert(CPS >= 1, "tile plane larger than the workgroup");
   typedef SlabGeom<C, SPLIT> SG;
   float* wl = lds;                                  // [nslab][SL] ring of weight slabs (nslab = 3, or 2 when LDS is short)
@@ -120,50 +147,80 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   };
   for (int j = 0; j < dist; ++j) dma_unit(j, j);
 
-  // ---- input tile: thread (chsub, pos) owns element pos of channel c0 + chsub in the step that stages channels c0...
-  const bool active = tid < CPS * C::PLANE;
-  const int chsub = active ? tid / C::PLANE : 0;
-  const int pos = active ? tid - chsub * C::PLANE : 0;
+  // ---- input tile of a pass: raw values by DMA into the [channel][ROWS][PITCH] layout.
   const size_t src_plane = (size_t)p.Hs * p.Ws;
-  unsigned keep, boff;
-  {
-    const int r = pos / C::PITCH, c = pos - r * C::PITCH;
-    const int y = y0 + r - C::HALO, x = x0 + c - C::HALO;
-    const bool inb = active && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
-    keep = inb ? 0xffffffffu : 0u;
-    const int yc = inb ? y : 0, xc = inb ? x : 0;     // padding reads a clamped address and is masked in the transform pass
-    const unsigned o = (RS == RS_UP) ? (unsigned)((yc >> 1) * p.Ws + (xc >> 1)) : (unsigned)(yc * p.Ws + xc);
-    boff = 4u * ((unsigned)chsub * (unsigned)src_plane + o);
-  }
   const float* pa = p.xa + (size_t)n * Ca * src_plane;
   const float* pb = p.xb + (size_t)n * p.Cb * src_plane - (size_t)Ca * src_plane;       // indexed by the concat channel
-  const unsigned xl_addr = lds_addr(xl) + 4u * (unsigned)(wave * 64);
-  // requests channels [cb, cb + pc) of the (concatenated, possibly up-sampled) input by DMA: raw values, halo'd layout
+  const unsigned xl_base = lds_addr(xl);
+  // wide (un-resampled source, rows 16-byte aligned): lane (csub, r, q) of a wave fetches float4 q of tile row r of
+  // channel c + csub: CPW whole channel tiles per instruction, LDS image lane-linear
+  unsigned wboff;
+  bool wlane;
+  {
+    const int csub = lane / C::LPC, rem = lane - csub * C::LPC, r = rem / C::RSEG, q = rem - r * C::RSEG;
+    const int y = y0 - C::HALO + r, xs = x0 - C::XM + 4 * q;
+    wlane = lane < C::CPW * C::LPC;
+    const bool inb = wlane && ((unsigned)y < (unsigned)p.H) && ((unsigned)xs < (unsigned)p.W);   // W % 4 == 0: all four or none
+    wboff = 4u * ((unsigned)csub * (unsigned)src_plane + (inb ? (unsigned)(y * p.Ws + xs) : 0u));   // padding: clamped, masked later
+  }
+  // narrow (2x up-sampled or unaligned source): thread pos of the workgroup fetches element pos of channel c (+ chsub)
+  const bool nactive = tid < CPS * C::PLANE;
+  unsigned nboff;
+  {
+    const int chsub = nactive ? tid / C::PLANE : 0, pos = nactive ? tid - chsub * C::PLANE : 0;
+    const int r = pos / C::PITCH, c = pos - r * C::PITCH;
+    const int y = y0 - C::HALO + r, x = x0 - C::XM + c;
+    const bool inb = nactive && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
+    const int yc = inb ? y : 0, xc = inb ? x : 0;
+    const unsigned o = (RS == RS_UP) ? (unsigned)((yc >> 1) * p.Ws + (xc >> 1)) : (unsigned)(yc * p.Ws + xc);
+    nboff = 4u * ((unsigned)chsub * (unsigned)src_plane + o);
+  }
+  // requests channels [cb, cb + pc) of the (concatenated, possibly up-sampled) input
   auto request_main = [&](int cb, int pc) {
-    const int cend = min(cb + pc, Cin);             // the launcher checks Ca % CPS == 0 and Cin % CPS == 0
-    if (wave * 64 < CPS * C::PLANE) {               // waves that own no tile element issue nothing
+    const int cend = min(cb + pc, Cin);
+    if (wide) {                                     // the launcher checks Ca % CPW == 0 and Cin % CPW == 0
+      for (int c0 = cb + wave * C::CPW; c0 < cend; c0 += 4 * C::CPW) {
+        const float* plane = (c0 < Ca ? pa : pb) + (size_t)c0 * src_plane;
+        if (wlane) lds_dma16(plane, wboff, xl_base + 4u * (unsigned)((c0 - cb) * C::PLANE));
+      }
+    } else if (wave * 64 < CPS * C::PLANE) {        // Ca % CPS == 0 and Cin % CPS == 0; waves without an element issue nothing
       for (int c0 = cb; c0 < cend; c0 += CPS) {
         const float* plane = (c0 < Ca ? pa : pb) + (size_t)c0 * src_plane;
-        if (active) lds_dma4(plane, boff, xl_addr + 4u * (unsigned)((c0 - cb) * C::PLANE));
+        if (nactive) lds_dma4(plane, nboff, xl_base + 4u * (unsigned)((c0 - cb) * C::PLANE + wave * 64));
       }
     }
     // channels that pad the last chunk: zeros (their packed weights are zero too, but LDS garbage may be NaN)
     for (int e = (cend - cb) * C::PLANE + tid; e < pc * C::PLANE; e += C::NT) xl[e] = 0.f;
   };
-  // GroupNorm / FiLM / SiLU and the zero padding, in place: each thread the elements its own wave's DMA wrote
+  // GroupNorm / FiLM / SiLU and the zero padding, in place, on PAIRS of horizontally adjacent elements (one 8-byte LDS
+  // read and write per pair; the per-element arithmetic is apply_coef's).  Thread (tsub, r, pj)
+  // owns layout columns PC0 + 2 pj, + 1 of row r of channel c + tsub; after the barrier that follows the DMA wait.
+  const bool tactive = tid < C::CPT * C::PPC;
+  int tsub, tpos;
+  unsigned keep0, keep1;
+  {
+    tsub = tactive ? tid / C::PPC : 0;
+    const int prem = tactive ? tid - tsub * C::PPC : 0, r = prem / C::PPR, col = C::PC0 + 2 * (prem - r * C::PPR);
+    const int y = y0 - C::HALO + r, x = x0 - C::XM + col;
+    const bool iny = (unsigned)y < (unsigned)p.H;
+    keep0 = (iny && (unsigned)x < (unsigned)p.W) ? 0xffffffffu : 0u;
+    keep1 = (iny && (unsigned)(x + 1) < (unsigned)p.W) ? 0xffffffffu : 0u;
+    tpos = r * C::PITCH + col;
+  }
   auto transform_main = [&](int cb, int pc) {
-    const int nsteps = (min(cb + pc, Cin) - cb) / CPS;
-    if (active) {
-      float* xt = xl + tid;
-      const Coef* ct = cfl + cb + chsub;
+    const int cend = min(cb + pc, Cin);
+    if (tactive) {
       auto pass = [&](auto act_tag) {
         constexpr bool ACT = decltype(act_tag)::value;
-#pragma unroll 8
-        for (int s = 0; s < nsteps; ++s) {
-          const Coef cf = ct[s * CPS];
-          float v = (xt[s * (CPS * C::PLANE)] - cf.mean) * cf.scale + cf.offset;
-          if (ACT) v = silu_f(v);
-          xt[s * (CPS * C::PLANE)] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
+#pragma unroll 4
+        for (int c = cb + tsub; c < cend; c += C::CPT) {
+          const Coef cf = cfl[c];
+          float* px = xl + (c - cb) * C::PLANE + tpos;          // 8-byte aligned: one ds_read_b64 / ds_write_b64
+          float v0 = (px[0] - cf.mean) * cf.scale + cf.offset;
+          float v1 = (px[1] - cf.mean) * cf.scale + cf.offset;
+          if (ACT) { v0 = silu_f(v0); v1 = silu_f(v1); }
+          px[0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & keep0);
+          px[1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & keep1);
         }
       };
       if (p.act) pass(std::true_type{}); else pass(std::false_type{});
@@ -174,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) {
     const int pix = (wn * C::TN + j) * 32 + (lane & 31);
-    boffm[j] = (lane >> 5) * C::PLANE + (pix / C::PW) * C::PITCH + (pix % C::PW);
+    boffm[j] = (lane >> 5) * C::PLANE + (pix / C::PW) * C::PITCH + (pix % C::PW) + C::XL0;
   }
   const int aoff = (lane >> 5) * C::MT + wm * C::TM * 32 + (lane & 31);
 
@@ -234,8 +291,8 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   for (int cb = 0; cb < cin_pad; cb += pass_c) {
     const int pc = min(pass_c, cin_pad - cb);
     if (cb > 0) request_main(cb, pc);               // (the barrier that ended the previous unit freed xl)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this pass's tile (and every older DMA) has landed
-    __syncthreads();                                // first pass: transform rows visible to every wave
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's share of the tile (and every older DMA) has landed
+    __syncthreads();                                // ... and everybody else's; first pass: transform rows visible
     transform_main(cb, pc);
     __syncthreads();
     if (cb == 0 && p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
@@ -250,16 +307,29 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   }
   // ---- passes over the folded projection's input: raw interior pixels, [channel][NPIX]
   if (Csk) {
-    const int pix = tid % C::NPIX, csub = tid / C::NPIX;
-    const int y = min(y0 + pix / C::PW, p.H - 1), x = min(x0 + pix % C::PW, p.W - 1);   // clamped: such pixels are never stored
     const size_t plane = (size_t)p.H * p.W;
-    const unsigned poff = 4u * (unsigned)((size_t)csub * plane + (size_t)y * p.W + x);
     const float* qa = p.sk_xa + (size_t)n * p.sk_Ca * plane;
     const float* qb = p.sk_xb + (size_t)n * p.sk_Cb * plane - (size_t)p.sk_Ca * plane;
+    // narrow: one pixel per thread, CPD channels per step; wide: one float4 of a tile row per lane, CPQ channels per instruction
+    constexpr int SEG = C::PW / 4, LPQ = C::PH * SEG, CPQ = 64 / LPQ;
+    unsigned poff, qoff;
+    {
+      const int pix = tid % C::NPIX, csub = tid / C::NPIX;
+      const int y = min(y0 + pix / C::PW, p.H - 1), x = min(x0 + pix % C::PW, p.W - 1);   // clamped: such pixels are never stored
+      poff = 4u * (unsigned)((size_t)csub * plane + (size_t)y * p.W + x);
+      const int cq = lane / LPQ, rem = lane - cq * LPQ, r = rem / SEG, q = rem - r * SEG;
+      const int yq = min(y0 + r, p.H - 1), xq = min(x0 + 4 * q, p.W - 4);
+      qoff = 4u * (unsigned)((size_t)cq * plane + (size_t)yq * p.W + xq);
+    }
     for (int sb = 0; sb < Csk; sb += pass_c) {
       const int pc = min(pass_c, Csk - sb);         // multiple of SKC
-      for (int c0 = sb; c0 < sb + pc; c0 += CPD)    // the launcher checks sk_Ca % CPD == 0
-        lds_dma4((c0 < p.sk_Ca ? qa : qb) + (size_t)c0 * plane, poff, xl_addr + 4u * (unsigned)((c0 - sb) * C::NPIX));
+      if (wide) {                                   // the launcher checks sk_Ca % CPQ == 0
+        for (int c0 = sb + wave * CPQ; c0 < sb + pc; c0 += 4 * CPQ)
+          lds_dma16((c0 < p.sk_Ca ? qa : qb) + (size_t)c0 * plane, qoff, xl_base + 4u * (unsigned)((c0 - sb) * C::NPIX));
+      } else {
+        for (int c0 = sb; c0 < sb + pc; c0 += CPD)  // sk_Ca % CPD == 0
+          lds_dma4((c0 < p.sk_Ca ? qa : qb) + (size_t)c0 * plane, poff, xl_base + 4u * (unsigned)((c0 - sb) * C::NPIX + wave * 64));
+      }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();
       for (int j = 0; j < pc / SKC; ++j) {
@@ -342,7 +412,7 @@ static int resident_level() {     // 0: off, 1: the 8 x 8-pixel tile (<= 16 x 16
 static constexpr int LDS_MAX = 160 * 1024;
 
 // Launch plan of one conv: channels resident per pass (0: this conv is not served here), weight slabs in the ring.
-struct ResidentPlan { int pass_c = 0, nslab = 0; size_t lds = 0; };
+struct ResidentPlan { int pass_c = 0, nslab = 0, wide = 0; size_t lds = 0; };
 
 template <class C, bool SPLIT>
 static size_t resident_lds_bytes(const ConvArgs& a, int pass_c, int nslab) {
@@ -353,11 +423,16 @@ static size_t resident_lds_bytes(const ConvArgs& a, int pass_c, int nslab) {
 // per pass as fit (a multiple of 16: whole K chunks of the conv and of the projection), at least min_pass.
 template <class C, bool SPLIT>
 static ResidentPlan resident_plan(const ConvArgs& a, size_t budget, int min_pass) {
-  constexpr int CPS = C::NT / C::PLANE, CPD = C::NT / C::NPIX;
+  constexpr int CPS = C::NT / C::PLANE, CPD = C::NT / C::NPIX, CPQ = 64 / (C::PH * (C::PW / 4));
   ResidentPlan r;
   const int Cin = a.Ca + a.Cb, Csk = a.sk_wpk ? a.sk_Ca + a.sk_Cb : 0;
-  if (!a.xa || a.Ca <= 0 || (a.Cb > 0 && !a.xb) || a.Ca % CPS || Cin % CPS) return r;
-  if (Csk && (!a.sk_xa || a.sk_Ca <= 0 || (a.sk_Cb > 0 && !a.sk_xb) || Csk % SKC || a.sk_Ca % CPD)) return r;
+  if (!a.xa || a.Ca <= 0 || (a.Cb > 0 && !a.xb)) return r;
+  if (Csk && (!a.sk_xa || a.sk_Ca <= 0 || (a.sk_Cb > 0 && !a.sk_xb) || Csk % SKC)) return r;
+  // wide staging (float4 row segments by DMA): un-resampled source whose rows and planes are 16-byte aligned
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  r.wide = a.resample == RS_NONE && a.Ws % 4 == 0 && a.W % 4 == 0 && al16(a.xa) && al16(a.xb) && a.Ca % C::CPW == 0 && Cin % C::CPW == 0 &&
+           (!Csk || (al16(a.sk_xa) && al16(a.sk_xb) && a.sk_Ca % CPQ == 0));
+  if (!r.wide && (a.Ca % CPS || Cin % CPS || (Csk && a.sk_Ca % CPD))) { r.wide = 0; return r; }
   const int need = std::max(ceil_div(Cin, C::KC) * C::KC, Csk);      // channels of the longest input (padded to chunks)
   const int all = ceil_div(need, 16) * 16;
   for (int nslab = 3; nslab >= 2; --nslab) {
@@ -389,8 +464,8 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
   }
   char name[96] = "";
   if (prof_enabled())
-    snprintf(name, sizeof(name), "conv_resident_kernel<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %d>, %d, %s>", C::MT, C::PH, C::PW,
-             C::WM, C::WN, C::TAPS, C::KC, C::NT, C::CPI, RS, SPLIT ? "true" : "false");
+    snprintf(name, sizeof(name), "conv_resident_kernel<ResCfg<%d, %d, %d, %d, %d, %d, %d>, %d, %s>", C::MT, C::PH, C::PW, C::WM, C::WN,
+             C::TAPS, C::KC, RS, SPLIT ? "true" : "false");
   const double px = (double)a.B * a.H * a.W;
   const double skc = a.sk_wpk ? (double)(a.sk_Ca + a.sk_Cb) : 0.0;
   const double flops = 2.0 * px * a.Cout * ((double)(a.Ca + a.Cb) * C::TAPS + skc);
@@ -398,7 +473,7 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
                               (double)a.Cout * ((a.Ca + a.Cb) * C::TAPS + skc));
   ProfScope ps(name, flops, bytes, stream);
   hipLaunchKernelGGL((conv_resident_kernel<C, RS, SPLIT>), dim3((unsigned)blocks), dim3(256), (unsigned)plan.lds, stream, a, tiles_x,
-                     tiles_y, mtiles, plan.pass_c, cout_padded(a.Cout), plan.nslab);
+                     tiles_y, mtiles, plan.pass_c, cout_padded(a.Cout), plan.nslab, plan.wide);
   MCEDM_LAUNCH_CHECK("conv_resident_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
   return MCEDM_OK;
@@ -413,8 +488,8 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
   const bool small = (long long)a.H * a.W <= 256 || a.W < 12;          // the 8 x 8-pixel tile of dispatch()
   const size_t whole_cu = (size_t)LDS_MAX - 1024, half_cu = 80 * 1024 - 512;
   if (taps == 9) {
-    typedef ConvCfg<64, 8, 8, 2, 2, 9, 8> S;
-    typedef ConvCfg<64, 8, 16, 1, 4, 9, 8> M;
+    typedef ResCfg<64, 8, 8, 2, 2, 9, 8> S;
+    typedef ResCfg<64, 8, 16, 1, 4, 9, 8> M;
     if (small) {          // <= 256 workgroups per 64 samples: one per CU, the whole LDS
       const ResidentPlan pl = resident_plan<S, false>(a, whole_cu, 64);
       if (!pl.pass_c) return -1;
@@ -429,7 +504,7 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
     }
     return -1;
   }
-  typedef ConvCfg<64, 8, 8, 2, 2, 1, 16> P;
+  typedef ResCfg<64, 8, 8, 2, 2, 1, 16> P;
   if (small && !a.sk_wpk) {
     const ResidentPlan pl = resident_plan<P, false>(a, whole_cu, 64);
     if (pl.pass_c) return launch_resident<P, RS_NONE>(a, pl, stream);
