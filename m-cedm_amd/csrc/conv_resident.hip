@@ -77,7 +77,7 @@ struct SlabGeom {
 
 template <class C, int RS, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int tiles_x, int tiles_y, int mtiles, int pass_c,
-                                                              int coutp, int nslab, int wide) {
+                                                              int coutp, int nslab, int wide, int stagger) {
   static_assert(RS == RS_NONE || RS == RS_UP, "resampling modes of the resident kernel");
   static_assert(C::NT == 256 && C::NWAVE == 4 && C::CPI == 1, "four compute waves");
   static_assert(SKC * C::MT / 4 == C::NT, "the projection's weight slab is one float4 per thread (one DMA step)");
@@ -276,7 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   // ---- passes over the conv's input channels: pass_c channels of the tile are resident at a time (all of them when
   // they fit).  While this workgroup re-stages, the other workgroup of the CU has the matrix pipe.
   const int cin_pad = nchunks * C::KC;
-  request_main(0, min(pass_c, cin_pad));
+  // Stagger: when the conv needs more than one pass, every other "slot" of workgroups (blockIdx / stagger: the launcher
+  // passes the CU count, so the two workgroups that share a CU differ) takes a short FIRST pass.  Its matrix phase then
+  // starts while its CU partner is still staging, and from there on one of them computes while the other re-stages.
+  // The K sum visits the chunks in the same order either way.
+  const int first_c = (stagger > 0 && cin_pad > pass_c && ((blockIdx.x / stagger) & 1)) ? 16 : pass_c;
+  request_main(0, min(first_c, cin_pad));
   // accumulators = bias (+ residual), transform rows: under the first pass's DMA
   if (m0 + C::MT <= p.Cout) {
     if (!p.res) conv_init_acc<C, 0, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
@@ -288,8 +293,8 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     else conv_init_acc<C, 1, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
   }
   stage_coef_rows<C::NT>(p, n, cfl, tid);
-  for (int cb = 0; cb < cin_pad; cb += pass_c) {
-    const int pc = min(pass_c, cin_pad - cb);
+  for (int cb = 0, pc = 0; cb < cin_pad; cb += pc) {
+    pc = min(cb == 0 ? first_c : pass_c, cin_pad - cb);
     if (cb > 0) request_main(cb, pc);               // (the barrier that ended the previous unit freed xl)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's share of the tile (and every older DMA) has landed
     __syncthreads();                                // ... and everybody else's; first pass: transform rows visible
@@ -455,9 +460,11 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
   const long long blocks = (long long)a.B * tiles_x * tiles_y * mtiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv grid out of range (%lld blocks)", blocks); return MCEDM_ERR_INVALID; }
   static bool attr_set[64] = {};
+  static int ncu[64] = {};
   int dev = 0;
   MCEDM_HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) { set_error("device index %d out of range", dev); return MCEDM_ERR_INVALID; }
+  if (!ncu[dev]) MCEDM_HIP_TRY(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
   if (!attr_set[dev]) {
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_resident_kernel<C, RS, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     attr_set[dev] = true;
@@ -473,7 +480,7 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
                               (double)a.Cout * ((a.Ca + a.Cb) * C::TAPS + skc));
   ProfScope ps(name, flops, bytes, stream);
   hipLaunchKernelGGL((conv_resident_kernel<C, RS, SPLIT>), dim3((unsigned)blocks), dim3(256), (unsigned)plan.lds, stream, a, tiles_x,
-                     tiles_y, mtiles, plan.pass_c, cout_padded(a.Cout), plan.nslab, plan.wide);
+                     tiles_y, mtiles, plan.pass_c, cout_padded(a.Cout), plan.nslab, plan.wide, SPLIT ? ncu[dev] : 0);
   MCEDM_LAUNCH_CHECK("conv_resident_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
   return MCEDM_OK;
