@@ -270,6 +270,9 @@ int mcedm_op_set_conv8(int enable);
  * weights streamed by DMA): 0 off (every conv takes conv_mfma_kernel), 1 for <= 16 x 16 images, 2 also for ~32 x 32
  * images (slower there today), -1 back to the default (env MCEDM_CONV_RESIDENT, else 1).  Bit-identical to conv_mfma_kernel on the same tile.  Process-global, not thread-safe. */
 int mcedm_op_set_conv_resident(int enable);
+/* The single-launch attention part of a UNetBlock at 8 x 8 x 64 channels (attn_fused.hip; inference only): 1 on, 0 off
+ * (qkv conv + attention kernel + proj conv), -1 back to the default (env MCEDM_ATTN_FUSED, else on).  Process-global. */
+int mcedm_op_set_attn_fused(int enable);
 /* Diagnostics: when buf != NULL every conv workgroup writes 16 x u64 at buf[16*blockIdx]: [0..3] timestamps (10 ns
  * units) at start / first chunk / end of K loop / end of epilogue, [4] (XCC id << 32 | HW_ID), [5..6] shader-clock
  * counter at the K loop's ends, [8..] per-phase cycle sums (MCEDM_CONV_TIMELINE builds) or per-wave HW_ID (8-wave

@@ -164,5 +164,11 @@ int launch_embedding(const EmbArgs& a, hipStream_t stream);
 
 // attention (K5): qkv [B][heads][3][64][T] -> a [B][heads*64][T]
 int launch_attention(const float* qkv, float* out, int B, int heads, int T, hipStream_t stream);
+// attn_fused.hip: z = proj(attention(qkv(group_norm(y)))) + y in one launch (8 x 8 tokens, 64 channels, one head; inference)
+bool attn_block_fused_applicable(int C, int heads, int H, int W, int groups);
+int launch_attn_block64(const float* y, float* z, const float* gamma, const float* beta, float eps, int groups, const float* wq,
+                        const float* bq, const float* wp, const float* bp, float* gsum, SumTiles* gsum_tiles, int B,
+                        hipStream_t stream);
+void set_attn_fused(int enable);      // 1 / 0, -1: default (env MCEDM_ATTN_FUSED, else on)
 
 }  // namespace mcedm

@@ -125,6 +125,11 @@ extern "C" int mcedm_op_set_conv_resident(int enable) {
   return MCEDM_OK;
 }
 
+extern "C" int mcedm_op_set_attn_fused(int enable) {
+  set_attn_fused(enable);
+  return MCEDM_OK;
+}
+
 extern "C" int mcedm_op_set_conv_debug(unsigned long long* buf) {
   set_conv_debug(buf);
   return MCEDM_OK;

@@ -555,6 +555,9 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   if ((rc = launch_conv(c1, 9, s))) return rc;
   if (!b.attn) return MCEDM_OK;
   // attention: z = proj(attn(qkv(norm2(y)))) + y
+  if (bl.stats2 < 0 && attn_block_fused_applicable(b.cout, b.heads, bl.H, bl.W, b.norm2.groups))     // inference, 8 x 8 x 64: one launch
+    return launch_attn_block64(T(bl.y), T(bl.z), pk + b.norm2.gamma, pk + b.norm2.beta, eps, b.norm2.groups, pk + b.qkv.wpk,
+                               pk + b.qkv.bias, pk + b.proj.wpk, pk + b.proj.bias, SUMS(bl.z), &st[bl.z], B, s);
   GnArgs g2{T(bl.y), nullptr, b.cout, 0, bl.H * bl.W, B, b.norm2.groups, pk + b.norm2.gamma, pk + b.norm2.beta,
             nullptr, 0, 0, eps, CF(bl.coef2), T(bl.stats2), SUMS(bl.y), nullptr, TL(bl.y), SumTiles{}, bl.W};
   ConvArgs cq{};

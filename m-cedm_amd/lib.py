@@ -623,7 +623,7 @@ def _bind_ops():
 OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv",
               "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report",
               "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd",
-              "mcedm_op_set_conv_debug", "mcedm_op_set_conv8", "mcedm_op_set_conv_resident", "mcedm_op_embedding"]
+              "mcedm_op_set_conv_debug", "mcedm_op_set_conv8", "mcedm_op_set_conv_resident", "mcedm_op_set_attn_fused", "mcedm_op_embedding"]
 
 
 def prof_enable(on: bool) -> None:
@@ -659,6 +659,13 @@ def set_conv_resident(enable: int = -1) -> None:
     lib = _bind_ops()
     lib.mcedm_op_set_conv_resident.argtypes = [C.c_int]
     check(lib.mcedm_op_set_conv_resident(int(enable)), "set_conv_resident")
+
+
+def set_attn_fused(enable: int = -1) -> None:
+    """Single-launch attention block at 8 x 8 x 64 (inference): 1 / 0; -1 = default (on)."""
+    lib = _bind_ops()
+    lib.mcedm_op_set_attn_fused.argtypes = [C.c_int]
+    check(lib.mcedm_op_set_attn_fused(int(enable)), "set_attn_fused")
 
 
 RS_NONE, RS_UP, RS_DOWN, RS_S2 = 0, 1, 2, 3

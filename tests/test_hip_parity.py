@@ -257,6 +257,28 @@ def test_unet_forward_resident_on_off_identical(lib, net_P):
     assert torch.equal(F1, F0), f"max |d| = {(F1 - F0).abs().max().item():.3e}"
 
 
+def test_unet_forward_fused_attention_block_vs_three_launches(lib, net_P):
+    """attn_block64_kernel (GroupNorm + qkv + softmax attention + proj + residual of an 8 x 8 x 64 block in one launch) against
+    the qkv conv / attention kernel / proj conv sequence on the whole 32 x 32 U-Net, and both against the oracle."""
+    plan, packed, P = net_P
+    x, cond = fx.randn("unet_P/x", 4, 2, 32, 32), fx.randn("unet_P/cond", 4, 2, 32, 32)
+    labels = dev(fx.UNET_LABELS["nB"])
+    lib.prof_enable(True)
+    try:
+        F1 = plan.forward(packed, dev(x), labels, cond=dev(cond))
+        names = [r["name"] for r in lib.prof_report()]
+    finally:
+        lib.prof_enable(False)
+    assert "attn_block64_kernel" in names and "attention_kernel" not in names, names
+    lib.set_attn_fused(0)
+    try:
+        F0 = plan.forward(packed, dev(x), labels, cond=dev(cond))
+    finally:
+        lib.set_attn_fused(-1)
+    close(F1, F0.cpu(), what="fused attention block vs three launches")
+    close(F1, orc.unet_forward(P, fx.CFG_P, x, fx.UNET_LABELS["nB"], cond), what="fused attention block vs oracle")
+
+
 @pytest.mark.parametrize("Cout", [1, 2, 3, 4])
 def test_output_conv_direct_kernel(lib, Cout):
     # ch -> out_channels 3x3 conv on a large image takes the direct (non-MFMA) kernel: ragged 72 x 88 image,
