@@ -505,8 +505,11 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
     if (a.W >= 24 && (long long)a.H * a.W <= 1024) {
       // ~32 x 32 images, 512+ workgroups: half-chunk weight slabs and <= 64 resident channels per pass keep a workgroup
       // under 80 KB of LDS, so TWO share a CU and one computes while the other re-stages
-      const ResidentPlan pl = resident_plan<M, true>(a, half_cu, 32);
+      ResidentPlan pl = resident_plan<M, true>(a, half_cu, 32);
       if (!pl.pass_c || pl.nslab != 3) return -1;
+      static int pass_env = -1;      // experiments: MCEDM_RES_PASS = channels per pass (multiple of 16, <= the plan's)
+      if (pass_env < 0) { const char* e = getenv("MCEDM_RES_PASS"); pass_env = e ? atoi(e) : 0; }
+      if (pass_env >= 16 && pass_env % 16 == 0 && pass_env < pl.pass_c) pl.pass_c = pass_env;
       return a.resample == RS_UP ? launch_resident<M, RS_UP, true>(a, pl, stream) : launch_resident<M, RS_NONE, true>(a, pl, stream);
     }
     return -1;
