@@ -133,7 +133,7 @@ int conv_resolve_identity(ConvArgs& a);                  // points a missing tra
 unsigned long long* conv_debug_buffer();
 int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream);   // conv_resident.hip; -1: not served there
 void set_conv_resident(int enable);                      // 1 / 0, -1: default (env MCEDM_CONV_RESIDENT, else on)
-static inline int conv_max_tiles(int H, int W) { return ((H + 7) / 8) * ((W + 7) / 8); }   // smallest pixel tile is 8x8
+static inline int conv_max_tiles(int H, int W) { return ((H + 3) / 4) * ((W + 7) / 8); }   // smallest pixel tile is 4x8 (conv_resident.hip)
 void set_conv_tile_override(int mt, int ph, int pw);
 void set_conv8(int enable);   // 1 / 0, -1: default (env MCEDM_CONV8, else off)
 void set_conv_debug(unsigned long long* buf);   // test hook; (0,0,0) restores the heuristic

@@ -33,9 +33,13 @@ static constexpr int SKC = 16;      // channels per K chunk of the folded projec
 // LDS tile whose rows are whole 16-byte segments of the image rows: row r holds image columns x0 - 4 ... x0 + PW + 3
 // (3x3; tile column -1 at layout column XL0 = 3), so a row is fetched as PITCH / 4 aligned float4 and the tile of one
 // channel ([ROWS][PITCH] floats) is ONE lane-linear DMA instruction of ROWS * PITCH / 4 lanes.
-template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_>
+// KS > 1 (K split): the workgroup's KS * WM * WN = 4 waves form KS groups that own the SAME output tile and take every
+// KS-th K chunk each; the partial accumulators meet in LDS before the epilogue.  It makes the tile small enough
+// (32 channels x 4 x 8 pixels) for 8 x 8 images to spread over 256 workgroups instead of 64, with a quarter of the
+// dependent MFMA chain per wave.
+template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_, int KS_ = 1>
 struct ResCfg {
-  static constexpr int MT = MT_, PH = PH_, PW = PW_, WM = WM_, WN = WN_, TAPS = TAPS_, KC = KC_;
+  static constexpr int MT = MT_, PH = PH_, PW = PW_, WM = WM_, WN = WN_, TAPS = TAPS_, KC = KC_, KS = KS_;
   static constexpr int CPI = 1, KCI = KC_, NT = 256;
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
   static constexpr int XL0 = HALO ? 3 : 0;                  // layout column of tile column -HALO
@@ -46,7 +50,7 @@ struct ResCfg {
   static constexpr int NPIX = PH * PW;
   static constexpr int TM = MT / WM / 32, TN = NPIX / WN / 32;
   static constexpr int XL = KCI * PLANE, WL = TAPS * KCI * MT;
-  static constexpr int NWAVE = WM * WN;
+  static constexpr int NWAVE = WM * WN * KS;
   static constexpr int OCC = 2;
   // wide staging: lanes per channel, channels per wave instruction
   static constexpr int RSEG = PITCH / 4, LPC = ROWS * RSEG, CPW = 64 / LPC;
@@ -66,12 +70,14 @@ struct SlabGeom {
   static constexpr int TSPLIT = 5;
   static constexpr int V4 = C::MT / 4;                              // float4 per row
   static constexpr int ROWS_IT = C::NT / V4;                        // slab rows per DMA step of the workgroup
-  static constexpr int ROWS_MAX = (SPLIT ? TSPLIT : C::TAPS) * C::KC;
+  static constexpr int CROWS = C::TAPS * C::KC;                     // table rows of one K chunk
+  static constexpr int ROWS_MAX = SPLIT ? TSPLIT * C::KC : C::KS * CROWS;   // a slab: half a chunk, or the KS chunks of a unit
   static constexpr int SL = ROWS_MAX * C::MT;                       // floats of a ring slot
   static constexpr int ITU = (ROWS_MAX * V4 + C::NT - 1) / C::NT;   // DMA instructions per wave and slab
   static constexpr int NU = SPLIT ? 2 : 1;                          // slabs (= K-loop units) per chunk
   static_assert(C::NT % V4 == 0 && (ROWS_MAX * V4) % 64 == 0 && ROWS_MAX * V4 >= C::NT, "whole rows per step, whole waves");
-  static_assert(!SPLIT || (C::TAPS == 9 && ((C::TAPS - TSPLIT) * C::KC * V4) % 64 == 0), "split slabs are for 3x3");
+  static_assert(!SPLIT || (C::KS == 1 && C::TAPS == 9 && ((C::TAPS - TSPLIT) * C::KC * V4) % 64 == 0), "split slabs are for 3x3");
+  static_assert((CROWS * V4) % 64 == 0, "a chunk is whole waves of float4");
   static_assert(ITU <= (SPLIT ? C::TAPS - TSPLIT : C::TAPS), "one DMA step per tap of a unit");
 };
 
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
                                                               int coutp, int nslab, int wide, int stagger) {
   static_assert(RS == RS_NONE || RS == RS_UP, "resampling modes of the resident kernel");
   static_assert(C::NT == 256 && C::NWAVE == 4 && C::CPI == 1, "four compute waves");
-  static_assert(SKC * C::MT / 4 == C::NT, "the projection's weight slab is one float4 per thread (one DMA step)");
+  static_assert(SKC * C::MT / 4 <= C::NT && (SKC * C::MT / 4) % 64 == 0, "the projection's weight slab is one DMA step of whole waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CPS = C::NT / C::PLANE;             // narrow staging: input channels per step of the workgroup
   constexpr int CPD = C::NT / C::NPIX;              // narrow staging of the projection's input: channels per step
@@ -94,7 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / C::WN;
+  const int ks = wave / (C::WM * C::WN);            // K group of this wave (0 when KS == 1)
+  const int wm = (wave / C::WN) % C::WM;
   const int wn = wave % C::WN;
   int bid = blockIdx.x;
   const int mt = bid % mtiles; bid /= mtiles;
@@ -107,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   const int Csk = p.sk_wpk ? p.sk_Ca + p.sk_Cb : 0;
   const int nchunks = (Cin + C::KC - 1) / C::KC;    // K chunks of the conv over all passes
   const int nsk = Csk / SKC;                        // K chunks of the folded projection (the launcher checks Csk % SKC == 0)
-  const int nwu = SG::NU * nchunks;                 // K-loop units that stream conv weights; then nsk projection units
+  const int nwu = SG::NU * ((nchunks + C::KS - 1) / C::KS);   // K-loop units that stream conv weights (KS chunks each, or half a
+                                                              // chunk in SPLIT mode); then nsk projection units
   const int nunits = nwu + nsk;
   const int dist = nslab - 1;                       // slabs in flight ahead of the one being consumed
 
@@ -121,20 +129,26 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   // unit v of the K loop -> where its slab comes from; kind 2: conv weights, 1: projection weights, 0: past the end
   auto unit_src = [&](int v, const float*& base, int& nv4) -> int {
     if (v < nwu) {
-      const int ch = SPLIT ? v >> 1 : v, part = SPLIT ? v & 1 : 0;
-      base = wbase + (size_t)ch * wchunk + (part ? (size_t)SG::TSPLIT * C::KC * coutp : 0);
-      nv4 = (SPLIT ? (part ? C::TAPS - SG::TSPLIT : SG::TSPLIT) : C::TAPS) * C::KC * SG::V4;
+      if (SPLIT) {
+        const int ch = v >> 1, part = v & 1;
+        base = wbase + (size_t)ch * wchunk + (part ? (size_t)SG::TSPLIT * C::KC * coutp : 0);
+        nv4 = (part ? C::TAPS - SG::TSPLIT : SG::TSPLIT) * C::KC * SG::V4;
+      } else {
+        base = wbase + (size_t)v * C::KS * wchunk;
+        nv4 = min(C::KS, nchunks - v * C::KS) * SG::CROWS * SG::V4;   // the last unit may hold fewer chunks
+      }
       return 2;
     }
-    if (v < nunits) { base = skbase + (size_t)(v - nwu) * SKC * coutp; nv4 = C::NT; return 1; }
+    if (v < nunits) { base = skbase + (size_t)(v - nwu) * SKC * coutp; nv4 = SKC * SG::V4; return 1; }
     return 0;
   };
+  // step `it` of a slab's DMA; a wave whose float4s of that step lie past the slab repeats its last valid step
   auto dma_step = [&](int it, const float* base, int nv4, int slab) {
     int st = it;
-    if (it * C::NT + wave * 64 >= nv4) st = it - 1;                   // wave-uniform
+    while (st > 0 && st * C::NT + wave * 64 >= nv4) --st;             // wave-uniform
     lds_dma16(base + (size_t)st * SG::ROWS_IT * coutp, wvoff, wl_addr + 4u * (unsigned)(slab * SG::SL) + 16u * (unsigned)(st * C::NT + wave * 64));
   };
-  auto dma_unit = [&](int v, int slab) -> int {     // all steps at once; returns the DMA instructions per wave
+  auto dma_unit = [&](int v, int slab) -> int {     // all steps at once; returns the DMA instructions this wave issued
     const float* base; int nv4;
     const int kind = unit_src(v, base, nv4);
     if (kind == 2) {
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
       for (int it = 0; it < SG::ITU; ++it) dma_step(it, base, nv4, slab);
       return SG::ITU;
     }
-    if (kind == 1) { dma_step(0, base, nv4, slab); return 1; }
+    if (kind == 1 && wave * 64 < nv4) { dma_step(0, base, nv4, slab); return 1; }
     return 0;
   };
   for (int j = 0; j < dist; ++j) dma_unit(j, j);
@@ -250,10 +264,12 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     sn = sn + 1 == nslab ? 0 : sn + 1;
     ++u;
   };
-  // one weight unit: taps [T0, T1) of the pass's chunk cl out of slab sc
-  auto weight_unit = [&](int cl, auto t0_tag, auto t1_tag) {
+  // one weight unit: taps [T0, T1) of the pass's chunk(s) KS * ul + ks out of slab sc; cmax = chunks in this pass
+  auto weight_unit = [&](int ul, int cmax, auto t0_tag, auto t1_tag) {
     constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
-    const float* wc = wl + sc * SG::SL;
+    const int cl = C::KS * ul + ks;
+    const float* wc = wl + sc * SG::SL + ks * (SG::CROWS * C::MT);
+    const float* xc = xl + cl * C::KC * C::PLANE;
     const float* nb; int nv4;
     const int kind = unit_src(u + dist, nb, nv4);
     if (kind == 2) {
@@ -261,14 +277,19 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
       // the shadow of the MFMAs (issued in a block in front of them they cost ~90 cycles each: the memory pipeline
       // accepts them slowly)
       const int slab = sn;
-      mfma_chunk<C, true, false, T0, T1>(xl + cl * C::KC * C::PLANE, wc, acc, aoff, boffm, [&](int t) {
-        if (t < SG::ITU) dma_step(t, nb, nv4, slab);
-      });
+      if (C::KS == 1 || cl < cmax) {
+        mfma_chunk<C, true, false, T0, T1>(xc, wc, acc, aoff, boffm, [&](int t) {
+          if (t < SG::ITU) dma_step(t, nb, nv4, slab);
+        });
+      } else {
+#pragma unroll
+        for (int t = 0; t < SG::ITU; ++t) dma_step(t, nb, nv4, slab);
+      }
       finish_unit(SG::ITU);
     } else {
-      const int issued = kind == 1 ? (dma_step(0, nb, nv4, sn), 1) : 0;
+      const int issued = (kind == 1 && wave * 64 < nv4) ? (dma_step(0, nb, nv4, sn), 1) : 0;
       __builtin_amdgcn_sched_barrier(0);
-      mfma_chunk<C, true, false, T0, T1>(xl + cl * C::KC * C::PLANE, wc, acc, aoff, boffm);
+      if (C::KS == 1 || cl < cmax) mfma_chunk<C, true, false, T0, T1>(xc, wc, acc, aoff, boffm);
       finish_unit(issued);
     }
   };
@@ -283,14 +304,23 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   const int first_c = (stagger > 0 && cin_pad > pass_c && ((blockIdx.x / stagger) & 1)) ? 16 : pass_c;
   request_main(0, min(first_c, cin_pad));
   // accumulators = bias (+ residual), transform rows: under the first pass's DMA
-  if (m0 + C::MT <= p.Cout) {
-    if (!p.res) conv_init_acc<C, 0, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else conv_init_acc<C, 1, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
+  if (ks == 0) {
+    if (m0 + C::MT <= p.Cout) {
+      if (!p.res) conv_init_acc<C, 0, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
+      else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
+      else conv_init_acc<C, 1, true>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    } else {
+      if (!p.res) conv_init_acc<C, 0, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
+      else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
+      else conv_init_acc<C, 1, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
+    }
   } else {
-    if (!p.res) conv_init_acc<C, 0, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else if (p.res_mode == RS_DOWN) conv_init_acc<C, 2, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
-    else conv_init_acc<C, 1, false>(p, acc, n, m0, y0, x0, wm, wn, lane);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
   stage_coef_rows<C::NT>(p, n, cfl, tid);
   for (int cb = 0, pc = 0; cb < cin_pad; cb += pc) {
@@ -301,12 +331,13 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     transform_main(cb, pc);
     __syncthreads();
     if (cb == 0 && p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
-    for (int cl = 0; cl < pc / C::KC; ++cl) {
+    const int cmax = pc / C::KC;                    // chunks of this pass (the launcher makes passes whole units)
+    for (int ul = 0; ul * C::KS < cmax; ++ul) {
       if constexpr (SPLIT) {
-        weight_unit(cl, std::integral_constant<int, 0>{}, std::integral_constant<int, SG::TSPLIT>{});
-        weight_unit(cl, std::integral_constant<int, SG::TSPLIT>{}, std::integral_constant<int, C::TAPS>{});
+        weight_unit(ul, cmax, std::integral_constant<int, 0>{}, std::integral_constant<int, SG::TSPLIT>{});
+        weight_unit(ul, cmax, std::integral_constant<int, SG::TSPLIT>{}, std::integral_constant<int, C::TAPS>{});
       } else {
-        weight_unit(cl, std::integral_constant<int, 0>{}, std::integral_constant<int, C::TAPS>{});
+        weight_unit(ul, cmax, std::integral_constant<int, 0>{}, std::integral_constant<int, C::TAPS>{});
       }
     }
   }
@@ -343,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
         const int issued = dma_unit(u + dist, sn);
         __builtin_amdgcn_sched_barrier(0);
         const float* skc = xl + (size_t)j * SKC * C::NPIX + (lane >> 5) * C::NPIX + (lane & 31);
+        if (C::KS == 1 || ks == j % C::KS) {          // K-split tiles: the groups take the projection's chunks in turn
         float fa[2][C::TM], fb[2][C::TN];
 #pragma unroll
         for (int ii = 0; ii < C::TM; ++ii) fa[0][ii] = wc[aoff + ii * 32];
@@ -362,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
           __builtin_amdgcn_sched_group_barrier(0x100, C::TM + C::TN, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, C::TM * C::TN, 0);
         }
+        }
         finish_unit(issued);
       }
     }
@@ -371,12 +404,40 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
   const bool full = (m0 + C::MT <= p.Cout);
   float* red = wl;                                  // the slabs are dead after the last barrier
-  if (p.gsum) {
-    if (full) conv_epilogue<C, true, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-    else conv_epilogue<C, false, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-  } else {
-    if (full) conv_epilogue<C, true, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-    else conv_epilogue<C, false, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+  if constexpr (C::KS > 1) {
+    // the K groups' partial sums meet in LDS (the input tile is dead): groups 1 ... KS-1 store, group 0 adds them in order
+    float* part = xl;                               // [KS - 1][WM * WN waves][TM * TN * 16][64 lanes]
+    constexpr int PER_WAVE = C::TM * C::TN * 16 * 64;
+    if (ks > 0) {
+      float* dst = part + ((ks - 1) * (C::WM * C::WN) + wm * C::WN + wn) * PER_WAVE + lane;
+#pragma unroll
+      for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((i * C::TN + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+      for (int g = 1; g < C::KS; ++g) {
+        const float* src = part + ((g - 1) * (C::WM * C::WN) + wm * C::WN + wn) * PER_WAVE + lane;
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * C::TN + j) * 16 + r) * 64];
+      }
+    }
+  }
+  if (ks == 0) {
+    if (p.gsum) {
+      if (full) conv_epilogue<C, true, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else conv_epilogue<C, false, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+    } else {
+      if (full) conv_epilogue<C, true, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+      else conv_epilogue<C, false, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+    }
   }
   if (p.dbg && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,11 +500,12 @@ static ResidentPlan resident_plan(const ConvArgs& a, size_t budget, int min_pass
            (!Csk || (al16(a.sk_xa) && al16(a.sk_xb) && a.sk_Ca % CPQ == 0));
   if (!r.wide && (a.Ca % CPS || Cin % CPS || (Csk && a.sk_Ca % CPD))) { r.wide = 0; return r; }
   const int need = std::max(ceil_div(Cin, C::KC) * C::KC, Csk);      // channels of the longest input (padded to chunks)
-  const int all = ceil_div(need, 16) * 16;
+  constexpr int G = C::KS * C::KC > 16 ? C::KS * C::KC : 16;         // a pass is whole K units of the conv and of the projection
+  const int all = ceil_div(need, G) * G;
   for (int nslab = 3; nslab >= 2; --nslab) {
     const size_t fixed = resident_lds_bytes<C, SPLIT>(a, 0, nslab);
     if (fixed >= budget) continue;
-    int pc = (int)((budget - fixed) / (sizeof(float) * C::PLANE)) / 16 * 16;
+    int pc = (int)((budget - fixed) / (sizeof(float) * C::PLANE)) / G * G;
     if (pc > all) pc = all;
     if (pc >= std::min(min_pass, all)) { r.pass_c = pc; r.nslab = nslab; r.lds = resident_lds_bytes<C, SPLIT>(a, pc, nslab); return r; }
   }
@@ -471,8 +533,8 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
   }
   char name[96] = "";
   if (prof_enabled())
-    snprintf(name, sizeof(name), "conv_resident_kernel<ResCfg<%d, %d, %d, %d, %d, %d, %d>, %d, %s>", C::MT, C::PH, C::PW, C::WM, C::WN,
-             C::TAPS, C::KC, RS, SPLIT ? "true" : "false");
+    snprintf(name, sizeof(name), "conv_resident_kernel<ResCfg<%d, %d, %d, %d, %d, %d, %d, %d>, %d, %s>", C::MT, C::PH, C::PW, C::WM, C::WN,
+             C::TAPS, C::KC, C::KS, RS, SPLIT ? "true" : "false");
   const double px = (double)a.B * a.H * a.W;
   const double skc = a.sk_wpk ? (double)(a.sk_Ca + a.sk_Cb) : 0.0;
   const double flops = 2.0 * px * a.Cout * ((double)(a.Ca + a.Cb) * C::TAPS + skc);
@@ -491,12 +553,20 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
 int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
   if (resident_level() <= 0) return -1;
   if (a.resample != RS_NONE && !(a.resample == RS_UP && taps == 9)) return -1;
-  if (cout_padded(a.Cout) % 64 != 0) return -1;
   const bool small = (long long)a.H * a.W <= 256 || a.W < 12;          // the 8 x 8-pixel tile of dispatch()
   const size_t whole_cu = (size_t)LDS_MAX - 1024, half_cu = 80 * 1024 - 512;
   if (taps == 9) {
     typedef ResCfg<64, 8, 8, 2, 2, 9, 8> S;
     typedef ResCfg<64, 8, 16, 1, 4, 9, 8> M;
+    typedef ResCfg<32, 4, 8, 1, 1, 9, 8, 4> K;
+    if (a.H <= 8 && a.W <= 8 && a.resample == RS_NONE && cout_padded(a.Cout) % 32 == 0) {
+      // <= 8 x 8 images: one <64, 8, 8> tile per sample would leave 3/4 of the CUs idle at B = 64.  Tiles of 32 channels
+      // x 4 x 8 pixels with the K loop split over the four waves: 4x the workgroups, a quarter of the MFMA chain each.
+      // (The K sum is grouped differently from conv_mfma_kernel's: same shape -> same bits, but not equal to that kernel's.)
+      const ResidentPlan pl = resident_plan<K, false>(a, whole_cu, 32);
+      if (pl.pass_c) return launch_resident<K, RS_NONE>(a, pl, stream);
+    }
+    if (cout_padded(a.Cout) % 64 != 0) return -1;
     if (small) {          // <= 256 workgroups per 64 samples: one per CU, the whole LDS
       const ResidentPlan pl = resident_plan<S, false>(a, whole_cu, 64);
       if (!pl.pass_c) return -1;
@@ -515,7 +585,7 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
     return -1;
   }
   typedef ResCfg<64, 8, 8, 2, 2, 1, 16> P;
-  if (small && !a.sk_wpk) {
+  if (small && !a.sk_wpk && cout_padded(a.Cout) % 64 == 0) {
     const ResidentPlan pl = resident_plan<P, false>(a, whole_cu, 64);
     if (pl.pass_c) return launch_resident<P, RS_NONE>(a, pl, stream);
   }

@@ -198,7 +198,8 @@ def test_conv_every_tile_configuration(lib, tile, k):
     (3, 64, 0, 64, 8, 8, 3, 0, 0), (2, 64, 64, 64, 8, 8, 3, 0, 0), (2, 64, 0, 64, 16, 16, 3, 0, 0), (1, 128, 128, 128, 16, 16, 3, 0, 0),
     (2, 64, 0, 64, 16, 16, 3, 1, 1), (2, 64, 0, 64, 8, 8, 3, 0, 2), (3, 2, 2, 64, 32, 32, 3, 0, 0), (2, 64, 0, 64, 32, 32, 3, 0, 0),
     (2, 64, 64, 64, 32, 32, 3, 0, 0), (2, 64, 0, 64, 32, 32, 3, 1, 1), (2, 64, 0, 192, 8, 8, 1, 0, 0), (1, 128, 0, 384, 16, 16, 1, 0, 0),
-    (2, 64, 0, 64, 16, 16, 1, 0, 0), (2, 24, 12, 64, 12, 10, 3, 0, 0), (1, 72, 0, 64, 28, 30, 3, 0, 0), (2, 256, 0, 128, 16, 16, 3, 0, 0), (1, 320, 64, 64, 16, 16, 3, 0, 0), (2, 128, 128, 128, 32, 32, 3, 0, 0),
+    (2, 64, 0, 64, 16, 16, 1, 0, 0), (2, 24, 12, 64, 12, 10, 3, 0, 0), (3, 72, 0, 64, 8, 8, 3, 0, 0), (2, 40, 24, 96, 6, 8, 3, 0, 0),
+    (5, 128, 128, 128, 8, 8, 3, 0, 1), (1, 72, 0, 64, 28, 30, 3, 0, 0), (2, 256, 0, 128, 16, 16, 3, 0, 0), (1, 320, 64, 64, 16, 16, 3, 0, 0), (2, 128, 128, 128, 32, 32, 3, 0, 0),
 ])
 def test_conv_resident_kernel_is_bit_identical_to_the_tiled_one(lib, shape):
     """conv_resident.hip (whole K extent of the tile in LDS, DMA weight stream) against conv_mfma_kernel on the same tile
@@ -232,7 +233,11 @@ def test_conv_resident_kernel_is_bit_identical_to_the_tiled_one(lib, shape):
         y0 = lib.op_conv(*args, **kw)
     finally:
         lib.set_conv_resident(-1)
-    assert torch.equal(y, y0), f"{tag}: max |d| = {(y - y0).abs().max().item():.3e}"
+    if k == 3 and H <= 8 and W <= 8 and rs == 0:      # K-split tiles: the K sum is grouped per wave, so only close to the tiled kernel
+        assert any("ResCfg<32, 4, 8, 1, 1, 9, 8, 4>" in n for n in names), names
+        close(y, y0.cpu(), rtol=1e-5, atol=1e-5, what=tag + " (K-split vs tiled)")
+    else:
+        assert torch.equal(y, y0), f"{tag}: max |d| = {(y - y0).abs().max().item():.3e}"
     x = torch.cat([xa, xb], 1) if Cb else xa
     r = res
     if rm == 1:
@@ -242,9 +247,10 @@ def test_conv_resident_kernel_is_bit_identical_to_the_tiled_one(lib, shape):
     close(y, orc.conv2d(apply_coef(x, coef, True), w, b, up=(rs == 1)) + r, what=tag)
 
 
-def test_unet_forward_resident_on_off_identical(lib, net_P):
-    """Whole 32 x 32 U-Net (fused GroupNorm statistics, folded 1x1 skip projections, attention 1x1 convs): the forward with
-    the input-resident kernels is bit-identical to the forward with conv_mfma_kernel everywhere."""
+def test_unet_forward_resident_on_off(lib, net_P):
+    """Whole 32 x 32 U-Net (fused GroupNorm statistics, folded 1x1 skip projections): the forward with the input-resident
+    kernels against the forward with conv_mfma_kernel everywhere.  (Bit-identical per tile configuration except at the
+    8 x 8 level, where the resident kernel splits the K loop over its waves.)"""
     plan, packed, P = net_P
     x, cond = fx.randn("unet_P/x", 4, 2, 32, 32), fx.randn("unet_P/cond", 4, 2, 32, 32)
     labels = dev(fx.UNET_LABELS["nB"])
@@ -254,7 +260,7 @@ def test_unet_forward_resident_on_off_identical(lib, net_P):
         F0 = plan.forward(packed, dev(x), labels, cond=dev(cond))
     finally:
         lib.set_conv_resident(-1)
-    assert torch.equal(F1, F0), f"max |d| = {(F1 - F0).abs().max().item():.3e}"
+    close(F1, F0.cpu(), rtol=1e-5, atol=2e-6, what="resident on / off")
 
 
 def test_unet_forward_fused_attention_block_vs_three_launches(lib, net_P):
