@@ -263,6 +263,20 @@ def test_unet_forward_resident_on_off(lib, net_P):
     close(F1, F0.cpu(), rtol=1e-5, atol=2e-6, what="resident on / off")
 
 
+def test_unet_32x32_batch_shard_invariance(lib, net_P):
+    """Every kernel of the 32 x 32 network (input-resident convs in all three tilings incl. the K-split one, multi-pass
+    staging, fused attention block, fused statistics) is chosen by shape only and computes each sample on its own: a batch
+    and its shards give identical bits (exact multi-GPU batch sharding), and a rerun is reproducible."""
+    plan, packed, P = net_P
+    x, cond = fx.randn("t/shard32/x", 6, 2, 32, 32), fx.randn("t/shard32/cond", 6, 2, 32, 32)
+    lab = dev(torch.tensor([0.3]))
+    full = plan.forward(packed, dev(x), lab, cond=dev(cond))
+    again = plan.forward(packed, dev(x), lab, cond=dev(cond))
+    assert torch.equal(full, again)
+    parts = [plan.forward(packed, dev(x[i:j]), lab, cond=dev(cond[i:j])) for i, j in ((0, 1), (1, 3), (3, 6))]
+    assert torch.equal(full, torch.cat(parts))
+
+
 def test_unet_forward_fused_attention_block_vs_three_launches(lib, net_P):
     """attn_block64_kernel (GroupNorm + qkv + softmax attention + proj + residual of an 8 x 8 x 64 block in one launch) against
     the qkv conv / attention kernel / proj conv sequence on the whole 32 x 32 U-Net, and both against the oracle."""
