@@ -566,8 +566,8 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
       const ResidentPlan pl = resident_plan<K, false>(a, whole_cu, 32);
       if (pl.pass_c) return launch_resident<K, RS_NONE>(a, pl, stream);
     }
-    if (cout_padded(a.Cout) % 64 != 0) return -1;
     if (small) {          // <= 256 workgroups per 64 samples: one per CU, the whole LDS
+      if (cout_padded(a.Cout) % 64 != 0) return -1;
       const ResidentPlan pl = resident_plan<S, false>(a, whole_cu, 64);
       if (!pl.pass_c) return -1;
       return a.resample == RS_UP ? launch_resident<S, RS_UP>(a, pl, stream) : launch_resident<S, RS_NONE>(a, pl, stream);
@@ -575,6 +575,12 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
     if (a.W >= 24 && (long long)a.H * a.W <= 1024) {
       // ~32 x 32 images, 512+ workgroups: half-chunk weight slabs and <= 64 resident channels per pass keep a workgroup
       // under 80 KB of LDS, so TWO share a CU and one computes while the other re-stages
+      if (cout_padded(a.Cout) % 64 != 0) {          // the ch -> out_channels output conv: one padded 32-channel tile
+        typedef ResCfg<32, 8, 16, 1, 4, 9, 8> M32;
+        const ResidentPlan p32 = resident_plan<M32, true>(a, half_cu, 32);
+        if (!p32.pass_c || p32.nslab != 3 || a.resample != RS_NONE) return -1;
+        return launch_resident<M32, RS_NONE, true>(a, p32, stream);
+      }
       ResidentPlan pl = resident_plan<M, true>(a, half_cu, 32);
       if (!pl.pass_c || pl.nslab != 3) return -1;
       static int pass_env = -1;      // experiments: MCEDM_RES_PASS = channels per pass (multiple of 16, <= the plan's)
