@@ -5,6 +5,8 @@
     python tools/rocpd_summary.py traffic <FETCH_SIZE results.db> <WRITE_SIZE results.db> <out.json>
         per-launch HBM traffic per kernel for bench.py's roofline.traffic (see tools/pmc_traffic.py for the gfx950
         corrections: KiB units; reads bracketed [x1, x2], the upper end is used)
+    python tools/rocpd_summary.py kernel_counters <out.json> <PMC results.db> ...
+        per-kernel mean of every collected counter (tools/pmc_mfma.sh: MfmaUtil, LDS bank conflicts)
 """
 import collections
 import csv
@@ -78,9 +80,29 @@ def counters(dbs):
                 print(f"{k:60s} {name:32s} n={len(v):4d} avg {sum(v) / len(v):16.1f}")
 
 
+def kernel_counters(out, dbs):
+    """Per-kernel mean of every counter in the given PMC results.db files -> JSON {kernel: {counter: mean, 'launches': n}}."""
+    res = {}
+    for db in dbs:
+        c = sqlite3.connect(db)
+        agg = collections.defaultdict(list)
+        for k, name, v in c.execute("select kernel_name, counter_name, value from counters_collection"):
+            agg[(k.split("(")[0].replace("void mcedm::", "").replace("mcedm::", "").strip(), name)].append(v)
+        for (k, name), v in agg.items():
+            e = res.setdefault(k, {})
+            e[name] = sum(v) / len(v)
+            e["launches"] = len(v)
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("launches", 0))[:12]:
+        print(f"{k[:70]:70s} " + "  ".join(f"{n} {v:.4g}" for n, v in e.items()))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "counters":
         counters(sys.argv[2:])
+    elif sys.argv[1] == "kernel_counters":
+        kernel_counters(sys.argv[2], sys.argv[3:])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
