@@ -266,9 +266,10 @@ int mcedm_op_set_conv_tile(int mt, int ph, int pw);
  * 3x3 layers large enough to give every CU a workgroup: 1 on, 0 off, -1 back to the default (env MCEDM_CONV8, else
  * off).  Results are bit-identical to the default kernel.  Process-global, not thread-safe. */
 int mcedm_op_set_conv8(int enable);
-/* The input-resident conv kernel that serves <= 32 x 32 images (conv_resident.hip: whole K extent of the tile in LDS,
- * weights streamed by DMA): 0 off (every conv takes conv_mfma_kernel), 1 for <= 16 x 16 images, 2 also for ~32 x 32
- * images (slower there today), -1 back to the default (env MCEDM_CONV_RESIDENT, else 1).  Bit-identical to conv_mfma_kernel on the same tile.  Process-global, not thread-safe. */
+/* The input-resident conv kernels that serve <= 32 x 32 images (conv_resident.hip: the tile's K extent in LDS by DMA,
+ * weights streamed under the MFMAs): 1 on, 0 off (every conv takes conv_mfma_kernel), -1 back to the default (env
+ * MCEDM_CONV_RESIDENT, else on).  Bit-identical to conv_mfma_kernel per tile configuration except the K-split tile used
+ * at <= 8 x 8 (same result for a given shape, grouped differently).  Process-global, not thread-safe. */
 int mcedm_op_set_conv_resident(int enable);
 /* The single-launch attention part of a UNetBlock at 8 x 8 x 64 channels (attn_fused.hip; inference only): 1 on, 0 off
  * (qkv conv + attention kernel + proj conv), -1 back to the default (env MCEDM_ATTN_FUSED, else on).  Process-global. */

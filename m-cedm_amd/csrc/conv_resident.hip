@@ -466,9 +466,9 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
 
 // -------------------------------------------------------------------------------------------
 // host side
-static int g_resident = -1;      // -1: default (MCEDM_CONV_RESIDENT, else on); 0 / 1: forced by mcedm_op_set_conv_resident
+static int g_resident = -1;      // -1: default (env MCEDM_CONV_RESIDENT, else on); 0 / 1: forced by mcedm_op_set_conv_resident
 void set_conv_resident(int enable) { g_resident = enable; }
-static int resident_level() {     // 0: off, 1: the 8 x 8-pixel tile (<= 16 x 16 images), 2: also the 8 x 16 tile (~32 x 32 images)
+static int resident_level() {     // 0: off, > 0: on
   if (g_resident >= 0) return g_resident;
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_CONV_RESIDENT"); env = e ? atoi(e) : 1; }

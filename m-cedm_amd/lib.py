@@ -655,7 +655,7 @@ def set_conv8(enable: int = -1) -> None:
 
 
 def set_conv_resident(enable: int = -1) -> None:
-    """Input-resident conv kernel for <= 32 x 32 images: 1 / 0; -1 = default (on)."""
+    """Input-resident conv kernels for <= 32 x 32 images: 1 / 0; -1 = default (on)."""
     lib = _bind_ops()
     lib.mcedm_op_set_conv_resident.argtypes = [C.c_int]
     check(lib.mcedm_op_set_conv_resident(int(enable)), "set_conv_resident")

@@ -219,7 +219,7 @@ def test_conv_resident_kernel_is_bit_identical_to_the_tiled_one(lib, shape):
     wpk, bpk = lib.op_pack_conv(dev(w), dev(b))
     args = (dev(xa), dev(xb) if Cb else None, wpk, bpk, Cout, k)
     kw = dict(coef=dev(coef), act=1, resample=rs, res=dev(res), res_mode=rm)
-    lib.set_conv_resident(2)          # level 2 = also the (opt-in) 8 x 16-pixel tile of ~32 x 32 images
+    lib.set_conv_resident(1)
     lib.prof_enable(True)
     try:
         y = lib.op_conv(*args, **kw)
