@@ -6,16 +6,23 @@
 // the CU to cover it: the in-kernel phase counters (tools/conv_small_timeline.py) showed 45 % matrix / 55 % staging per
 // iteration on the 8 x 8 tile, with 100 of 256 threads owning a tile element.  Here
 //   * phase 0 requests every byte the workgroup needs by LDS-DMA (global -> LDS without registers): the raw halo tile of
-//     ALL input channels ([Cin][PH+2][PW+2] floats: 25-100 KB), the raw input of a folded 1x1 projection, the first
+//     the resident input channels, laid out as whole 16-byte segments of the image rows ([channel][PH+2][PW+8] floats, one
+//     lane-linear instruction per channel tile; 2x up-sampled / unaligned sources: one element per lane), and the first
 //     weight slabs: scalar base + one per-lane offset, tight issue loops, no vector arithmetic;
-//   * phase 1 applies GroupNorm/FiLM/SiLU and the zero padding IN PLACE in LDS (each thread the elements its own wave
-//     fetched), while the accumulators are initialised with bias + residual;
-//   * phase 2 walks K: the weight slab of chunk c+2 streams global -> LDS by DMA into a ring of three slabs while the
-//     MFMAs of chunk c run; ONE barrier per chunk, a counted vmcnt wait, nothing else in the loop.
+//   * phase 1 applies GroupNorm/FiLM/SiLU and the zero padding IN PLACE in LDS (pairs of adjacent elements per thread),
+//     while the accumulators are initialised with bias + residual and the transform rows are derived;
+//   * phase 2 walks K in units (a chunk; half a chunk in SPLIT mode; KS chunks in K-split mode): the weight slab two units
+//     ahead streams global -> LDS by DMA into a ring of three, one instruction per tap under the MFMAs; ONE barrier and a
+//     counted vmcnt wait per unit, nothing else in the loop.  A folded 1x1 projection streams its raw input through the
+//     same tile buffer afterwards.
+//   * passes: when the input does not fit the LDS budget, pass_c channels are resident at a time.  At ~32 x 32 the budget
+//     is 80 KB so that two workgroups share a CU (one computes while the other re-stages); at <= 8 x 8 the tile is
+//     32 channels x 4 x 8 pixels with the K loop split over the four waves (4x the workgroups).
 // The MFMA chunk loop, the accumulator initialisation (bias + residual), the epilogue and the fused GroupNorm
 // statistics are the ones of conv_mfma_kernel, and K is summed in the same order (chunk, tap, channel pair; then the
-// folded projection's channel pairs), so for one tile configuration the two kernels are BIT-IDENTICAL (tested); which one
-// runs is decided by the image size and channel counts only, never by the batch size.
+// folded projection's channel pairs), so for one tile configuration the two kernels are BIT-IDENTICAL (tested; the K-split
+// tile groups the sum per wave and is only close); which one runs is decided by the image size, channel counts and
+// alignment only, never by the batch size.  DESIGN.md section 3 has the measurements and what did not work.
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -54,7 +61,7 @@ struct ResCfg {
   static constexpr int OCC = 2;
   // wide staging: lanes per channel, channels per wave instruction
   static constexpr int RSEG = PITCH / 4, LPC = ROWS * RSEG, CPW = 64 / LPC;
-  // transform pass on pairs of elements (packed fp32 math): pairs per row / channel, channels per workgroup step
+  // transform pass on pairs of adjacent elements: pairs per row / channel, channels per workgroup step
   static constexpr int PPR = HALO ? (PW + 4) / 2 : PW / 2, PC0 = HALO ? 2 : 0, PPC = ROWS * PPR, CPT = NT / PPC;
   static_assert(NWAVE == 4 && TM >= 1 && TN >= 1 && PITCH % 4 == 0 && LPC <= 64 && CPW >= 1 && CPT >= 1, "tile shape");
 };
