@@ -51,8 +51,82 @@ def _beta_schedule(kind, beta_start, beta_end, n):
         raise NotImplementedError(kind)
     return torch.from_numpy(b).float()
 
+def _l1(a, b):
+    """nn.L1Loss() (mean); an empty slice gives nan like the reference's own call does."""
+    return (a - b).abs().mean()
 
-class PlCondEdm(_Base):
+
+def _masked_l1(pred, target, mask):
+    """MaskedLoss('l1'), models/losses.py:62-78."""
+    return (pred * mask - target * mask).abs().sum() / mask.sum()
+
+
+def _correlation(pred, target):
+    """CorrelationLoss(reduction='none'), models/losses.py:93-124: per-channel Pearson correlation over the grid, averaged
+    over the batch."""
+    p = pred.reshape(pred.shape[0], -1, pred.shape[-1])
+    t = target.reshape(target.shape[0], -1, target.shape[-1])
+    pc, tc = p - p.mean(dim=1, keepdim=True), t - t.mean(dim=1, keepdim=True)
+    den = ((pc * pc).sum(dim=1) * (tc * tc).sum(dim=1)).sqrt()
+    den = den + (den == 0) * 1e-7
+    return ((tc * pc).sum(dim=1) / den).mean(dim=0)
+
+
+class _EvalMetrics:
+    """Host-side bookkeeping both reference evaluation loops share (models/ddim.py:235-262, 652-698)."""
+
+    def data_transform(self, h, u):
+        x = torch.cat([self.normalizer_input(h), self.normalizer_target(u)], dim=-1)
+        if self.uniform_dequantization:
+            x = x / 256.0 * 255.0 + torch.rand_like(x) / 256.0
+        if self.gaussian_dequantization:
+            x = x + torch.randn_like(x) * 0.01
+        return 2 * x - 1.0 if self.rescaled else x
+
+    def inverse_data_transform(self, h, u):
+        if self.rescaled:
+            h, u = (h + 1.0) / 2.0, (u + 1.0) / 2.0
+        if self.normalization == "min_max":
+            h, u = torch.clamp(h, 0.0, 1.0), torch.clamp(u, 0.0, 1.0)
+        return self.normalizer_input(h, inverse=True), self.normalizer_target(u, inverse=True)
+
+    @staticmethod
+    def scale_each_min_max(state, return_min_max=False):
+        """Per (sample, channel) min-max scaling of a 'b h w c' field to [0, 1] (models/ddim.py:689-698)."""
+        b, hh, ww, c = state.shape
+        flat = state.permute(0, 3, 1, 2).reshape(b, c, hh * ww)
+        lo, hi = flat.min(dim=2, keepdim=True)[0], flat.max(dim=2, keepdim=True)[0]
+        scaled = ((flat - lo) / (hi - lo)).reshape(b, c, hh, ww).permute(0, 2, 3, 1)
+        return (scaled, lo, hi) if return_min_max else scaled
+
+    @staticmethod
+    def scale_back_min_max(state_scaled, state_min, state_max):
+        b, hh, ww, c = state_scaled.shape
+        flat = state_scaled.permute(0, 3, 1, 2).reshape(b, c, hh * ww) * (state_max - state_min) + state_min
+        return flat.reshape(b, c, hh, ww).permute(0, 2, 3, 1)
+
+    def recover_correct_scale(self, gt, xs_scaled_mean):
+        _, lo, hi = self.scale_each_min_max(gt, return_min_max=True)
+        return self.scale_back_min_max(xs_scaled_mean, lo, hi)
+
+    def get_best_by_pde_error(self, gt, xs_scaled, n_samples, use_gt=True):
+        """models/ddim.py:652-674: per input the sample (re-scaled to the ground truth's range) with the smallest mean PDE
+        residual; returns (indices [b, 1], the selected scaled samples [b, h, w, c])."""
+        gt_rep = gt.repeat(n_samples, 1, 1, 1)
+        _, lo, hi = self.scale_each_min_max(gt_rep, return_min_max=True)
+        xs_gt = self.scale_back_min_max(xs_scaled, lo, hi)
+        err = self.pde_loss(xs_gt, gt_rep if use_gt else xs_gt, self.normalizer_input, self.normalizer_target)
+        nb = err.shape[0] // n_samples
+        err = err.reshape(n_samples, nb, -1).permute(1, 0, 2).mean(dim=2)                 # '(n b) ... -> b n (...)'
+        indices = err.min(dim=1, keepdim=True)[1]
+        per_b = xs_scaled.reshape(n_samples, nb, *xs_scaled.shape[1:]).transpose(0, 1)    # b n h w c
+        return indices, per_b[torch.arange(nb, device=indices.device), indices[:, 0]]
+
+    def _log(self, name, value):
+        self.log(name, value, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
+
+
+class PlCondEdm(_EvalMetrics, _Base):
     def __init__(self, hparams):
         super().__init__()
         self.save_hyperparameters()
@@ -133,14 +207,6 @@ class PlCondEdm(_Base):
             self.ema_model.update(self.model)
 
     # ---- data ------------------------------------------------------------------------------------------------
-    def data_transform(self, h, u):
-        x = torch.cat([self.normalizer_input(h), self.normalizer_target(u)], dim=-1)
-        if self.uniform_dequantization:
-            x = x / 256.0 * 255.0 + torch.rand_like(x) / 256.0
-        if self.gaussian_dequantization:
-            x = x + torch.randn_like(x) * 0.01
-        return 2 * x - 1.0 if self.rescaled else x
-
     def inverse_data_transform_u(self, u):
         if self.rescaled:
             u = (u + 1.0) / 2.0
@@ -260,41 +326,93 @@ class PlCondEdm(_Base):
             return net.plan.sample(net.packed_weights(), sd, h, None, init, step_noise, return_last=return_last,
                                    ws=self._sample_ws, guidance=guidance)
 
-    # ---- evaluation bookkeeping (models/ddim.py:1154-1330; scaled-MAE / correlation / PDE extras are host metrics)
-    def _eval(self, batch, sp, n):
-        h_unnorm, dx, dt, u_unnorm = batch
-        self.h_ch, self.u_ch = h_ch, u_ch = h_unnorm.shape[-1], u_unnorm.shape[-1]
-        state = self.data_transform(h_unnorm, u_unnorm)
-        h, u = state[..., :h_ch], state[..., h_ch:h_ch + u_ch]
-        cond = self.get_cond_in(h, u, dx, dt).repeat(n, 1, 1, 1)
-        xs = self.sample_edm(cond, torch.randn_like(u.repeat(n, 1, 1, 1)), sp, return_last=sp.return_last, guide_dx=sp.guide_dx)
-        nb = len(h_unnorm)
-        xs_mean = xs.reshape(n, nb, *xs.shape[1:]).mean(dim=0)
-        u_last = xs_mean[:, -1, :, :, :u_ch]
-        loss_u = (u_last - u).abs().mean()
-        loss_u_un = (self.inverse_data_transform_u(u_last) - u_unnorm).abs().mean()
-        return xs, u, loss_u, loss_u_un, nb
+    # ---- evaluation loops (models/ddim.py:1154-1319): sampling on the device, metric bookkeeping on the host ----------
+    def get_pde_loss(self, cond, x_denoised, x_gt_unnorm=None, noise_level=None, clamp_loss=True, do_rearrange=True,
+                     reduce=True):
+        """models/ddim.py:1388-1422: residual of (h = the first h_ch conditioning channels, u = x_denoised)."""
+        h, u = cond[..., :self.h_ch].to(torch.float32), x_denoised.to(torch.float32)
+        if do_rearrange:
+            h, u = h.permute(0, 2, 3, 1), u.permute(0, 2, 3, 1)
+        x_un = torch.cat(self.inverse_data_transform(h, u), dim=-1)
+        err = self.pde_loss(x_un, x_un if x_gt_unnorm is None else x_gt_unnorm, self.normalizer_input, self.normalizer_target,
+                            return_d=False, calc_prob=False, clamp_loss=clamp_loss)
+        if err.dim() > 3:
+            err = err.sum(dim=-1)
+        if noise_level is not None:
+            err = err / (noise_level.reshape(-1, 1, 1, 1) + 1.0)
+        return err.sum() if reduce else err
 
     def validation_step(self, val_batch, batch_idx):
         if (self.current_epoch + 1) % 100 != 0 and self.current_epoch != 0:
             return {"epoch": self.current_epoch}
-        xs, u, loss_u, loss_u_un, _ = self._eval(val_batch, self.sparams, 1)
-        self.log("val_mae_u", loss_u, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
-        self.log("val_mae_u_un", loss_u_un, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
-        return {"epoch": self.current_epoch, "loss": loss_u, "loss_u_un": loss_u_un, "traj": xs[:, -1].unsqueeze(1), "gt": u}
+        h_unnorm, dx, dt, u_unnorm = val_batch
+        self.h_ch, self.u_ch = h_ch, u_ch = h_unnorm.shape[-1], u_unnorm.shape[-1]
+        state_gt = self.data_transform(h_unnorm, u_unnorm)
+        h, u = state_gt[..., :h_ch], state_gt[..., h_ch:h_ch + u_ch]
+        u_noise = torch.randn_like(u)
+        sp = self.sparams
+        if sp.type != "edm":
+            raise NotImplementedError("only the EDM sampler is built (models/ddim.py:1172-1175)")
+        xs = self.sample_edm(self.get_cond_in(h, u, dx, dt), u_noise, sp, return_last=True, guide_dx=sp.guide_dx)
+        last = xs[:, -1]
+        loss_u = _l1(last[..., :u_ch], u)
+        loss_u_un = _l1(self.inverse_data_transform_u(last[..., :u_ch]), u_unnorm)
+        gt_scaled, xs_scaled = self.scale_each_min_max(state_gt), self.scale_each_min_max(last)
+        loss_u_scaled = _l1(xs_scaled, gt_scaled[..., h_ch:h_ch + u_ch])
+        self._log("val_mae_u", loss_u)
+        self._log("val_mae_u_un", loss_u_un)
+        self._log("val_mae_u_scaled", loss_u_scaled)
+        self._log("val_corr_u", _correlation(last, u).mean())
+        self._log("val_pde_loss", self.get_pde_loss(h, last, clamp_loss=False, do_rearrange=False) / len(h_unnorm))
+        traj, gt = (xs_scaled, gt_scaled[..., h_ch:h_ch + u_ch]) if sp.plot_scaled else (last, u)
+        return {"epoch": self.current_epoch, "loss": loss_u, "loss_u_un": loss_u_un, "val_loss_u_scaled": loss_u_scaled,
+                "traj": traj.unsqueeze(1), "gt": gt}
 
     def test_step(self, test_batch, test_idx):
-        n = self.test_sparams.n_samples
-        xs, u, loss_u, loss_u_un, nb = self._eval(test_batch, self.test_sparams, n)
-        print(f"\nLoss u {loss_u}, loss u un {loss_u_un}")
-        self.log("test_mae_u", loss_u, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
-        self.log("test_mae_u_un", loss_u_un, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
-        last = xs[:, -1]
-        traj = last.reshape(n, nb, *last.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)       # '(n b) h w c -> b h w n c'
-        return {"loss": loss_u, "loss_u_un": loss_u_un, "traj": traj, "gt": u}
+        h_unnorm, dx, dt, u_unnorm = test_batch
+        self.h_ch, self.u_ch = h_ch, u_ch = h_unnorm.shape[-1], u_unnorm.shape[-1]
+        state_gt = self.data_transform(h_unnorm, u_unnorm)
+        h, u = state_gt[..., :h_ch], state_gt[..., h_ch:h_ch + u_ch]
+        sp = self.test_sparams
+        n, nb = sp.n_samples, len(h_unnorm)
+        cond_rep = self.get_cond_in(h, u, dx, dt).repeat(n, 1, 1, 1)
+        u_noise = torch.randn_like(u.repeat(n, 1, 1, 1))
+        if sp.type != "edm":
+            raise NotImplementedError("only the EDM sampler is built (models/ddim.py:1239-1242)")
+        xs = self.sample_edm(cond_rep, u_noise, sp, return_last=sp.return_last, guide_dx=sp.guide_dx)
+        xs_mean = xs.reshape(n, nb, *xs.shape[1:]).mean(dim=0)               # '(n b) t h w c -> n b t h w c', mean over n
+        u_last = xs_mean[:, -1, :, :, :u_ch]
+        loss_u = _l1(u_last, u)
+        loss_u_un = _l1(self.inverse_data_transform_u(u_last), u_unnorm)
+        gt_scaled, xs_scaled = self.scale_each_min_max(state_gt), self.scale_each_min_max(xs[:, -1])
+        if sp.select_by_pde:                                                 # best sample by PDE error instead of the mean
+            print("Use the best sample determined by PDE error")
+            h_rep_scaled = self.scale_each_min_max(h.repeat(n, 1, 1, 1).unsqueeze(-1))
+            indices, best = self.get_best_by_pde_error(torch.cat([h_unnorm, u_unnorm], dim=-1),
+                                                       torch.cat([h_rep_scaled, xs_scaled], dim=-1), n, sp.use_gt_pde_select)
+            xs_scaled_mean = best[..., -1:]
+            per_b = xs.reshape(n, nb, *xs.shape[1:]).transpose(0, 1)
+            xs_mean = per_b[torch.arange(nb, device=indices.device), indices[:, 0]]
+        else:
+            xs_scaled_mean = xs_scaled.reshape(n, nb, *xs_scaled.shape[1:]).mean(dim=0)
+        loss_u_scaled = _l1(xs_scaled_mean, gt_scaled[..., h_ch:h_ch + u_ch])
+        self._log("test_corr_u", _correlation(xs_mean[:, -1], u).mean())
+        print(f"\nLoss u {loss_u}, loss u un {loss_u_un}\nLoss u scaled {loss_u_scaled}")
+        self._log("test_mae_u", loss_u)
+        self._log("test_mae_u_un", loss_u_un)
+        self._log("test_mae_u_scaled", loss_u_scaled)
+        pde = self.get_pde_loss(state_gt.repeat(n, 1, 1, 1)[..., :h_ch], xs[:, -1], clamp_loss=False, do_rearrange=False) / n / nb
+        self._log("test_pde_loss", pde)
+        pde_gt = self.get_pde_loss(h, u, clamp_loss=False, do_rearrange=False) / nb
+        self._log("test_pde_loss_gt", pde_gt)
+        print(f"Pde loss is {pde}\nPde loss gt is {pde_gt}")
+        shown = xs_scaled if sp.plot_scaled else xs[:, -1]
+        traj = shown.reshape(n, nb, *shown.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)      # '(n b) h w c -> b 1 h w n c'
+        return {"loss": loss_u, "loss_u_un": loss_u_un, "test_mae_u_scaled": loss_u_scaled, "traj": traj,
+                "gt": gt_scaled[..., h_ch:h_ch + u_ch] if sp.plot_scaled else u}
 
 
-class PlDdim(_Base):
+class PlDdim(_EvalMetrics, _Base):
     """models/ddim.py:16-1051, the part BASELINE config 5 exercises: EDM / RePaint sampling of the joint (h, u) DDPM.
     Constructor, buffers (``betas``, ``logvar``), attributes and the signatures of ``set_test_sampler_params``,
     ``get_edm_steps``, ``compute_alpha``, ``round_sigma``, ``get_denoised`` and ``sample_edm`` follow the reference.
@@ -411,6 +529,123 @@ class PlDdim(_Base):
         with torch.no_grad():
             return net.plan.repaint_sample(net.packed_weights(), rd, hu, hu_noise, step_noise, repeat_noise,
                                            return_last=return_last, ws=self._sample_ws)
+
+    # ---- evaluation loops (models/ddim.py:294-533): BASELINE config 5 is run through trainer.test -> test_step ------------
+    def get_pde_loss(self, cond, x_denoised, x_gt_unnorm=None, noise_level=None, clamp_loss=True, do_rearrange=True,
+                     reduce=True):
+        """models/ddim.py:535-565: residual of the joint (h, u) state."""
+        if do_rearrange:
+            x_denoised = x_denoised.permute(0, 2, 3, 1)
+        h = x_denoised[..., :self.h_ch].to(torch.float32)
+        u = x_denoised[..., self.h_ch:self.h_ch + self.u_ch].to(torch.float32)
+        x_un = torch.cat(self.inverse_data_transform(h, u), dim=-1)
+        err = self.pde_loss(x_un, x_un if x_gt_unnorm is None else x_gt_unnorm, self.normalizer_input, self.normalizer_target,
+                            return_d=False, calc_prob=False, clamp_loss=clamp_loss)
+        if noise_level is not None:
+            err = err / (noise_level.reshape(-1, 1, 1, 1) + 1.0)
+        return err.sum() if reduce else err
+
+    def _require_edm(self, sp):
+        if sp.type != "edm":
+            raise NotImplementedError("only the EDM / RePaint sampler (type 'edm') is built; the DDIM loops are not "
+                                      "(models/ddim.py:706-913)")
+
+    def validation_step(self, val_batch, batch_idx):
+        if (self.current_epoch + 1) % 100 != 0 and self.current_epoch != 0:
+            return {"epoch": self.current_epoch}
+        h_unnorm, dx, dt, u_unnorm = val_batch
+        self.h_ch, self.u_ch = h_ch, u_ch = h_unnorm.shape[-1], u_unnorm.shape[-1]
+        state_gt = self.data_transform(h_unnorm, u_unnorm)
+        h, u = state_gt[..., :h_ch], state_gt[..., h_ch:h_ch + u_ch]
+        sp = self.sparams
+        self._require_edm(sp)
+        # the reference hands NOISE in as the u field here (models/ddim.py:306-309): rows < n_time_u of it count as known
+        xs = self.sample_edm(h, torch.randn_like(u), sp, return_last=True, guide_dx=sp.guide_dx)
+        last = xs[:, -1]
+        h_last, u_last = last[..., :h_ch], last[..., h_ch:h_ch + u_ch]
+        loss_h, loss_u = _l1(h_last, h), _l1(u_last, u)
+        h_un, u_un = self.inverse_data_transform(h_last, u_last)
+        loss_h_un, loss_u_un = _l1(h_un, h_unnorm), _l1(u_un, u_unnorm)
+        gt_scaled, xs_scaled = self.scale_each_min_max(state_gt), self.scale_each_min_max(last)
+        loss_h_scaled = _l1(xs_scaled[..., :h_ch], gt_scaled[..., :h_ch])
+        loss_u_scaled = _l1(xs_scaled[..., h_ch:h_ch + u_ch], gt_scaled[..., h_ch:h_ch + u_ch])
+        for name, v in (("val_mae_h", loss_h), ("val_mae_u", loss_u), ("val_mae_h_un", loss_h_un), ("val_mae_u_un", loss_u_un),
+                        ("val_mae_h_scaled", loss_h_scaled), ("val_mae_u_scaled", loss_u_scaled)):
+            self._log(name, v)
+        corr = _correlation(last, state_gt)
+        self._log("val_corr_h", corr[:h_ch].mean())
+        self._log("val_corr_u", corr[h_ch:h_ch + u_ch].mean())
+        self._log("val_pde_loss", self.get_pde_loss(None, last, clamp_loss=False, do_rearrange=False) / len(h_unnorm))
+        traj, gt = (xs_scaled, gt_scaled) if sp.plot_scaled else (last, state_gt)
+        return {"epoch": self.current_epoch, "loss_h": loss_h, "loss": loss_u, "loss_h_un": loss_h_un, "loss_u_un": loss_u_un,
+                "val_loss_h_scaled": loss_h_scaled, "val_loss_u_scaled": loss_u_scaled, "traj": traj.unsqueeze(1), "gt": gt}
+
+    def test_step(self, test_batch, test_idx):
+        h_unnorm, dx, dt, u_unnorm = test_batch
+        self.h_ch, self.u_ch = h_ch, u_ch = h_unnorm.shape[-1], u_unnorm.shape[-1]
+        hs, us = slice(0, h_ch), slice(h_ch, h_ch + u_ch)
+        state_gt = self.data_transform(h_unnorm, u_unnorm)
+        h, u = state_gt[..., hs], state_gt[..., us]
+        sp = self.test_sparams
+        self._require_edm(sp)
+        n, nb = sp.n_samples, len(h_unnorm)
+        rep = state_gt.repeat(n, 1, 1, 1)
+        n_all, n_time_h, n_time_u = h.shape[1], sp.n_time_h, sp.n_time_u
+        xs = self.sample_edm(rep[..., hs], rep[..., us], sp, return_last=sp.return_last, guide_dx=sp.guide_dx)
+        xs_mean = xs.reshape(n, nb, *xs.shape[1:]).mean(dim=0)               # '(n b) t h w c -> n b t h w c', mean over n
+        h_last, u_last = xs_mean[:, -1, :, :, hs], xs_mean[:, -1, :, :, us]
+        loss_h, loss_u = _l1(h_last, h), _l1(u_last, u)
+        h_un, u_un = self.inverse_data_transform(h_last, u_last)
+        loss_h_un, loss_u_un = _l1(h_un, h_unnorm), _l1(u_un, u_unnorm)
+        hu_un, gt_un = torch.cat([h_un, u_un], dim=-1), torch.cat([h_unnorm, u_unnorm], dim=-1)
+        unknown = torch.ones_like(hu_un)                                     # 1 = generated entries (:419-424)
+        if n_time_h > 0:
+            unknown[:, :n_time_h, :, hs] = 0.0
+        if n_time_u > 0:
+            unknown[:, :n_time_u, :, us] = 0.0
+        loss_hu_un = _masked_l1(hu_un, gt_un, unknown)
+        gt_scaled, xs_scaled = self.scale_each_min_max(state_gt), self.scale_each_min_max(xs[:, -1])
+        if sp.select_by_pde:
+            print("Use the best sample determined by PDE error")
+            indices, xs_scaled_mean = self.get_best_by_pde_error(gt_un, xs_scaled, n, sp.use_gt_pde_select)
+            per_b = xs.reshape(n, nb, *xs.shape[1:]).transpose(0, 1)
+            xs_mean = per_b[torch.arange(nb, device=indices.device), indices[:, 0]]
+        else:
+            xs_scaled_mean = xs_scaled.reshape(n, nb, *xs_scaled.shape[1:]).mean(dim=0)
+        loss_h_scaled = _l1(xs_scaled_mean[..., hs], gt_scaled[..., hs])
+        loss_u_scaled = _l1(xs_scaled_mean[..., us], gt_scaled[..., us])
+        corr = _correlation(xs_mean[:, -1], state_gt)
+        self._log("test_corr_h", corr[hs].mean())
+        self._log("test_corr_u", corr[us].mean())
+        for tag, ch, last, ref, k, on in (("h", hs, h_last, h, n_time_h, n_time_h < n_all),
+                                          ("u", us, u_last, u, n_time_u, n_all > n_time_u > 0)):
+            if on:      # error on the rows handed in (0 by construction) and scaled error on / off them (:460-482)
+                self._log(f"test_{tag}_known", _l1(last[:, :k], ref[:, :k]))
+                self._log(f"test_{tag}_kn_scaled", _l1(xs_scaled_mean[:, :k, :, ch], gt_scaled[:, :k, :, ch]))
+                self._log(f"test_{tag}_unkn_scaled", _l1(xs_scaled_mean[:, k:, :, ch], gt_scaled[:, k:, :, ch]))
+        print(f"\nLoss h {loss_h}, loss h un {loss_h_un}\nLoss u {loss_u}, loss u un {loss_u_un}\nLoss hu un {loss_hu_un}\n"
+              f"Loss h scaled {loss_h_scaled}, loss u scaled {loss_u_scaled}")
+        for name, v in (("test_mae_h", loss_h), ("test_mae_u", loss_u), ("test_mae_h_un", loss_h_un), ("test_mae_u_un", loss_u_un),
+                        ("test_mae_hu_un", loss_hu_un), ("test_mae_h_scaled", loss_h_scaled), ("test_mae_u_scaled", loss_u_scaled)):
+            self._log(name, v)
+        pde = self.get_pde_loss(None, xs[:, -1], clamp_loss=False, do_rearrange=False) / n / nb
+        self._log("test_pde_loss", pde)
+        pde_gt = self.get_pde_loss(None, state_gt, clamp_loss=False, do_rearrange=False) / nb
+        self._log("test_pde_loss_gt", pde_gt)
+        print(f"Pde loss is {pde}\nPde loss gt is {pde_gt}")
+        if sp.return_last:                 # the last state of every sample: '(n b) h w c -> b 1 h w n c'
+            last = xs[:, -1]
+            xs_plot = last.reshape(n, nb, *last.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)
+            sc_plot = xs_scaled.reshape(n, nb, *xs_scaled.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)
+        else:                              # every second state of the FIRST sample, time steps in the sample slot (:518-525)
+            first = xs[:, ::2].reshape(n, nb, *xs[:, ::2].shape[1:])[0]               # b t h w c
+            nt = first.shape[1]
+            xs_plot = first.reshape(nb * nt, *first.shape[2:])                          # '(b t) h w c'
+            sc = self.scale_each_min_max(xs_plot)
+            sc_plot = sc.reshape(nb, nt, *sc.shape[1:]).permute(0, 2, 3, 1, 4).unsqueeze(1)   # 'b 1 h w t c'
+        return {"loss_h": loss_h, "loss": loss_u, "loss_h_un": loss_h_un, "loss_u_un": loss_u_un,
+                "test_mae_u_scaled": loss_u_scaled, "traj": sc_plot if sp.plot_scaled else xs_plot,
+                "gt": gt_scaled if sp.plot_scaled else state_gt}
 
     def sample(self, *a, **k):
         raise NotImplementedError("the DDIM sampler (models/ddim.py:706-806) is not built; use sample_edm")

@@ -324,3 +324,73 @@ def sample_edm_repaint(P, cfg: DdpmConfig, hu: Tensor, sp: RepaintParams, init_n
             x_next = hu * mask + x_next * (1.0 - mask)
         xs = [x_next] if return_last else xs + [x_next]
     return torch.stack(xs, dim=0).permute(1, 0, 3, 4, 2).contiguous()
+
+
+# --------------------------------------------------------------------------- #
+# evaluation loops of PlDdim (models/ddim.py:294-533): what `trainer.test` runs for BASELINE config 5
+# --------------------------------------------------------------------------- #
+def eval_test_step(P, cfg: DdpmConfig, h: Tensor, u: Tensor, norm_stats, sp: RepaintParams, n_samples: int, system: str,
+                   init: Tensor, step_noise, repeat_noise) -> Dict[str, Tensor]:
+    """PlDdim.test_step, models/ddim.py:372-533 with type 'edm', return_last True, select_by_pde False, plot_scaled False.
+    h, u: un-normalised 'b t x 1'; norm_stats = (input mean, std, target mean, std); the noises replace the draws of
+    sample_edm (:969, :1004, :1037) on the (n b) batch.  Logged scalars are returned under 'log::<name>'."""
+    from . import mcedm_oracle as mo
+    st = norm_stats
+    hn, un = (h - st[0]) / st[1], (u - st[2]) / st[3]
+    state_gt = torch.cat([hn, un], dim=-1)
+    nb, n_all = len(h), h.shape[1]
+    hu = state_gt.repeat(n_samples, 1, 1, 1).permute(0, 3, 1, 2)
+    xs = sample_edm_repaint(P, cfg, hu, sp, init, step_noise, repeat_noise, return_last=True)
+    xs_mean = xs.reshape(n_samples, nb, *xs.shape[1:]).mean(dim=0)
+    h_last, u_last = xs_mean[:, -1, :, :, 0:1], xs_mean[:, -1, :, :, 1:2]
+    out = {"loss_h": mo.l1(h_last, hn), "loss": mo.l1(u_last, un)}
+    h_un, u_un = h_last * st[1] + st[0], u_last * st[3] + st[2]
+    out["loss_h_un"], out["loss_u_un"] = mo.l1(h_un, h), mo.l1(u_un, u)
+    unknown = torch.ones(nb, n_all, h.shape[2], 2, dtype=h_un.dtype)
+    if sp.n_time_h > 0:
+        unknown[:, :sp.n_time_h, :, 0] = 0.0
+    if sp.n_time_u > 0:
+        unknown[:, :sp.n_time_u, :, 1] = 0.0
+    out["log::test_mae_hu_un"] = mo.masked_l1(torch.cat([h_un, u_un], dim=-1), torch.cat([h, u], dim=-1), unknown)
+    gt_scaled, xs_scaled = mo.scale_each_min_max(state_gt), mo.scale_each_min_max(xs[:, -1])
+    sc_mean = xs_scaled.reshape(n_samples, nb, *xs_scaled.shape[1:]).mean(dim=0)
+    out["log::test_mae_h_scaled"] = mo.l1(sc_mean[..., 0:1], gt_scaled[..., 0:1])
+    out["test_mae_u_scaled"] = mo.l1(sc_mean[..., 1:2], gt_scaled[..., 1:2])
+    corr = mo.correlation(xs_mean[:, -1], state_gt)
+    out["log::test_corr_h"], out["log::test_corr_u"] = corr[0:1].mean(), corr[1:2].mean()
+    for tag, c, last, ref, k, on in (("h", 0, h_last, hn, sp.n_time_h, sp.n_time_h < n_all),
+                                     ("u", 1, u_last, un, sp.n_time_u, n_all > sp.n_time_u > 0)):
+        if on:
+            out[f"log::test_{tag}_known"] = mo.l1(last[:, :k], ref[:, :k])
+            out[f"log::test_{tag}_kn_scaled"] = mo.l1(sc_mean[:, :k, :, c:c + 1], gt_scaled[:, :k, :, c:c + 1])
+            out[f"log::test_{tag}_unkn_scaled"] = mo.l1(sc_mean[:, k:, :, c:c + 1], gt_scaled[:, k:, :, c:c + 1])
+    out["log::test_pde_loss"] = mo.pde_metric(system, xs[:, -1], st) / n_samples / nb
+    out["log::test_pde_loss_gt"] = mo.pde_metric(system, state_gt, st) / nb
+    last = xs[:, -1]
+    out["traj"] = last.reshape(n_samples, nb, *last.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)
+    out["gt"] = state_gt
+    return out
+
+
+def eval_validation_step(P, cfg: DdpmConfig, h: Tensor, u: Tensor, norm_stats, sp: RepaintParams, system: str, u_noise: Tensor,
+                         init: Tensor, step_noise, repeat_noise) -> Dict[str, Tensor]:
+    """PlDdim.validation_step on an evaluated epoch, models/ddim.py:294-370: the u field handed to sample_edm is NOISE
+    (``u_noise`` 'b t x 1', :306-309), so rows < n_time_u of it are treated as known."""
+    from . import mcedm_oracle as mo
+    st = norm_stats
+    hn, un = (h - st[0]) / st[1], (u - st[2]) / st[3]
+    state_gt = torch.cat([hn, un], dim=-1)
+    hu = torch.cat([hn, u_noise], dim=-1).permute(0, 3, 1, 2)
+    xs = sample_edm_repaint(P, cfg, hu, sp, init, step_noise, repeat_noise, return_last=True)
+    last = xs[:, -1]
+    h_last, u_last = last[..., 0:1], last[..., 1:2]
+    out = {"loss_h": mo.l1(h_last, hn), "loss": mo.l1(u_last, un),
+           "loss_h_un": mo.l1(h_last * st[1] + st[0], h), "loss_u_un": mo.l1(u_last * st[3] + st[2], u)}
+    gt_scaled, xs_scaled = mo.scale_each_min_max(state_gt), mo.scale_each_min_max(last)
+    out["val_loss_h_scaled"] = mo.l1(xs_scaled[..., 0:1], gt_scaled[..., 0:1])
+    out["val_loss_u_scaled"] = mo.l1(xs_scaled[..., 1:2], gt_scaled[..., 1:2])
+    corr = mo.correlation(last, state_gt)
+    out["log::val_corr_h"], out["log::val_corr_u"] = corr[0:1].mean(), corr[1:2].mean()
+    out["log::val_pde_loss"] = mo.pde_metric(system, last, st) / len(h)
+    out["traj"], out["gt"] = last.unsqueeze(1), state_gt
+    return out

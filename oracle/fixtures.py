@@ -302,3 +302,50 @@ def data_tree_flat():
     for k, v in attrs.items():
         flat[f"__attrs__/{k}"] = np.asarray(v)
     return flat
+
+
+# ---- evaluation loops of models/ddim.py: PlDdim.test_step / validation_step (:294-533, what BASELINE config 5 is run
+# through) and PlCondEdm.test_step / validation_step (:1154-1319, BASELINE config 4 read as the single-task model) -----------
+# tag -> (system, n_samples, timesteps, n_repeat, S_churn, n_time_h, n_time_u)
+EVAL_DDPM_CASES = {
+    "n1_r2": ("swe_per", 1, 5, 2, 0.0, 0, 16),         # config 5 at plumbing size: h unknown, first half of u known
+    "n5_r3": ("swe_per", 5, 4, 3, 15.0, 8, 0),
+}
+EVAL_DDPM_VAL = ("swe_per", 1, 4, 2, 0.0, 0, 16)
+# input mean/std, target mean/std: a random-weight network drives the states to O(500), so the scales are kept small enough
+# that the un-normalised water height stays positive (the residual divides by it)
+EVAL_DDPM_STATS = (1.4, 0.002, 0.0, 0.002)
+EVAL_B = 2
+# tag -> (system, n_samples, guide_dx, norm stats)
+EVAL_COND_CASES = {
+    "swe_n2": ("swe_per", 2, False, STEP_NORM_STATS),
+    "darcy_n16": ("darcy", 16, False, STEP_NORM_STATS),
+    # guided Darcy sampling with every cell of the log-probability form saturated (u is scaled down until D u ~ 0, so
+    # sigmoid(1e5 (Du - 1)^2) == 1 in fp32 and the gradient is exactly zero): the whole guided loop is comparable
+    "darcy_guided_sat": ("darcy", 2, True, (1.4, 0.05, 0.0, 1e-8)),
+}
+
+
+def eval_ddpm_inputs(tag: str):
+    """h, u un-normalised 'b t x 1' + the (n b)-batch noises of sample_edm (NCHW; per-step and per-repeat draws fp64)."""
+    system, n, N, R, churn, nth, ntu = EVAL_DDPM_VAL if tag == "val" else EVAL_DDPM_CASES[tag]
+    B, S, st = EVAL_B, CFG_D.resolution, EVAL_DDPM_STATS
+    h = randn(f"evalddpm/{tag}/h", B, S, S, 1) * st[1] + st[0]
+    u = randn(f"evalddpm/{tag}/u", B, S, S, 1) * st[3] + st[2]
+    init = randn(f"evalddpm/{tag}/init", n * B, 2, S, S)
+    steps = [randn(f"evalddpm/{tag}/step{i}", n * B, 2, S, S).double() for i in range(N)]
+    reps = [[randn(f"evalddpm/{tag}/rep{i}_{k}", n * B, 2, S, S).double() for k in range(R - 1)] for i in range(N)]
+    u_noise = randn(f"evalddpm/{tag}/u_noise", B, S, S, 1)          # validation_step hands noise in as u
+    return h, u, init, steps, reps, u_noise
+
+
+def eval_cond_inputs(tag: str):
+    """h, u un-normalised 'b t x 1' and the sampler's initial noise '(n b) t x 1'."""
+    if tag == "val":
+        n, st = 1, STEP_NORM_STATS
+    else:
+        _, n, _, st = EVAL_COND_CASES[tag]
+    B, T, X = EVAL_B, 32, 32
+    h = randn(f"evalcond/{tag}/h", B, T, X, 1) * st[1] + st[0]
+    u = randn(f"evalcond/{tag}/u", B, T, X, 1) * st[3] + st[2]
+    return h, u, randn(f"evalcond/{tag}/init", n * B, T, X, 1)

@@ -572,3 +572,74 @@ def eval_validation_step(P, cfg, h, u, masks, noises, norm_stats, sp: SamplerPar
         out[f"traj_{name}"] = hu_last.unsqueeze(1)
         out[f"gt_{name}"] = state_gt
     return out
+
+
+# --------------------------------------------------------------------------- #
+# metrics shared by the evaluation loops of models/ddim.py (PlDdim :294-533, PlCondDdim :1154-1319)
+# --------------------------------------------------------------------------- #
+def l1(a: Tensor, b: Tensor) -> Tensor:
+    """nn.L1Loss(): mean |a - b| (nan on an empty slice, as in the reference)."""
+    return (a - b).abs().mean()
+
+
+def scale_each_min_max(state: Tensor) -> Tensor:
+    """models/ddim.py:689-698: 'b h w c' -> per (sample, channel) (x - min) / (max - min)."""
+    lo = state.amin(dim=(1, 2), keepdim=True)
+    hi = state.amax(dim=(1, 2), keepdim=True)
+    return (state - lo) / (hi - lo)
+
+
+def correlation(pred: Tensor, target: Tensor) -> Tensor:
+    """CorrelationLoss(reduction='none'), models/losses.py:93-124 -> [c]."""
+    x = pred.reshape(pred.shape[0], -1, pred.shape[-1])
+    y = target.reshape(target.shape[0], -1, target.shape[-1])
+    xb, yb = x - x.mean(dim=1, keepdim=True), y - y.mean(dim=1, keepdim=True)
+    den = torch.sqrt((xb * xb).sum(dim=1) * (yb * yb).sum(dim=1))
+    den = torch.where(den == 0, den + 1e-7, den)
+    return ((yb * xb).sum(dim=1) / den).mean(dim=0)
+
+
+def _unnorm(x: Tensor, mean, std) -> Tensor:
+    return x * std + mean
+
+
+def eval_cond_test_step(P, cfg, h: Tensor, u: Tensor, norm_stats, sp: SamplerParams, n_samples: int, system: str,
+                        init: Tensor, guidance: bool = False) -> Dict[str, Tensor]:
+    """PlCondEdm.test_step, models/ddim.py:1219-1319 (cond_channels == h_ch, return_last True, select_by_pde False,
+    plot_scaled False).  ``init`` [(n b), T, X, 1] replaces the randn_like(u_rep) of :1237.  Logged scalars under 'log::'."""
+    st = norm_stats
+    hn, un = (h - st[0]) / st[1], (u - st[2]) / st[3]
+    state_gt = torch.cat([hn, un], dim=-1)
+    nb = len(h)
+    cond = hn.repeat(n_samples, 1, 1, 1).permute(0, 3, 1, 2)
+    g = (lambda hh, dd: guidance_dx_cond(system, hh, dd, st)) if guidance else None
+    xs = sample_edm_cond(P, cfg, cond, sp, init.permute(0, 3, 1, 2), None, return_last=True, guidance=g)
+    xs_mean = xs.reshape(n_samples, nb, *xs.shape[1:]).mean(dim=0)
+    u_last = xs_mean[:, -1, :, :, :1]
+    out = {"loss": l1(u_last, un), "loss_u_un": l1(_unnorm(u_last, st[2], st[3]), u)}
+    gt_scaled, xs_scaled = scale_each_min_max(state_gt), scale_each_min_max(xs[:, -1])
+    xs_scaled_mean = xs_scaled.reshape(n_samples, nb, *xs_scaled.shape[1:]).mean(dim=0)
+    out["test_mae_u_scaled"] = l1(xs_scaled_mean, gt_scaled[..., 1:2])
+    out["log::test_corr_u"] = correlation(xs_mean[:, -1], un).mean()
+    joint = torch.cat([hn.repeat(n_samples, 1, 1, 1).double(), xs[:, -1]], dim=-1)
+    out["log::test_pde_loss"] = pde_metric(system, joint, st) / n_samples / nb
+    out["log::test_pde_loss_gt"] = pde_metric(system, state_gt, st) / nb
+    last = xs[:, -1]
+    out["traj"] = last.reshape(n_samples, nb, *last.shape[1:]).permute(1, 2, 3, 0, 4).unsqueeze(1)
+    out["gt"] = un
+    return out
+
+
+def eval_cond_validation_step(P, cfg, h: Tensor, u: Tensor, norm_stats, sp: SamplerParams, system: str, init: Tensor) -> Dict[str, Tensor]:
+    """PlCondEdm.validation_step on an evaluated epoch, models/ddim.py:1154-1217; ``init`` [b, T, X, 1] = randn_like(u)."""
+    st = norm_stats
+    hn, un = (h - st[0]) / st[1], (u - st[2]) / st[3]
+    state_gt = torch.cat([hn, un], dim=-1)
+    xs = sample_edm_cond(P, cfg, hn.permute(0, 3, 1, 2), sp, init.permute(0, 3, 1, 2), None, return_last=True)
+    last = xs[:, -1]
+    out = {"loss": l1(last, un), "loss_u_un": l1(_unnorm(last, st[2], st[3]), u)}
+    out["val_loss_u_scaled"] = l1(scale_each_min_max(last), scale_each_min_max(state_gt)[..., 1:2])
+    out["log::val_corr_u"] = correlation(last, un).mean()
+    out["log::val_pde_loss"] = pde_metric(system, torch.cat([hn.double(), last], dim=-1), st) / len(h)
+    out["traj"], out["gt"] = last.unsqueeze(1), un
+    return out

@@ -249,3 +249,57 @@ def test_ddpm_repaint_sampler(golden, tag):
     with torch.no_grad():
         xs = dorc.sample_edm_repaint(P, cfg, hu, sp, init, stp, reps, return_last=False)
     close(xs, g[f"{tag}_xs"], rtol=1e-5, atol=1e-6 * float(np.abs(g[f"{tag}_xs"]).max()))
+
+
+# ---- evaluation loops of models/ddim.py (tests/golden/eval_steps.npz, oracle/make_golden_eval.py) ------------------------
+def _check_eval(g, prefix, o):
+    ref_keys = sorted(k.split("::", 1)[1] for k in g if k.startswith(prefix + "::") and "::log::" not in k)
+    assert ref_keys == sorted(k for k in o if not k.startswith("log::")), (ref_keys, sorted(o))
+    for k in ref_keys:
+        ref = torch.as_tensor(g[f"{prefix}::{k}"])
+        close(o[k], ref, rtol=1e-4, atol=1e-5 * max(1.0, float(ref.abs().max())))
+    n_logs = 0
+    for k in (k.split("::log::")[1] for k in g if k.startswith(prefix + "::log::")):
+        if f"log::{k}" not in o:
+            continue
+        ref = torch.as_tensor(g[f"{prefix}::log::{k}"])
+        torch.testing.assert_close(torch.as_tensor(o[f"log::{k}"]).to(ref.dtype), ref, rtol=2e-3 if "pde" in k else 1e-4, atol=1e-6,
+                                   equal_nan=True)
+        n_logs += 1
+    return n_logs
+
+
+@pytest.mark.parametrize("tag", list(fx.EVAL_DDPM_CASES) + ["val"])
+def test_eval_plddim_steps(golden, tag):
+    """PlDdim.test_step / validation_step (models/ddim.py:294-533): how BASELINE config 5 is driven."""
+    from oracle import ddpm_oracle as dorc
+    g = golden("eval_steps.npz")
+    cfg = fx.CFG_D
+    P = dorc.make_params(cfg, 21)
+    system, n, N, R, churn, nth, ntu = fx.EVAL_DDPM_VAL if tag == "val" else fx.EVAL_DDPM_CASES[tag]
+    sp = dorc.RepaintParams(timesteps=N, n_repeat=R, S_churn=churn, n_time_h=nth, n_time_u=ntu)
+    h, u, init, steps, reps, u_noise = fx.eval_ddpm_inputs(tag)
+    with torch.no_grad():
+        if tag == "val":
+            o = dorc.eval_validation_step(P, cfg, h, u, fx.EVAL_DDPM_STATS, sp, system, u_noise, init, steps, reps)
+        else:
+            o = dorc.eval_test_step(P, cfg, h, u, fx.EVAL_DDPM_STATS, sp, n, system, init, steps, reps)
+    assert _check_eval(g, f"ddpm_{tag}", o) >= 3
+    if tag == "n1_r2":          # n_time_h = 0: the reference's L1 over an empty slice is nan, and it is logged as such
+        assert np.isnan(g["ddpm_n1_r2::log::test_h_known"])
+
+
+@pytest.mark.parametrize("tag", list(fx.EVAL_COND_CASES) + ["val"])
+def test_eval_plcondedm_steps(golden, tag):
+    """PlCondEdm.test_step / validation_step (models/ddim.py:1154-1319)."""
+    g = golden("eval_steps.npz")
+    cfg = fx.CFG_C
+    P = orc.make_params(cfg, 13)
+    h, u, init = fx.eval_cond_inputs(tag)
+    with torch.no_grad():
+        if tag == "val":
+            o = orc.eval_cond_validation_step(P, cfg, h, u, fx.STEP_NORM_STATS, orc.SamplerParams(), "swe_per", init)
+        else:
+            system, n, guided, st = fx.EVAL_COND_CASES[tag]
+            o = orc.eval_cond_test_step(P, cfg, h, u, st, orc.SamplerParams(), n, system, init, guidance=guided)
+    assert _check_eval(g, f"cond_{tag}", o) >= 2
