@@ -164,7 +164,6 @@ class DhariwalUNet(nn.Module):
         self._plan: Optional[_lib.Plan] = None
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
-        self._param_list = None
         self._ws = _lib.Workspace()
 
     # ---- HIP plumbing -------------------------------------------------------------------------------
@@ -191,19 +190,17 @@ class DhariwalUNet(nn.Module):
         return super()._load_from_state_dict(*args, **kwargs)
 
     def packed_weights(self) -> torch.Tensor:
-        """MFMA-ordered copies of the weights; re-packed whenever a parameter was written (autograd-visible) or moved."""
-        if self._packed_key is not None and self._param_list is not None:
-            params_l = self._param_list
-        else:
-            params_l = self._param_list = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params_l)
+        """MFMA-ordered copies of the weights; re-packed whenever a parameter was written (autograd-visible), moved or
+        REPLACED: the key walks the live ``self.parameters()`` and holds (id, data_ptr, version) of each, so a new
+        ``nn.Parameter`` object put in by ``setattr`` / parametrize / pruning is seen (walking ~200 parameters costs tens
+        of microseconds per sampling call or training step)."""
+        key = tuple((id(p), p.data_ptr(), p._version) for p in self.parameters())
         if self._packed is not None and key == self._packed_key:
             return self._packed
         params = self.named_param_dict()
-        if self._packed is None or key != self._packed_key:
-            self._packed = self.plan.pack(params, self._packed if (self._packed is not None and self._packed.device ==
-                                                                  next(iter(params.values())).device) else None)
-            self._packed_key = key
+        reuse = self._packed is not None and self._packed.device == next(iter(params.values())).device
+        self._packed = self.plan.pack(params, self._packed if reuse else None)
+        self._packed_key = key
         return self._packed
 
     def _check_extra(self, x_self_cond, dx, class_labels, augment_labels):
@@ -229,9 +226,8 @@ class EmaModel(nn.Module):
         import copy
         self.beta = beta
         plan, packed, model._plan, model._packed = model._plan, model._packed, None, None   # not deep-copyable
-        plist, model._param_list = model._param_list, None
         self.ma_model = copy.deepcopy(model)
-        model._plan, model._packed, model._param_list = plan, packed, plist
+        model._plan, model._packed = plan, packed
         self.ma_model._packed_key = None
 
     def update(self, current_model):

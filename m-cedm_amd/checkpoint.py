@@ -5,8 +5,9 @@ it.  A ``.ckpt`` is a ``torch.save``-d dict whose ``"state_dict"`` holds ``model
 checkpoint loads with ``strict=True``.
 
 The other entries of a Lightning checkpoint (``hyper_parameters`` -- an OmegaConf object --, optimizer states, callbacks)
-may need packages this image does not have: ``read_checkpoint`` therefore unpickles with stand-ins for unknown classes
-and returns only tensors, numbers and plain containers.
+may need packages this image does not have, and a pickle can name ANY importable callable: ``read_checkpoint`` therefore
+unpickles through an allow-list (tensors, storages, dtypes, numpy arrays, plain containers) and turns every other global
+into an inert placeholder.
 """
 from __future__ import annotations
 
@@ -18,10 +19,17 @@ import torch
 
 
 class _Opaque:
-    """Stand-in for an object whose class is not importable here (e.g. omegaconf.DictConfig)."""
+    """Inert stand-in for an object whose class is not on the allow-list (e.g. omegaconf.DictConfig, a callback, or a
+    hostile reducer): it swallows whatever the pickle stream does to it (construction, state, items) and does nothing."""
+
+    args, kwargs, state = (), {}, None     # class-level defaults: pickle may build instances through __new__ alone
 
     def __init__(self, *a, **k):
-        self.args, self.kwargs, self.state = a, k, None
+        self.args, self.kwargs = a, k
+
+    @property
+    def items(self):
+        return self.__dict__.setdefault("_items", [])
 
     def __setstate__(self, state):
         self.state = state
@@ -29,33 +37,72 @@ class _Opaque:
     def __call__(self, *a, **k):          # some reducers call the reconstructed object
         return self
 
+    def __setitem__(self, key, value):    # SETITEM(S) of dict subclasses
+        self.items.append((key, value))
 
-class _TolerantUnpickler(pickle.Unpickler):
+    def append(self, value):              # APPEND(S) of list subclasses
+        self.items.append(value)
+
+    def extend(self, values):
+        self.items.extend(values)
+
+    def add(self, value):                 # ADDITEMS of set subclasses
+        self.items.append(value)
+
+
+# Globals a tensor checkpoint legitimately needs.  Everything else -- importable or not -- is replaced by an inert
+# placeholder, so unpickling never resolves (and REDUCE never calls) os.system, builtins.eval, subprocess.Popen, ...
+_ALLOWED = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("_codecs", "encode"),                       # how pickle protocol 2 (torch.save's) spells a bytes literal
+    ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "slice"), ("builtins", "range"), ("builtins", "complex"),
+}
+
+
+def _allowed(module: str, name: str) -> bool:
+    if (module, name) in _ALLOWED:
+        return True
+    if module == "torch" and (name.endswith("Storage") or isinstance(getattr(torch, name, None), torch.dtype)):
+        return True
+    return module.startswith("numpy") and name in ("float32", "float64", "int32", "int64", "bool_", "uint8", "int8", "int16",
+                                                    "float16", "complex64", "complex128")
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    """Allow-list unpickler: tensors, storages, dtypes, numpy arrays and plain containers are rebuilt; every other global
+    (hyper_parameters' OmegaConf objects, callbacks, optimizer classes, or anything hostile) becomes an ``_Opaque``."""
+
     def find_class(self, module, name):
-        try:
+        if _allowed(module, name):
             return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            return type(f"{module}.{name}".replace(".", "_"), (_Opaque,), {})
+        return type(f"{module}.{name}".replace(".", "_"), (_Opaque,), {})
 
 
-class _TolerantPickle:
+class _RestrictedPickle:
     """The ``pickle_module`` interface torch.load expects."""
-    __name__ = "mcedm_tolerant_pickle"
-    Unpickler = _TolerantUnpickler
+    __name__ = "mcedm_restricted_pickle"
+    Unpickler = _RestrictedUnpickler
 
     @staticmethod
     def load(f, **kw):
-        return _TolerantUnpickler(f, **kw).load()
+        return _RestrictedUnpickler(f, **kw).load()
 
 
 def read_checkpoint(path_or_buffer) -> Dict[str, Any]:
-    """Load a Lightning ``.ckpt`` (or any ``torch.save`` dict) to CPU.  Unknown classes become opaque placeholders."""
+    """Load a Lightning ``.ckpt`` (or any ``torch.save`` dict) to CPU.  ``weights_only=True`` first; a real Lightning file
+    fails that (its ``hyper_parameters`` entry holds OmegaConf objects), and is then read by the allow-list unpickler above,
+    which never imports or calls a global outside ``_ALLOWED``: loading an untrusted file cannot execute code."""
     try:
         return torch.load(path_or_buffer, map_location="cpu", weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError:
         if hasattr(path_or_buffer, "seek"):
             path_or_buffer.seek(0)
-        return torch.load(path_or_buffer, map_location="cpu", weights_only=False, pickle_module=_TolerantPickle)
+        return torch.load(path_or_buffer, map_location="cpu", weights_only=False, pickle_module=_RestrictedPickle)
 
 
 def state_dict_of(ckpt: Dict[str, Any]) -> Dict[str, torch.Tensor]:

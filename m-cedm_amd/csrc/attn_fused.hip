@@ -7,6 +7,7 @@
 // fragments (A operands of qkv / proj) straight from the packed 1x1 tables, all requested before anything waits.
 //   layout of a 32 x 32 MFMA result: lane l, register r  <->  row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
 // The fused GroupNorm statistics of z (for the next block's conv0) are emitted exactly as a conv epilogue would.
+#include <atomic>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -214,12 +215,12 @@ int launch_attn_block64(const float* y, float* z, const float* gamma, const floa
   ProfScope ps("attn_block64_kernel", (double)B * 2.0 * 64 * 64 * (192 + 64 + 64 + 64),
                4.0 * ((double)B * 2 * 64 * 64 + 64.0 * (192 + 64)), stream);
   constexpr int lds_bytes = (4 * 64 * 64 + 64 * 65 + 4 * 64 + 2 * 16 * 3) * (int)sizeof(float);
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];      // zero-initialised; a repeated set is benign, a data race is not
   int dev = 0;
   MCEDM_HIP_TRY(hipGetDevice(&dev));
-  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+  if (dev >= 0 && dev < 64 && !attr_set[dev].load(std::memory_order_acquire)) {
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)attn_block64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set[dev] = true;
+    attr_set[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(attn_block64_kernel, dim3(B), dim3(256), lds_bytes, stream, a);
   MCEDM_LAUNCH_CHECK("attn_block64_kernel");

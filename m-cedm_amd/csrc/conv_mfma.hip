@@ -20,6 +20,7 @@
 // bit-identical), conv_small_cout_kernel (the ch -> out_channels output conv), pack_conv / pack_bias.
 // What bounds them and what was tried is written up in DESIGN.md section 3; the short version: fp32 VALU work
 // does not overlap fp32 MFMA work on gfx950, so every vector instruction here is paid in matrix time.
+#include <atomic>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -766,13 +767,13 @@ static int launch_conv8(const ConvArgs& a_in, hipStream_t stream) {
   const long long blocks = (long long)a.B * tiles_x * tiles_y * mtiles;
   constexpr int lds_max = 160 * 1024;
   const int lds_bytes = 2 * (C::WL + C::XL) * (int)sizeof(float) + (a.Ca + a.Cb) * (int)sizeof(Coef);
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];      // zero-initialised; a repeated set is benign, a data race is not
   {
     int dev = 0;
     MCEDM_HIP_TRY(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    if (dev >= 0 && dev < 64 && !attr_set[dev].load(std::memory_order_acquire)) {
       MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv8_mfma_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-      attr_set[dev] = true;
+      attr_set[dev].store(true, std::memory_order_release);
     }
   }
   char name[96] = "";

@@ -23,6 +23,7 @@
 // folded projection's channel pairs), so for one tile configuration the two kernels are BIT-IDENTICAL (tested; the K-split
 // tile groups the sum per wave and is only close); which one runs is decided by the image size, channel counts and
 // alignment only, never by the batch size.  DESIGN.md section 3 has the measurements and what did not work.
+#include <atomic>
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -528,15 +529,19 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
   const int mtiles = ceil_div(a.Cout, C::MT);
   const long long blocks = (long long)a.B * tiles_x * tiles_y * mtiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) { set_error("conv grid out of range (%lld blocks)", blocks); return MCEDM_ERR_INVALID; }
-  static bool attr_set[64] = {};
-  static int ncu[64] = {};
+  static std::atomic<bool> attr_set[64];      // zero-initialised; a repeated set is benign, a data race is not
+  static std::atomic<int> ncu[64];
   int dev = 0;
   MCEDM_HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) { set_error("device index %d out of range", dev); return MCEDM_ERR_INVALID; }
-  if (!ncu[dev]) MCEDM_HIP_TRY(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev));
-  if (!attr_set[dev]) {
+  int n_cu = ncu[dev].load(std::memory_order_acquire);
+  if (!n_cu) {
+    MCEDM_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    ncu[dev].store(n_cu, std::memory_order_release);
+  }
+  if (!attr_set[dev].load(std::memory_order_acquire)) {
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_resident_kernel<C, RS, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
-    attr_set[dev] = true;
+    attr_set[dev].store(true, std::memory_order_release);
   }
   char name[96] = "";
   if (prof_enabled())
@@ -549,7 +554,7 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
                               (double)a.Cout * ((a.Ca + a.Cb) * C::TAPS + skc));
   ProfScope ps(name, flops, bytes, stream);
   hipLaunchKernelGGL((conv_resident_kernel<C, RS, SPLIT>), dim3((unsigned)blocks), dim3(256), (unsigned)plan.lds, stream, a, tiles_x,
-                     tiles_y, mtiles, plan.pass_c, cout_padded(a.Cout), plan.nslab, plan.wide, SPLIT ? ncu[dev] : 0);
+                     tiles_y, mtiles, plan.pass_c, cout_padded(a.Cout), plan.nslab, plan.wide, SPLIT ? n_cu : 0);
   MCEDM_LAUNCH_CHECK("conv_resident_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
   return MCEDM_OK;

@@ -455,8 +455,15 @@ class PlDdim(_EvalMetrics, _Base):
         self.h_ch = self.u_ch = n_state
         self.edm_steps = None
         self.sigma_min = self.sigma_max = None
+        from .pde_loss import get_pde_loss_function
+        self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system="swe", flip_xy=False)    # models/ddim.py:76-78
         self._sample_ws = _lib.Workspace()
         self._graphs = {}
+
+    def set_pde_loss_function(self, system, flip_xy):
+        """models/ddim.py:97-101; the residual metric runs on the device (m-cedm_amd/pde_loss.py)."""
+        from .pde_loss import get_pde_loss_function
+        self.pde_loss, self.pde_loss_simulator = get_pde_loss_function(system, flip_xy)
 
     # ---- schedule (host side, the reference's own expressions on CPU tensors) ----------------------------------
     def set_test_sampler_params(self, params):

@@ -143,7 +143,6 @@ class Model(nn.Module):
         self._plan: Optional[_lib.DdpmPlan] = None
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
-        self._param_list = None          # (EmaModel's deep copy resets the runtime state by these names)
         self._ws = _lib.Workspace()
 
     # ---- HIP plumbing -------------------------------------------------------------------------------

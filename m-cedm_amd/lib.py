@@ -467,15 +467,45 @@ class DdpmPlan:
         return out
 
 
+class _PinnedWorkspace:
+    """Workspace view with a FIXED buffer: a captured graph bakes the pointer in, so the buffer must neither move nor be
+    freed while the graph lives (the owner of the graph holds this object)."""
+
+    def __init__(self, ws: Optional[Workspace], nbytes: int, device):
+        self.buf = (ws or Workspace()).get(nbytes, device)
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if nbytes > self.buf.numel() or self.buf.device != torch.device(device):
+            raise RuntimeError("graphed call: workspace request differs from the captured one")
+        return self.buf
+
+
+def _capture(run, dev) -> "torch.cuda.CUDAGraph":
+    """Warm ``run`` up once off the capture (lazily initialised library state settles), then capture it into a HIP graph.
+    capture_error_mode='thread_local': HIP calls of OTHER threads (DataLoader pin-memory thread, RCCL watchdog, logger
+    hooks) during the long capture do not invalidate it."""
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        run()
+    return graph
+
+
 class GraphedSampler:
     """The whole Heun sampling call (every U-Net evaluation and state update of mcedm_heun_sample: ~4000 launches at
     18 steps) captured ONCE into a HIP graph and replayed.  The library never allocates or synchronises and the sigma
     schedule is host-side arithmetic baked into kernel arguments, so a replay is exact; inputs are copied into static
     buffers first.  Shapes, sampler parameters and the packed-weight buffer are fixed per instance (re-packing weights
-    in place into the same buffer is fine)."""
+    in place into the same buffer is fine).  ``ws``: the caller's workspace to borrow (replays and eager calls of one
+    module are serial on one stream, so one buffer serves both); the instance keeps the buffer it captured with alive."""
 
     def __init__(self, plan: "Plan", packed: torch.Tensor, sd: SamplerDesc, B: int, H: int, W: int, masked: bool = True,
-                 has_cond: bool = True, churn: bool = False, return_last: bool = True):
+                 has_cond: bool = True, churn: bool = False, return_last: bool = True, ws: Optional[Workspace] = None):
         dev = packed.device
         self.plan, self.packed, self.sd, self.return_last = plan, packed, sd, return_last
         C = plan.in_channels
@@ -485,17 +515,8 @@ class GraphedSampler:
         self.step_noise = torch.zeros((sd.timesteps, B, C, H, W), dtype=torch.float64, device=dev) if churn else None
         T = 1 if return_last else sd.timesteps + 1
         self.out = torch.empty((B, T, H, W, C), dtype=torch.float64, device=dev)
-        self.ws = Workspace()
-        self.ws.get(plan.sampler_workspace_bytes(B, H, W), dev)
-        side = torch.cuda.Stream(device=dev)          # warm-up off the capture: lazily initialised library state settles
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            self._run()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._run()
+        self.ws = _PinnedWorkspace(ws, plan.sampler_workspace_bytes(B, H, W), dev)
+        self.graph = _capture(self._run, dev)
 
     def _run(self):
         self.plan.sample(self.packed, self.sd, self.cond, self.mask, self.init, self.step_noise, self.return_last, self.ws,
@@ -511,6 +532,27 @@ class GraphedSampler:
                 dst.copy_(src)
         self.graph.replay()
         return self.out
+
+
+def graphed_or_eager(cache: dict, key, build, eager, max_entries: int = 2):
+    """Replay the cached graph for ``key`` (building it with ``build()`` on first use, at most ``max_entries`` kept, oldest
+    evicted) and return ``fn`` such that fn(*args) runs the call; if the capture fails (another thread's HIP call under a
+    global capture mode, an out-of-memory while the static buffers are made) the entry is dropped, the failure is
+    remembered for this key and ``eager`` is returned instead: the evaluation loop goes on without a graph."""
+    hit = cache.get(key)
+    if hit is not None:
+        return hit if hit != "eager" else eager
+    while len(cache) >= max_entries:
+        cache.pop(next(iter(cache)))
+    try:
+        cache[key] = build()
+    except (RuntimeError, torch.cuda.OutOfMemoryError) as e:
+        import warnings
+        warnings.warn(f"HIP-graph capture of the sampling call failed ({str(e)[:200]}); running it eagerly")
+        torch.cuda.synchronize()
+        cache[key] = "eager"
+        return eager
+    return cache[key]
 
 
 # ---- flat-buffer training helpers -------------------------------------------------------------

@@ -320,20 +320,20 @@ class PlMcedm(_Base):
         cond, hu_mask, hu_noise = cond.float().contiguous(), hu_mask.float().contiguous(), hu_noise.contiguous()
         with torch.no_grad():
             packed = net.packed_weights()
-            if os.environ.get("MCEDM_HIP_GRAPH", "1") != "0":
-                # the ~4000 launches of one sampling call replayed from one HIP graph (lib.GraphedSampler); instances are
-                # kept per (shape, sampler parameters, weight buffer) -- test / validation loops repeat the same call
-                B, _, H, W = hu_noise.shape
-                key = (B, H, W, bool(return_last), churn, packed.data_ptr(), hu_noise.device.index,
-                       tuple(getattr(sd, f) for f, _ in sd._fields_))
-                gs = self._graphs.get(key)
-                if gs is None:
-                    if len(self._graphs) >= 4:
-                        self._graphs.pop(next(iter(self._graphs)))
-                    gs = self._graphs[key] = _lib.GraphedSampler(net.plan, packed, sd, B, H, W, masked=True, has_cond=True,
-                                                                churn=churn, return_last=return_last)
-                return gs(cond, hu_mask, hu_noise, step_noise).clone()
-            return net.plan.sample(packed, sd, cond, hu_mask, hu_noise, step_noise, return_last=return_last, ws=self._sample_ws)
+            eager = lambda c, m_, i, sn: net.plan.sample(packed, sd, c, m_, i, sn, return_last=return_last, ws=self._sample_ws)
+            if os.environ.get("MCEDM_HIP_GRAPH", "1") == "0":
+                return eager(cond, hu_mask, hu_noise, step_noise)
+            # the ~4000 launches of one sampling call replayed from one HIP graph (lib.GraphedSampler); at most two
+            # instances are kept per module (the evaluation loops repeat one call; a ragged last batch is the second),
+            # they borrow this module's sampler workspace, and a failed capture falls back to the eager call
+            B, _, H, W = hu_noise.shape
+            key = (B, H, W, bool(return_last), churn, packed.data_ptr(), hu_noise.device.index,
+                   tuple(getattr(sd, f) for f, _ in sd._fields_))
+            fn = _lib.graphed_or_eager(self._graphs, key, lambda: _lib.GraphedSampler(
+                net.plan, packed, sd, B, H, W, masked=True, has_cond=True, churn=churn, return_last=return_last,
+                ws=self._sample_ws), eager)
+            out = fn(cond, hu_mask, hu_noise, step_noise)
+            return out.clone() if fn is not eager else out
 
     # ---- evaluation loops (host-side bookkeeping, mcedm.py:283-441) ----------------------------------------
     def get_pde_loss(self, x_denoised, x_gt_unnorm=None, noise_level=None, clamp_loss=True, do_rearrange=True,

@@ -1,7 +1,8 @@
 """Golden vectors for PDE guidance inside the sampler, made by RUNNING THE REFERENCE (build
 container only): PlCondEdm.sample_edm(..., guide_dx=True) (models/ddim.py:1532-1601 with get_dx_log_prob :641-650 and
 get_dx_pde :1424-1450) for the SWE and Darcy residuals.  (The joint model's hook, models/mcedm.py:500-518, slices the
-last axis of an NCHW tensor and raises in the reference: there is nothing to pin there, see tests/test_guidance_cpu.py.)
+last axis of an NCHW tensor and raises in the reference: the fact is recorded as 'joint_model_guidance_raises' and checked by
+tests/test_hip_cond_edm.py::test_joint_model_guidance_is_rejected_like_the_reference.)
 
     python oracle/make_golden_guided.py        # rewrites tests/golden/guided.npz
 """

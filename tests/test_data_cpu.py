@@ -149,3 +149,32 @@ def test_tolerant_unpickler_skips_unknown_classes(tmp_path):
     del sys.modules["vanishing_pkg"]                         # the class can no longer be imported
     c = ck.read_checkpoint(str(path))
     assert c["epoch"] == 7 and torch.equal(c["state_dict"]["w"], torch.ones(3)) and c["hyper_parameters"] is not None
+
+
+class _Boom:
+    """A pickle whose REDUCE would call an importable function with side effects."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __reduce__(self):
+        import os
+        return (os.mkdir, (self.path,))
+
+
+def test_checkpoint_loading_never_calls_importable_globals(tmp_path):
+    """A hostile .ckpt (hyper_parameters reducing to os.mkdir(...)) must load its tensors WITHOUT executing the call: the
+    fallback unpickler is an allow-list, importable globals included (round-2 advisor finding)."""
+    marker = tmp_path / "pwned"
+    path = tmp_path / "evil.ckpt"
+    torch.save({"state_dict": {"w": torch.arange(4.0)}, "hyper_parameters": _Boom(str(marker)), "epoch": 3}, str(path))
+    c = ck.read_checkpoint(str(path))
+    assert not marker.exists(), "unpickling executed os.mkdir"
+    assert c["epoch"] == 3 and torch.equal(c["state_dict"]["w"], torch.arange(4.0))
+    assert isinstance(c["hyper_parameters"], ck._Opaque)
+    # numpy payloads (Lightning stores some counters as numpy scalars) still load
+    import numpy as np
+    p2 = tmp_path / "np.ckpt"
+    torch.save({"state_dict": {"w": torch.ones(2)}, "best": np.float64(0.25), "arr": np.arange(3)}, str(p2))
+    c2 = ck.read_checkpoint(str(p2))
+    assert float(c2["best"]) == 0.25 and list(c2["arr"]) == [0, 1, 2]

@@ -96,3 +96,85 @@ def test_one_state_against_oracle_full_size(net):
     with torch.no_grad():
         ref = orc.sample_edm(P, CFG, cond, m, orc.SamplerParams(timesteps=18), init)
     torch.testing.assert_close(xs.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+# ---- BASELINE config 5 at full size: the DDPM U-Net (configs/model/ddim_res32.yaml at 128 x 128: levels 128 / 64 / 32,
+# single-head attention over T = 1024 tokens at 32^2, stride-2 convs 128 -> 64 -> 32) under the RePaint sampler ------------
+from oracle import ddpm_oracle as dorc  # noqa: E402
+
+CFG_D128 = dorc.DdpmConfig()            # resolution 128, ch 64, ch_mult (1, 1, 1), attn_resolutions (32,), self_cond
+
+
+@pytest.fixture(scope="module")
+def ddpm_net():
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd import lib
+    c = CFG_D128
+    plan = lib.DdpmPlan(c.in_channels, c.out_ch, c.ch, c.ch_mult, c.num_res_blocks, c.attn_resolutions, c.resolution)
+    P = dorc.make_params(c, 21)
+    packed = plan.pack({k: v.cuda() for k, v in P.items()}, dorc.timestep_freqs(c.ch).cuda())
+    return lib, plan, packed, P
+
+
+def repaint_inputs(B, N, R, seed):
+    g = torch.Generator().manual_seed(seed)
+    hu = torch.randn(B, 2, H, W, generator=g)
+    init = torch.randn(B, 2, H, W, generator=g)
+    steps = torch.randn(N, B, 2, H, W, generator=g).double()
+    reps = torch.randn(N, R - 1, B, 2, H, W, generator=g).double()
+    return hu, init, steps, reps
+
+
+def repaint_desc(lib, sp):
+    betas = dorc.betas_of(CFG_D128)
+    return lib.repaint_desc(sp, dorc.edm_steps_of(betas), dorc.alphas_ext_of(betas), 1, 1)
+
+
+def test_repaint_full_size_shard_invariance_determinism_and_known_entries(ddpm_net):
+    """config 5's shape (n_time_h = 0, n_time_u = 64) with 3 resampling loops and churn: one B = 8 call == two B = 4 calls
+    bit for bit, reruns are bitwise identical, known rows come out as the clean data, the rest is finite and non-trivial."""
+    lib, plan, packed, _ = ddpm_net
+    B, N, R = 8, 4, 3
+    sp = dorc.RepaintParams(timesteps=N, n_repeat=R, S_churn=15.0, n_time_h=0, n_time_u=64)
+    rd, keep = repaint_desc(lib, sp)
+    hu, init, steps, reps = repaint_inputs(B, N, R, 0)
+    ws = lib.Workspace()
+    run = lambda s: plan.repaint_sample(packed, rd, hu[s].contiguous().cuda(), init[s].contiguous().cuda(),
+                                        steps[:, s].contiguous().cuda(), reps[:, :, s].contiguous().cuda(), return_last=False,
+                                        ws=ws)
+    full = run(slice(0, B))
+    assert torch.equal(full, run(slice(0, B))), "the RePaint path must be bitwise reproducible"
+    halves = torch.cat([run(slice(0, 4)), run(slice(4, 8))])
+    assert torch.equal(full, halves), "batch items must be independent (exact shardability across GPUs)"
+    assert full.dtype == torch.float64 and tuple(full.shape) == (B, N + 1, H, W, 2) and bool(torch.isfinite(full).all())
+    last = full[:, -1].cpu()
+    assert torch.equal(last[:, :64, :, 1], hu[:, 1, :64].double()), "known rows of u must be the clean data"
+    assert float((last[:, :, :, 0] - hu[:, 0].double()).abs().max()) > 1e-3, "h is generated, not copied"
+    assert float(last[:, 64:, :, 1].std()) > 1e-3
+
+
+def test_repaint_one_state_against_oracle_full_size(ddpm_net):
+    """one state, 4 steps x 2 resampling loops (14 evaluations of the 128 x 128 network) against the CPU oracle."""
+    lib, plan, packed, P = ddpm_net
+    N, R = 4, 2
+    sp = dorc.RepaintParams(timesteps=N, n_repeat=R, S_churn=0.0, n_time_h=0, n_time_u=64)
+    rd, keep = repaint_desc(lib, sp)
+    hu, init, steps, reps = repaint_inputs(1, N, R, 4)
+    xs = plan.repaint_sample(packed, rd, hu.cuda(), init.cuda(), None, reps.cuda(), return_last=False)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    with torch.no_grad():
+        ref = dorc.sample_edm_repaint(P, CFG_D128, hu, sp, init, [s for s in steps], [[r for r in rr] for rr in reps],
+                                      return_last=False)
+    scale = float(ref.abs().max())
+    print(f"repaint 128^2 one state: max|d| = {float((xs.cpu() - ref).abs().max()):.3e} on max|x| = {scale:.1f}")
+    torch.testing.assert_close(xs.cpu(), ref, rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_ddpm_forward_full_size_against_oracle(ddpm_net):
+    """Model.forward at 128 x 128 (T = 1024 single-head attention, stride-2 convs) for two samples."""
+    lib, plan, packed, P = ddpm_net
+    x = fx.randn("fullsize/ddpm/x", 2, 2, H, W)
+    y = plan.forward(packed, x.cuda(), 417.0)
+    with torch.no_grad():
+        ref = dorc.model_forward(P, CFG_D128, x, torch.tensor([417.0]))
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-5 * max(1.0, float(ref.abs().max())))

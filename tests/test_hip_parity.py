@@ -1,9 +1,9 @@
 """GPU parity: every HIP kernel and schedule, called through the C ABI (ctypes), against the oracle on the
 same seeded inputs and against the committed golden vectors (outputs of the reference itself).
 
-Tolerance (north_star): rtol 1e-4 / atol 1e-5 in fp32 for kernels, blocks and the whole network; the
-35-evaluation sampler is compared at rtol 1e-3 / atol 1e-4 on O(1) states (error growth through the
-fp64 Heun recursion) and its observed entries must be preserved bit-exactly.
+Tolerance (north_star): rtol 1e-4 / atol 1e-5 in fp32 for kernels, blocks, the whole network AND the
+35-evaluation sampler (the CPU noise floor of that sampler is 7-10e-7 on states of magnitude 4.7, the HIP path
+measures 1.3e-6: DESIGN.md section 4); its observed entries must be preserved bit-exactly.
 """
 import math
 
