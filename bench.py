@@ -55,7 +55,7 @@ WORKLOADS = {
 # BASELINE config 5: RePaint-style EDM sampling of the joint DDPM (PlDdim.sample_edm, models/ddim.py:959-1051) with
 # configs/model/ddim_res32.yaml (DDPM U-Net ch=64, attention at 32^2) on 128x128 fields: u known for the first 64 time
 # rows, h unknown (n_time_h=0, n_time_u=64), 32 resampling loops per step -> 18*32*2 - 32 = 1120 U-Net evaluations / state
-REPAINT = dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=16, n_repeat=32, n_time_h=0, n_time_u=64,
+REPAINT = dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32, n_repeat=32, n_time_h=0, n_time_u=64,
                name="SWE dam-break 128x128 RePaint (n_time_h=0, n_time_u=64, 32 resample loops/step), DDPM U-Net ch=64 "
                     "(BASELINE config 5)")
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -276,9 +276,11 @@ class Runner:
 
 
 class RepaintRunner:
-    """BASELINE config 5 on this rank's GPU (same interface as Runner; launches are eager: one call is ~80k kernels)."""
+    """BASELINE config 5 on this rank's GPU (same interface as Runner).  The per-step / per-loop noise is generated on the
+    device (mcedm_repaint_sample_rng: no 576-tensor noise buffer) and the whole call -- 18 steps x 32 resampling loops =
+    1120 U-Net evaluations per state, ~70 000 launches -- is replayed from ONE HIP graph (lib.GraphedRepaint)."""
 
-    def __init__(self, B, device, rank):
+    def __init__(self, B, device, rank, use_graph=True):
         import torch
         from mcedm_amd import lib
         self.lib, self.torch = lib, torch
@@ -301,16 +303,24 @@ class RepaintRunner:
             timesteps, sigma_min, sigma_max, rho, S_churn, S_min, S_max, S_noise, w = STEPS, 0.002, 80.0, 7.0, 0.0, 0.0, float("inf"), 1.0, 0.0
             n_repeat, n_time_h, n_time_u = wl["n_repeat"], wl["n_time_h"], wl["n_time_u"]
         self.rd, self._keep = lib.repaint_desc(SP, steps, aext, 1, 1)
-        self.rep = torch.randn((STEPS, wl["n_repeat"] - 1, self.B, 2, self.H, self.W), dtype=torch.float64, device=device)
+        self.seed = torch.tensor([4242 + rank], dtype=torch.int64, device=device)
         self.ws = lib.Workspace()
         self.nfe = STEPS * wl["n_repeat"] * 2 - wl["n_repeat"]
-        self.graph = None
+        self.graph, self.capture_s, self.calls = None, None, 0
+        if use_graph:
+            t0 = time.perf_counter()
+            self.graph = lib.GraphedRepaint(self.plan, self.packed, self.rd, self._keep, self.B, True, ws=self.ws)
+            torch.cuda.synchronize()
+            self.capture_s = time.perf_counter() - t0          # one warm-up call + capture + instantiation
 
     def step(self):
+        self.calls += 1
+        if self.graph is not None:
+            return self.graph(self.hu, self.init, 4242 + self.calls)       # fresh noise every call
         return self.eager()
 
     def eager(self):
-        return self.plan.repaint_sample(self.packed, self.rd, self.hu, self.init, None, self.rep, return_last=True, ws=self.ws)
+        return self.plan.repaint_sample(self.packed, self.rd, self.hu, self.init, return_last=True, ws=self.ws, rng_seed=self.seed)
 
     profile = Runner.profile
 
@@ -374,7 +384,7 @@ def main():
     from mcedm_amd import lib
 
     repaint = args.workload == "repaint128"
-    run = RepaintRunner(args.batch, device, rank) if repaint else Runner(args.workload, args.batch, device, rank, not args.no_graph)
+    run = RepaintRunner(args.batch, device, rank, not args.no_graph) if repaint else Runner(args.workload, args.batch, device, rank, not args.no_graph)
     wl, B, H, W = run.wl, run.B, run.H, run.W
     if repaint:
         args.no_train = True
@@ -435,10 +445,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "states_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
                    "sampler": (f"EDM Heun + RePaint, 18 steps x {wl['n_repeat']} resampling loops, {run.nfe} NFE/state, S_churn=0, "
-                               "fp64 state / fp32 net") if repaint else
+                               "re-noising draws generated on the device (Philox), fp64 state / fp32 net") if repaint else
                               "EDM Heun, 18 steps, 35 NFE/state, S_churn=0, w=0, fp64 state / fp32 net",
                    "parallelism": f"batch-sharded x{world}, no data-path collective",
-                   "launch": "eager" if (args.no_graph or repaint) else "one HIP graph per sampler call"},
+                   "launch": "eager" if args.no_graph else "one HIP graph per sampler call"},
         "timed_with_profiler": False, "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B, "train_step_ms": train_ms,
         "train_samples_per_sec": (B * world / (train_ms * 1e-3)) if train_ms else None,
         "roofline": roofline_of(prof), "kernels": kernel_table(prof)[:8], "csrc_digest": csrc_digest(),
@@ -472,16 +482,30 @@ def main():
             del r2
             torch.cuda.empty_cache()
 
-        # BASELINE config 5 (RePaint on the DDPM U-Net): one call of 8 states = 8960 U-Net evaluations
-        r5 = RepaintRunner(8, device, 0)
-        t5 = time.perf_counter()
-        r5.step()
+        # BASELINE config 5 (RePaint on the DDPM U-Net): 32 states per call = 35 840 U-Net evaluations, graph-replayed,
+        # 1 warm-up + 2 timed calls, then one eager call with event pairs for its own roofline
+        r5 = RepaintRunner(0, device, 0, not args.no_graph)
+        o5 = r5.step()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t5
+        n5 = 2
+        t5 = time.perf_counter()
+        for _ in range(n5):
+            o5 = r5.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t5) / n5
+        assert torch.isfinite(o5).all()
+        p5 = r5.profile(1)
+        ro = roofline_of(p5)
         line["secondary"]["repaint128"] = {"workload": r5.wl["name"], "states_per_gpu": r5.B, "value": r5.B / dt, "unit": "states/s",
-                                           "ms_per_step": dt * 1e3, "steps": 1, "nfe_per_state": r5.nfe,
+                                           "ms_per_step": dt * 1e3, "steps": n5, "warmup": 1, "nfe_per_state": r5.nfe,
                                            "unet_evals_per_s": r5.B * r5.nfe / dt, "unet_fwd_ms": r5.fwd_ms(),
-                                           "note": "one un-warmed eager call (includes first-launch overheads)"}
+                                           "launch": "eager" if args.no_graph else "one HIP graph per call",
+                                           "graph_capture_s": r5.capture_s,
+                                           "fp32_frac_whole_sampler": sum(r["flops"] for r in p5) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                           "gflop_per_unet_eval_per_state": sum(r["flops"] for r in p5) / (r5.B * r5.nfe) / 1e9,
+                                           "dominant_kernel": ro["kernel"], "dominant_kernel_tflops": ro["achieved"],
+                                           "dominant_kernel_frac": ro["frac"], "dominant_kernel_share": ro["share_of_kernel_time"],
+                                           "kernels": kernel_table(p5)[:6]}
         del r5
         torch.cuda.empty_cache()
 

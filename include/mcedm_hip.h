@@ -350,6 +350,17 @@ int mcedm_repaint_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* by
 int mcedm_repaint_sample(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_repaint_desc* sp, const float* hu,
                          const float* init_noise, const double* step_noise, const double* repeat_noise, double* out,
                          int return_last, void* workspace, size_t workspace_bytes, int B, void* stream);
+/* The same sampler with the per-step and per-loop noise GENERATED ON THE DEVICE instead of read from tensors (the
+ * reference draws timesteps * n_repeat randn_like tensors per call, ddim.py:1004, 1037: 576 at BASELINE config 5):
+ * Philox4x32-10 keyed by the 64-bit seed at *rng_seed (DEVICE memory, read by the kernels when they run, so one captured
+ * HIP graph replays with fresh noise after the host rewrites the seed), counter = (element pair, draw index), Box-Muller
+ * on 53-bit uniforms.  Draw index of step i: i * n_repeat (the :1004 draw), i * n_repeat + 1 + k (the :1037 draw after
+ * inner loop k).  Statistically equivalent to, not the same stream as, torch.randn_like. */
+int mcedm_repaint_sample_rng(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_repaint_desc* sp, const float* hu,
+                             const float* init_noise, const uint64_t* rng_seed, double* out, int return_last,
+                             void* workspace, size_t workspace_bytes, int B, void* stream);
+/* out[0 .. n) = the N(0, 1) values of draw `draw` of that generator (fp64). */
+int mcedm_normal_fill(double* out, size_t n, const uint64_t* rng_seed, uint64_t draw, void* stream);
 
 /* ---- PDE residuals (forward) ----------------------------------------------
  * Replace the tensor-op bodies of models/pde_loss.py; results are bit-identical to the PyTorch CPU path.

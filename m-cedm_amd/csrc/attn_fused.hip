@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void attn_block64_kernel(AttnBlockArgs a) {
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wpj[s], XN[(2 * s + lh) * T + 32 * wn + l31], acc[0][0], 0, 0, 0);
   ConvArgs p{};
   p.out = a.z; p.Cout = C; p.H = 8; p.W = 8; p.gsum = a.gsum;
-  if (a.gsum) conv_epilogue<AttnTile, true, true>(p, acc, n, 0, 0, 0, wm, wn, lane, red);
-  else conv_epilogue<AttnTile, true, false>(p, acc, n, 0, 0, 0, wm, wn, lane, red);
+  if (a.gsum) conv_epilogue<AttnTile, true, 4>(p, acc, n, 0, 0, 0, wm, wn, lane, red);
+  else conv_epilogue<AttnTile, true, 0>(p, acc, n, 0, 0, 0, wm, wn, lane, red);
   if (a.gsum) {
     __syncthreads();
     constexpr int NG = C / 4;

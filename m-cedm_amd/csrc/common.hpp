@@ -61,15 +61,16 @@ enum Resample { RS_NONE = 0, RS_UP = 1, RS_DOWN = 2, RS_S2 = 3 };
 // deviations from the TILE's own mean, so no large-mean cancellation ever happens in fp32; the consumer merges the
 // records in fp64 (Chan et al.), with the element count of a tile recomputed from this geometry.
 struct SumTiles {
-  int tiles = 0;     // records per sample and 4-channel block
+  int tiles = 0;     // records per sample and channel block
   int tiles_x = 0;   // tiles along W
   int ph = 0, pw = 0;
+  int rc = 4;        // channels per record: 4, or 2 where a consumer's GroupNorm has 2-channel groups (ConvArgs::gsum_rc)
 };
 __host__ __device__ static inline int sum_tile_count(const SumTiles& g, int t, int H, int W) {
   const int ty = t / g.tiles_x, tx = t - ty * g.tiles_x;
   const int h = H - ty * g.ph < g.ph ? H - ty * g.ph : g.ph;
   const int w = W - tx * g.pw < g.pw ? W - tx * g.pw : g.pw;
-  return 4 * h * w;
+  return g.rc * h * w;
 }
 
 // Arguments of the implicit-GEMM convolution (3x3 pad 1, or 1x1).
@@ -113,7 +114,8 @@ struct ConvArgs {
   float* gsum;       // optional [B][tiles][ceil(Cout/4)][2]: per output tile and 4-channel block, (sum, M2 about the
                      // tile mean) of the OUTPUT written by the epilogue (no atomics); feeds the next GroupNorm without
                      // a stats pass.  Must hold B * conv_max_tiles(H, W) * ceil(Cout/4) * 2 floats.
-  SumTiles* gsum_tiles;   // host out: the tiling the launcher used (rows of gsum per sample, tile shape)
+  int gsum_rc;       // channels per statistics record: 0 / 4 = quads; 2 = pairs (table holds ceil(Cout/2) records per tile)
+  SumTiles* gsum_tiles;   // host out: the tiling the launcher used (rows of gsum per sample, tile shape, record width)
   // gn_on: the kernel derives this sample's transform rows itself from the producers' per-tile (sum, sumsq) tables
   // (gn.suma / gn.sumb ...; gn.coef / gn.stats / gn.xa / gn.xb are not used), so no GroupNorm kernel runs at all
   // Optional second GEMM onto the same output tile: a 1x1 projection of another (un-transformed) tensor, folded into this

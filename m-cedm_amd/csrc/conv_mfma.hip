@@ -198,17 +198,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   }
   // ---- epilogue: store NCHW (+ the fused GroupNorm partial sums); bias and residual are already in acc
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
-  const bool full = (m0 + C::MT <= p.Cout);
   float* red = xl;            // the input tile is dead after the last chunk's closing barrier
-  if (wave < C::NWAVE) {
-    if (p.gsum) {
-      if (full) conv_epilogue<C, true, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else conv_epilogue<C, false, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-    } else {
-      if (full) conv_epilogue<C, true, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else conv_epilogue<C, false, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-    }
-  }
+  if (wave < C::NWAVE) conv_epilogue_any<C>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
   if (p.dbg && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     p.dbg[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -220,18 +211,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   }
   if (p.gsum) {               // wave-uniform: every wave of the workgroup reaches this barrier
     __syncthreads();
-    constexpr int NG = C::MT / 4;                 // 4-channel blocks of the tile
-    if (tid < NG) {
-      float sum, m2;
-      conv_stats_combine<C::WN>(red + tid * 3, NG * 3, sum, m2);
-      const int g = m0 / 4 + tid;
-      const int ngroups = (p.Cout + 3) / 4;
-      const int ntiles = tiles_x * tiles_y;
-      if (g < ngroups) {
-        float* row = p.gsum + (((size_t)n * ntiles + ty * tiles_x + tx) * ngroups + g) * 2;
-        row[0] = sum; row[1] = m2;
-      }
-    }
+    conv_stats_store<C, C::WN>(p, red, n, m0, ty * tiles_x + tx, tiles_x * tiles_y, tid);
   }
 }
 
@@ -379,12 +359,12 @@ __global__ __launch_bounds__(512, 1) void conv8_mfma_kernel(ConvArgs p, int tile
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
   const bool full = (m0 + C::MT <= p.Cout);
   float* red = lds8;          // every slab is dead after the last chunk's barrier
-  if (p.gsum) {
-    if (full) conv_epilogue<C, true, true>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
-    else conv_epilogue<C, false, true>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
+  if (p.gsum) {                // (the launcher refuses pair records for this kernel)
+    if (full) conv_epilogue<C, true, 4>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
+    else conv_epilogue<C, false, 4>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
   } else {
-    if (full) conv_epilogue<C, true, false>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
-    else conv_epilogue<C, false, false>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
+    if (full) conv_epilogue<C, true, 0>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
+    else conv_epilogue<C, false, 0>(p, acc, n, m0, y0, x0, 0, wn, lane, red);
   }
   if (p.dbg && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -694,7 +674,7 @@ static int launch_cfg(const ConvArgs& a_in, hipStream_t stream) {
     hipLaunchKernelGGL((conv_mfma_kernel<C, RS_DOWN>), dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, tiles_x, tiles_y,
                        mtiles, nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_mfma_kernel");
-  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
+  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW, a.gsum_rc == 2 ? 2 : 4};
   return MCEDM_OK;
 }
 
@@ -729,7 +709,7 @@ static int launch_cfg_s2(const ConvArgs& a_in, hipStream_t stream) {
   hipLaunchKernelGGL((conv_s2_mfma_kernel<C>), dim3((unsigned)blocks), dim3(256), rows_bytes, stream, a, tiles_x, tiles_y,
                      mtiles, nchunks, cout_padded(a.Cout));
   MCEDM_LAUNCH_CHECK("conv_s2_mfma_kernel");
-  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
+  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW, a.gsum_rc == 2 ? 2 : 4};
   return MCEDM_OK;
 }
 
@@ -879,7 +859,7 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
   if (a.W >= 24) {
     if (g_conv8 < 0) { const char* e = getenv("MCEDM_CONV8"); g_conv8 = e ? atoi(e) : 0; }
     // experimental 8-wave kernel (needs about one workgroup per CU); results are bit-identical to <128, 8, 32>
-    if (g_conv8 && !a.sk_wpk && TAPS == 9 && a.resample == RS_NONE && coutp % 128 == 0 && a.Ca + a.Cb <= 2048 &&
+    if (g_conv8 && !a.sk_wpk && a.gsum_rc != 2 && TAPS == 9 && a.resample == RS_NONE && coutp % 128 == 0 && a.Ca + a.Cb <= 2048 &&
         blocks_for(128, 16, 32) >= 224)
       return launch_conv8(a, stream);
     if (coutp % 128 == 0 && blocks_for(128, 8, 32) >= want) return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);

@@ -410,7 +410,6 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
 
   // ---- epilogue (as conv_mfma_kernel): store + fused GroupNorm statistics
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
-  const bool full = (m0 + C::MT <= p.Cout);
   float* red = wl;                                  // the slabs are dead after the last barrier
   if constexpr (C::KS > 1) {
     // the K groups' partial sums meet in LDS (the input tile is dead): groups 1 ... KS-1 store, group 0 adds them in order
@@ -438,15 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
       }
     }
   }
-  if (ks == 0) {
-    if (p.gsum) {
-      if (full) conv_epilogue<C, true, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else conv_epilogue<C, false, true>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-    } else {
-      if (full) conv_epilogue<C, true, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-      else conv_epilogue<C, false, false>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
-    }
-  }
+  if (ks == 0) conv_epilogue_any<C>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
   if (p.dbg && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     p.dbg[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -457,18 +448,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   }
   if (p.gsum) {
     __syncthreads();
-    constexpr int NG = C::MT / 4;
-    if (tid < NG) {
-      float sum, m2;
-      conv_stats_combine<C::WN>(red + tid * 3, NG * 3, sum, m2);
-      const int g = m0 / 4 + tid;
-      const int ngroups = (p.Cout + 3) / 4;
-      const int ntiles = tiles_x * tiles_y;
-      if (g < ngroups) {
-        float* row = p.gsum + (((size_t)n * ntiles + ty * tiles_x + tx) * ngroups + g) * 2;
-        row[0] = sum; row[1] = m2;
-      }
-    }
+    conv_stats_store<C, C::WN>(p, red, n, m0, ty * tiles_x + tx, tiles_x * tiles_y, tid);
   }
 }
 
@@ -556,7 +536,7 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
   hipLaunchKernelGGL((conv_resident_kernel<C, RS, SPLIT>), dim3((unsigned)blocks), dim3(256), (unsigned)plan.lds, stream, a, tiles_x,
                      tiles_y, mtiles, plan.pass_c, cout_padded(a.Cout), plan.nslab, plan.wide, SPLIT ? n_cu : 0);
   MCEDM_LAUNCH_CHECK("conv_resident_kernel");
-  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW};
+  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_x * tiles_y, tiles_x, C::PH, C::PW, a.gsum_rc == 2 ? 2 : 4};
   return MCEDM_OK;
 }
 

@@ -114,23 +114,23 @@ __device__ __forceinline__ void stage_coef_rows(const ConvArgs& p, int n, Coef* 
     const int gi = g0 + tid / lpg;
     const bool live = gi < G;
     const int c0 = live ? gi * cpg : 0;
-    const int nq = cpg / 4;          // the group = nq 4-channel blocks, each in xa's or xb's table (may straddle)
+    // the group = whole statistic records (4 or 2 channels each, SumTiles::rc), each in xa's or xb's table (may straddle).
     // Chan merge of the per-tile records (sum_t, M2_t about the tile mean), all in fp64:
     //   M2 = sum_t M2_t + sum_t s_t^2 / n_t - (sum_t s_t)^2 / N      (s_t are fp32 values: exact in fp64)
     double s1 = 0, sq = 0, mw = 0;
     const int Himg = g.HW / g.W;
-    for (int q = 0; q < (live ? nq : 0); ++q) {
-      const int cb = c0 + 4 * q;
+    for (int cb = c0; cb < (live ? c0 + cpg : c0);) {
       const bool in_a = cb < g.Ca;
       const float* sums = in_a ? g.suma : g.sumb;
       const SumTiles& tg = in_a ? g.ta : g.tb;
-      const int q4 = ((in_a ? g.Ca : g.Cb) + 3) / 4;
-      const int qi = (in_a ? cb : cb - g.Ca) / 4;
+      const int nrec = ((in_a ? g.Ca : g.Cb) + tg.rc - 1) / tg.rc;
+      const int qi = (in_a ? cb : cb - g.Ca) / tg.rc;
       for (int t = sub; t < tg.tiles; t += lpg) {
-        const float* row = sums + (((size_t)n * tg.tiles + t) * q4 + qi) * 2;
+        const float* row = sums + (((size_t)n * tg.tiles + t) * nrec + qi) * 2;
         const double st = (double)row[0];
         s1 += st; sq += st * st / (double)sum_tile_count(tg, t, Himg, g.W); mw += (double)row[1];
       }
+      cb += tg.rc;
     }
     for (int off = lpg >> 1; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); sq += __shfl_xor(sq, off); mw += __shfl_xor(mw, off); }
     if (live) {
@@ -349,18 +349,25 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[C
 }
 
 // FULL: every output channel of the tile exists (m0 + MT <= Cout).  Store-only: nothing here waits on memory.
-// STATS: fused GroupNorm statistics of what is stored.  Per wave and 4-channel block a record (count, sum, M2) with
+// STATS (0 / 4 / 2): fused GroupNorm statistics of what is stored, one record per wave and STATS-channel block (4: the
+// four accumulator registers of a lane that are consecutive channels; 2: their two halves -- GroupNorm(32) over 64
+// channels has 2-channel groups, models/ddim_blocks.py:62-63).  A record is (count, sum, M2) with
 // M2 = sum (v - wave mean)^2: two passes over the accumulator registers, so a large mean never cancels in fp32
 // (E[x^2] - E[x]^2 on fp32 partial sums loses rstd at |mean|/std ~ 30).  Records go to the LDS slot of the wave
 // (3 floats per block); conv_stats_combine merges the waves of the tile in a fixed order.
-template <class C, bool FULL, bool STATS>
+template <class C, bool FULL, int STATS>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C::TM][C::TN], int n, int m0, int y0,
                                               int x0, int wm, int wn, int lane, float* red) {
+  static_assert(STATS == 0 || STATS == 4 || STATS == 2, "record width");
+  constexpr int NR = STATS == 2 ? 8 : 4;            // records per lane: register r belongs to record r / STATS
+  constexpr int RSH = STATS == 2 ? 1 : 2;
   const size_t HW = (size_t)p.H * p.W;
 #pragma unroll
   for (int i = 0; i < C::TM; ++i) {
     const int cbase = m0 + (wm * C::TM + i) * 32 + 4 * (lane >> 5);     // + (r&3) + 8*(r>>2)
-    float gs1[4] = {0.f, 0.f, 0.f, 0.f}, cnt[4] = {0.f, 0.f, 0.f, 0.f};
+    float gs1[NR], cnt[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) { gs1[q] = 0.f; cnt[q] = 0.f; }
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
       const int pix = (wn * C::TN + j) * 32 + (lane & 31);
@@ -373,21 +380,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
           const float v = acc[i][j][r];
           if (FULL || co < p.Cout) {
             p.out[((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x] = v;
-            if (STATS) { gs1[r >> 2] += v; cnt[r >> 2] += 1.f; }
+            if (STATS) { gs1[r >> RSH] += v; cnt[r >> RSH] += 1.f; }
           }
         }
       }
     }
     if (STATS) {
-      // 4-channel block inside the MT tile: gl = 8 (wm TM + i) + 2 (r>>2) + (lane>>5); pixels = the 32-lane half.
-      float mean[4];
+      // block inside the MT tile: quads gl = 8 (wm TM + i) + 2 (r>>2) + (lane>>5), pairs 2 gl + ((r>>1)&1);
+      // pixels = the 32-lane half.
+      float mean[NR];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NR; ++q) {
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) { gs1[q] += __shfl_xor(gs1[q], off); cnt[q] += __shfl_xor(cnt[q], off); }
         mean[q] = cnt[q] > 0.f ? gs1[q] / cnt[q] : 0.f;
       }
-      float gm2[4] = {0.f, 0.f, 0.f, 0.f};
+      float gm2[NR];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) gm2[q] = 0.f;
 #pragma unroll
       for (int j = 0; j < C::TN; ++j) {
         const int pix = (wn * C::TN + j) * 32 + (lane & 31);
@@ -397,24 +407,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = cbase + (r & 3) + 8 * (r >> 2);
-            if (FULL || co < p.Cout) { const float d = acc[i][j][r] - mean[r >> 2]; gm2[r >> 2] = fmaf(d, d, gm2[r >> 2]); }
+            if (FULL || co < p.Cout) { const float d = acc[i][j][r] - mean[r >> RSH]; gm2[r >> RSH] = fmaf(d, d, gm2[r >> RSH]); }
           }
         }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NR; ++q) {
         float b = gm2[q];
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) b += __shfl_xor(b, off);
         if ((lane & 31) == 0) {
-          const int gl = (wm * C::TM + i) * 8 + 2 * q + (lane >> 5);
-          float* slot = red + (wn * (C::MT / 4) + gl) * 3;
+          const int quad = (wm * C::TM + i) * 8 + 2 * (STATS == 2 ? q >> 1 : q) + (lane >> 5);
+          const int gl = STATS == 2 ? 2 * quad + (q & 1) : quad;
+          float* slot = red + (wn * (C::MT / (STATS ? STATS : 4)) + gl) * 3;
           slot[0] = cnt[q]; slot[1] = gs1[q]; slot[2] = b;
         }
       }
     }
   }
 }
+
+// The epilogue for the statistics mode a launch asks for (ConvArgs::gsum / gsum_rc); wave-uniform dispatch.
+template <class C>
+__device__ __forceinline__ void conv_epilogue_any(const ConvArgs& p, f32x16 (&acc)[C::TM][C::TN], int n, int m0, int y0,
+                                                  int x0, int wm, int wn, int lane, float* red) {
+  const bool full = (m0 + C::MT <= p.Cout);
+  if (!p.gsum) {
+    if (full) conv_epilogue<C, true, 0>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+    else conv_epilogue<C, false, 0>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+  } else if (p.gsum_rc == 2) {
+    if (full) conv_epilogue<C, true, 2>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+    else conv_epilogue<C, false, 2>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+  } else {
+    if (full) conv_epilogue<C, true, 4>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+    else conv_epilogue<C, false, 4>(p, acc, n, m0, y0, x0, wm, wn, lane, red);
+  }
+}
+
+// After conv_epilogue_any and a workgroup barrier: merge the NW waves' records of every block of the tile (fixed order)
+// and store them as row (sample n, tile `tile` of `ntiles`) of the table.
+template <class C, int NW>
+__device__ __forceinline__ void conv_stats_store(const ConvArgs& p, const float* red, int n, int m0, int tile, int ntiles,
+                                                 int tid);
 
 // Merge NW per-wave records (count, sum, M2) of one 4-channel block in a fixed order (bitwise reproducible):
 // M2 = sum_w [M2_w + n_w (mean_w - mean)^2].  Returns (sum, M2).
@@ -432,6 +466,23 @@ __device__ __forceinline__ void conv_stats_combine(const float* red, int stride_
     m2 += red[w * stride_w + 2] + nw * d * d;
   }
   sum_out = st; m2_out = m2;
+}
+
+template <class C, int NW>
+__device__ __forceinline__ void conv_stats_store(const ConvArgs& p, const float* red, int n, int m0, int tile, int ntiles,
+                                                 int tid) {
+  const int rc = p.gsum_rc == 2 ? 2 : 4;
+  const int NG = C::MT / rc;                      // records of the tile
+  for (int e = tid; e < NG; e += C::NT) {
+    float sum, m2;
+    conv_stats_combine<NW>(red + e * 3, NG * 3, sum, m2);
+    const int g = m0 / rc + e;
+    const int ngroups = (p.Cout + rc - 1) / rc;
+    if (g < ngroups) {
+      float* row = p.gsum + (((size_t)n * ntiles + tile) * ngroups + g) * 2;
+      row[0] = sum; row[1] = m2;
+    }
+  }
 }
 
 // One K chunk (KC input channels x all taps) of the implicit GEMM out of the LDS slabs.

@@ -394,7 +394,15 @@ __global__ __launch_bounds__(256) void ddpm_temb_kernel(float t, int ch, const f
 // ------------------------------------------------------------------------------------------
 // forward schedule, written once and run twice: `dry` (sizes only) and for real
 // ------------------------------------------------------------------------------------------
-struct DT { int C = 0, H = 0, W = 0; size_t off = NONE, bytes = 0, sums = NONE, sums_bytes = 0; SumTiles st; };
+struct DT { int C = 0, H = 0, W = 0; size_t off = NONE, bytes = 0, sums = NONE, sums_bytes = 0; SumTiles st; int rc = 0; };
+
+// Channels per fused-statistics record of a C-channel tensor: GroupNorm(32) consumes it alone with C / 32 channels per
+// group (2 at C = 64: pair records; multiples of 4: quad records) or inside a concat whose groups are unions of those.
+// 0: no fused statistics for this width (a gn_coef_kernel pass instead).
+static int record_width(int C) {
+  const int cpg = C / 32;
+  return (C % 32) ? 0 : (cpg % 4 == 0) ? 4 : (cpg % 2 == 0) ? 2 : 0;
+}
 
 struct DExec {
   const mcedm_ddpm_plan& P;
@@ -410,8 +418,9 @@ struct DExec {
     DT d; d.C = C; d.H = H; d.W = W;
     d.bytes = (size_t)B * C * H * W * sizeof(float);
     d.off = pool.alloc(d.bytes);
-    if (with_sums) {
-      d.sums_bytes = (size_t)B * conv_max_tiles(H, W) * ceil_div(C, 4) * 2 * sizeof(float);
+    d.rc = with_sums ? record_width(C) : 0;
+    if (d.rc) {
+      d.sums_bytes = (size_t)B * conv_max_tiles(H, W) * ceil_div(C, d.rc) * 2 * sizeof(float);
       d.sums = pool.alloc(d.sums_bytes);
     }
     t.push_back(d);
@@ -427,8 +436,9 @@ struct DExec {
   float* sums(int id) const { return (id < 0 || t[id].sums == NONE) ? nullptr : reinterpret_cast<float*>(base + t[id].sums); }
 };
 
-// conv `c` reads swish(GroupNorm(cat(xa, xb))): fused from the producers' statistics records when the 32 groups are
-// whole 4-channel blocks, else one pass of gn_coef_kernel into a table (returned id, to be released after the conv)
+// conv `c` reads swish(GroupNorm(cat(xa, xb))): fused from the producers' statistics records when every group is a
+// whole number of records of each source (pair records on the 64-channel tensors, quads on wider ones), else one pass
+// of gn_coef_kernel into a table (returned id, to be released after the conv)
 static int gn_into(DExec& E, const DNorm& n, int xa, int xb, ConvArgs& c, int* table_id) {
   const DT& A = E.t[xa];
   const int Ca = A.C, Cb = xb >= 0 ? E.t[xb].C : 0;
@@ -436,7 +446,8 @@ static int gn_into(DExec& E, const DNorm& n, int xa, int xb, ConvArgs& c, int* t
            nullptr, nullptr, E.sums(xa), E.sums(xb), A.st, xb >= 0 ? E.t[xb].st : SumTiles{}, A.W};
   *table_id = -1;
   c.act = 1; c.coef_batch = 1;
-  const bool usable = (Ca + Cb) % 128 == 0 && Ca % 4 == 0 && g.suma != nullptr && (Cb == 0 || g.sumb != nullptr);
+  const int cpg = (Ca + Cb) / 32, ra = A.rc, rb = xb >= 0 ? E.t[xb].rc : A.rc;
+  const bool usable = (Ca + Cb) % 32 == 0 && ra > 0 && rb > 0 && cpg % ra == 0 && cpg % rb == 0 && Ca % ra == 0 && Ca % rb == 0;
   if (usable) {
     if (!E.dry && !gn_sums_usable(g)) { set_error("ddpm forward: statistics table of a %d-channel input is unusable", Ca + Cb); return MCEDM_ERR_INVALID; }
     c.gn = g; c.gn_on = 1; c.coef = nullptr;
@@ -456,12 +467,12 @@ static void src_of(const DExec& E, ConvArgs& c, int xa, int xb) {
 static void dst_of(DExec& E, ConvArgs& c, int out, const DConv& cv, const float* bias, bool stats) {
   c.wpk = E.pk + cv.wpk; c.bias = bias ? bias : E.pk + cv.bias;
   c.out = E.ptr(out); c.Cout = cv.cout; c.B = E.B;
-  if (stats) { c.gsum = E.sums(out); c.gsum_tiles = &E.t[out].st; }
+  if (stats && E.t[out].rc) { c.gsum = E.sums(out); c.gsum_rc = E.t[out].rc; c.gsum_tiles = &E.t[out].st; }
 }
 // the tiling a launch WOULD use must be known in the dry run too (the consumer's usability test reads st.tiles):
 // the real launch overwrites it with the same values
 static int run_conv(DExec& E, ConvArgs& c, int taps, int out) {
-  if (E.dry) { if (c.gsum_tiles) *c.gsum_tiles = SumTiles{1, 1, 8, 8}; (void)out; return MCEDM_OK; }
+  if (E.dry) { if (c.gsum_tiles) *c.gsum_tiles = SumTiles{1, 1, 8, 8, c.gsum_rc == 2 ? 2 : 4}; (void)out; return MCEDM_OK; }
   return launch_conv(c, taps, E.s);
 }
 
@@ -476,24 +487,24 @@ static int res_block(DExec& E, const DRes& r, int xa, int xb, const float* bias_
   dst_of(E, c1, h, r.c1, bias_table + r.brow, true);          // bias = conv1.bias + temb_proj(swish(temb))
   if ((rc = run_conv(E, c1, 9, h))) return rc;
   E.release(tab);
-  int res = xa;
-  if (r.has_sc) {
-    res = E.act(r.cout, H, W, false);
-    ConvArgs cs{};
-    src_of(E, cs, xa, xb);
-    dst_of(E, cs, res, r.sc, nullptr, false);
-    if ((rc = run_conv(E, cs, 1, res))) return rc;
-  }
+  // y = conv2(swish(norm2(h))) + (nin_shortcut(x) | x).  The 1x1 shortcut is a GEMM onto conv2's output tile, so it rides on
+  // conv2 as extra K chunks at the centre tap (ConvArgs::sk_*, as the ADM decoder's skip projection does): the projected
+  // tensor is neither written nor read back, one launch less per block
   const int y = E.act(r.cout, H, W, true);
   ConvArgs c2{};
   src_of(E, c2, h, -1);
   if ((rc = gn_into(E, r.n2, h, -1, c2, &tab))) return rc;
   dst_of(E, c2, y, r.c2, nullptr, true);
-  c2.res = E.ptr(res); c2.res_mode = RS_NONE;
+  if (r.has_sc) {
+    c2.sk_xa = E.ptr(xa); c2.sk_Ca = E.t[xa].C;
+    c2.sk_xb = E.ptr(xb); c2.sk_Cb = xb >= 0 ? E.t[xb].C : 0;
+    c2.sk_wpk = E.pk + r.sc.wpk; c2.sk_bias = E.pk + r.sc.bias;
+  } else {
+    c2.res = E.ptr(xa); c2.res_mode = RS_NONE;
+  }
   if ((rc = run_conv(E, c2, 9, y))) return rc;
   E.release(tab);
   E.release(h);
-  if (r.has_sc) E.release(res);
   *out_id = y;
   return MCEDM_OK;
 }
@@ -745,10 +756,36 @@ extern "C" int mcedm_repaint_schedule(const mcedm_repaint_desc* sp, double* t_st
   return MCEDM_OK;
 }
 
+namespace mcedm {
+static int repaint_impl(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_repaint_desc* sp, const float* hu,
+                        const float* init_noise, const double* step_noise, const double* repeat_noise,
+                        const unsigned long long* rng_seed, double* out, int return_last, void* workspace,
+                        size_t workspace_bytes, int B, void* stream);
+}
 extern "C" int mcedm_repaint_sample(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_repaint_desc* sp,
                                     const float* hu, const float* init_noise, const double* step_noise,
                                     const double* repeat_noise, double* out, int return_last, void* workspace,
                                     size_t workspace_bytes, int B, void* stream) {
+  return repaint_impl(plan, packed, sp, hu, init_noise, step_noise, repeat_noise, nullptr, out, return_last, workspace,
+                      workspace_bytes, B, stream);
+}
+extern "C" int mcedm_repaint_sample_rng(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_repaint_desc* sp,
+                                        const float* hu, const float* init_noise, const uint64_t* rng_seed, double* out,
+                                        int return_last, void* workspace, size_t workspace_bytes, int B, void* stream) {
+  MCEDM_REQUIRE(rng_seed != nullptr, "repaint_sample_rng: rng_seed is null");
+  return repaint_impl(plan, packed, sp, hu, init_noise, nullptr, nullptr, reinterpret_cast<const unsigned long long*>(rng_seed),
+                      out, return_last, workspace, workspace_bytes, B, stream);
+}
+extern "C" int mcedm_normal_fill(double* out, size_t n, const uint64_t* rng_seed, uint64_t draw, void* stream) {
+  MCEDM_REQUIRE(out && rng_seed, "normal_fill: null argument");
+  if (n == 0) return MCEDM_OK;
+  return launch_normal_fill(out, reinterpret_cast<const unsigned long long*>(rng_seed), draw, n, (hipStream_t)stream);
+}
+
+static int mcedm::repaint_impl(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_repaint_desc* sp, const float* hu,
+                               const float* init_noise, const double* step_noise, const double* repeat_noise,
+                               const unsigned long long* rng_seed, double* out, int return_last, void* workspace,
+                               size_t workspace_bytes, int B, void* stream) {
   MCEDM_REQUIRE(plan && packed && sp && hu && init_noise && out && workspace, "repaint_sample: null argument");
   const mcedm_ddpm_plan& P = *plan;
   MCEDM_REQUIRE(P.desc.in_channels == P.desc.out_channels, "repaint_sample: in_channels != out_channels");
@@ -756,7 +793,7 @@ extern "C" int mcedm_repaint_sample(const mcedm_ddpm_plan* plan, const void* pac
   MCEDM_REQUIRE(sp->timesteps >= 2 && sp->timesteps <= 4096 && sp->n_repeat >= 1, "repaint_sample: timesteps=%d n_repeat=%d out of range", sp->timesteps, sp->n_repeat);
   MCEDM_REQUIRE(sp->h_ch >= 0 && sp->u_ch >= 0 && sp->h_ch + sp->u_ch <= P.desc.in_channels, "repaint_sample: h_ch + u_ch exceeds the state channels");
   MCEDM_REQUIRE(std::fabs(sp->w) < 0.001, "repaint_sample: classifier-free guidance needs a conditional network (cond is None on this path, ddim.py:935)");
-  MCEDM_REQUIRE(sp->n_repeat == 1 || repeat_noise != nullptr, "repaint_sample: n_repeat > 1 needs repeat_noise");
+  MCEDM_REQUIRE(sp->n_repeat == 1 || repeat_noise != nullptr || rng_seed != nullptr, "repaint_sample: n_repeat > 1 needs repeat_noise");
   const int N = sp->timesteps, R = sp->n_repeat, n = sp->num_diffusion_timesteps;
   const int S = P.desc.resolution, C = P.desc.in_channels;
   std::vector<double> t(N + 1);
@@ -810,8 +847,12 @@ extern "C" int mcedm_repaint_sample(const mcedm_ddpm_plan* plan, const void* pac
     {
       const double c = std::sqrt(t_hat * t_hat - t_cur * t_cur) * sp->S_noise;          // ddim.py:1004
       if (c != 0.0) {
-        MCEDM_REQUIRE(step_noise != nullptr, "repaint_sample: step %d adds noise (t_hat > t_cur) but step_noise is NULL", i);
-        if ((rc = launch_heun_churn(x, step_noise + (size_t)i * total, nullptr, c, total, x32, s))) return rc;
+        if (rng_seed) {
+          if ((rc = launch_heun_churn_rng(x, rng_seed, (unsigned long long)i * R, c, total, x32, s))) return rc;
+        } else {
+          MCEDM_REQUIRE(step_noise != nullptr, "repaint_sample: step %d adds noise (t_hat > t_cur) but step_noise is NULL", i);
+          if ((rc = launch_heun_churn(x, step_noise + (size_t)i * total, nullptr, c, total, x32, s))) return rc;
+        }
       }
     }
     for (int k = 0; k < R; ++k) {
@@ -829,7 +870,9 @@ extern "C" int mcedm_repaint_sample(const mcedm_ddpm_plan* plan, const void* pac
       if (k < R - 1) {                                                                   // back up from t_next to a new t_hat (:1033-1037)
         t_hat = round_sigma(t_next + (std::sqrt(2.0) - 1.0) * t_next);
         const double c = std::sqrt(t_hat * t_hat - t_next * t_next) * sp->S_noise;
-        if ((rc = launch_heun_churn(x, repeat_noise + ((size_t)i * (R - 1) + k) * total, nullptr, c, total, x32, s))) return rc;
+        if (rng_seed) rc = launch_heun_churn_rng(x, rng_seed, (unsigned long long)i * R + 1 + k, c, total, x32, s);
+        else rc = launch_heun_churn(x, repeat_noise + ((size_t)i * (R - 1) + k) * total, nullptr, c, total, x32, s);
+        if (rc) return rc;
       }
     }
     if (i == N - 1 && (rc = launch_repaint_known(x, hu, init_noise, mask, 0.f, 0.f, 1, total, x32, s))) return rc;   // :1041-1043

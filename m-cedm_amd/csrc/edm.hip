@@ -174,6 +174,71 @@ int launch_heun_store(const double* x, int C, size_t hw, int t, int T, size_t to
   return MCEDM_OK;
 }
 
+// ---- counter-based normal noise on the device (Philox4x32-10, Salmon et al. 2011) -----------------------------------
+// The reference draws one randn_like tensor per Heun step and per resampling loop (models/ddim.py:1004, 1037); at
+// BASELINE config 5 (18 steps x 32 loops) that is 576 fp64 tensors per call.  Instead of materialising them, the
+// re-noising kernel generates its own: counter = (element pair index, draw index), key = a 64-bit seed read from DEVICE
+// memory (so a captured HIP graph replays with fresh noise after the host bumps the seed).  Statistically equivalent to,
+// but not the same stream as, torch's generator.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+// two independent N(0, 1) doubles from 128 random bits (Box-Muller on 53-bit uniforms; u1 in (0, 1])
+__device__ __forceinline__ void normal_pair(const unsigned (&c)[4], double& z0, double& z1) {
+  const double u1 = ((double)((((unsigned long long)c[0] << 32) | c[1]) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+  const double u2 = (double)((((unsigned long long)c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0);
+  const double r = sqrt(-2.0 * log(u1));
+  double sn, cs;
+  sincos(6.283185307179586476925 * u2, &sn, &cs);
+  z0 = r * cs; z1 = r * sn;
+}
+__global__ void heun_churn_rng_kernel(double* __restrict__ x, const unsigned long long* __restrict__ seed_dev,
+                                      unsigned long long draw, double c, size_t total, float* __restrict__ x32) {
+  const unsigned long long seed = *seed_dev;
+  const size_t pairs = (total + 1) / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned ctr[4] = {(unsigned)i, (unsigned)((unsigned long long)i >> 32), (unsigned)draw, (unsigned)(draw >> 32)};
+    philox4x32_10(ctr, (unsigned)seed, (unsigned)(seed >> 32));
+    double z0, z1;
+    normal_pair(ctr, z0, z1);
+    const double v0 = x[2 * i] + c * z0;
+    x[2 * i] = v0; x32[2 * i] = (float)v0;
+    if (2 * i + 1 < total) { const double v1 = x[2 * i + 1] + c * z1; x[2 * i + 1] = v1; x32[2 * i + 1] = (float)v1; }
+  }
+}
+int launch_heun_churn_rng(double* x, const unsigned long long* seed_dev, unsigned long long draw, double c, size_t total, float* x32,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(heun_churn_rng_kernel, dim3(grid_for((total + 1) / 2)), dim3(256), 0, s, x, seed_dev, draw, c, total, x32);
+  MCEDM_LAUNCH_CHECK("heun_churn_rng_kernel");
+  return MCEDM_OK;
+}
+// out[i] = N(0, 1) of draw `draw` (the generator on its own: tests, and callers that want the tensor)
+__global__ void normal_fill_kernel(double* __restrict__ out, const unsigned long long* __restrict__ seed_dev, unsigned long long draw,
+                                   size_t total) {
+  const unsigned long long seed = *seed_dev;
+  const size_t pairs = (total + 1) / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned ctr[4] = {(unsigned)i, (unsigned)((unsigned long long)i >> 32), (unsigned)draw, (unsigned)(draw >> 32)};
+    philox4x32_10(ctr, (unsigned)seed, (unsigned)(seed >> 32));
+    double z0, z1;
+    normal_pair(ctr, z0, z1);
+    out[2 * i] = z0;
+    if (2 * i + 1 < total) out[2 * i + 1] = z1;
+  }
+}
+int launch_normal_fill(double* out, const unsigned long long* seed_dev, unsigned long long draw, size_t total, hipStream_t s) {
+  hipLaunchKernelGGL(normal_fill_kernel, dim3(grid_for((total + 1) / 2)), dim3(256), 0, s, out, seed_dev, draw, total);
+  MCEDM_LAUNCH_CHECK("normal_fill_kernel");
+  return MCEDM_OK;
+}
+
 // ---- RePaint-style EDM sampling on the DDPM U-Net (PlDdim, models/ddim.py:915-1051) -------------------------------
 __global__ void vp_finish_kernel(const float* __restrict__ x, const float* __restrict__ F, float c_out, size_t total,
                                  float* __restrict__ D) {

@@ -110,24 +110,23 @@ __global__ __launch_bounds__(256) void gn_coef_from_sums_kernel(GnArgs a) {
   const int n = pair / a.groups, g = pair - n * a.groups;
   const int cpg = C / a.groups;
   const int c0 = g * cpg;
-  // the group is a run of 4-channel blocks; each block lives in xa's or xb's table (a group may straddle the
-  // concat boundary: Ca is a multiple of 4, see gn_sums_usable)
-  const int nq = cpg / 4;
-  // Chan merge of the per-tile records (sum_t, M2_t about the tile mean) in fp64, as in conv_mfma.hip stage_coef_rows
+  // the group is a run of statistic records (4 or 2 channels each, SumTiles::rc); each lives in xa's or xb's table (a
+  // group may straddle the concat boundary, see gn_sums_usable).
+  // Chan merge of the per-tile records (sum_t, M2_t about the tile mean) in fp64, as in conv_tile.hpp stage_coef_rows
   double s1 = 0, sq = 0, mw = 0;
   const int Himg = a.HW / a.W;
-  for (int q = 0; q < nq; ++q) {
-    const int cb = c0 + 4 * q;
+  for (int cb = c0; cb < c0 + cpg;) {
     const bool in_a = cb < a.Ca;
     const float* sums = in_a ? a.suma : a.sumb;
     const SumTiles& tg = in_a ? a.ta : a.tb;
-    const int q4 = ((in_a ? a.Ca : a.Cb) + 3) / 4;
-    const int qi = (in_a ? cb : cb - a.Ca) / 4;
+    const int nrec = ((in_a ? a.Ca : a.Cb) + tg.rc - 1) / tg.rc;
+    const int qi = (in_a ? cb : cb - a.Ca) / tg.rc;
     for (int t = lane; t < tg.tiles; t += 64) {
-      const float* row = sums + (((size_t)n * tg.tiles + t) * q4 + qi) * 2;
+      const float* row = sums + (((size_t)n * tg.tiles + t) * nrec + qi) * 2;
       const double st = (double)row[0];
       s1 += st; sq += st * st / (double)sum_tile_count(tg, t, Himg, a.W); mw += (double)row[1];
     }
+    cb += tg.rc;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); sq += __shfl_xor(sq, off); mw += __shfl_xor(mw, off); }
@@ -159,8 +158,13 @@ bool gn_sums_usable(const GnArgs& a) {
   const int C = a.Ca + a.Cb;
   if (a.groups <= 0 || C % a.groups != 0) return false;
   const int cpg = C / a.groups;
-  return cpg % 4 == 0 && a.Ca % 4 == 0 && a.suma != nullptr && (a.Cb == 0 || a.sumb != nullptr) && a.W > 0 &&
-         a.HW % a.W == 0 && a.ta.tiles > 0 && (a.Cb == 0 || a.tb.tiles > 0);
+  if (a.suma == nullptr || (a.Cb != 0 && a.sumb == nullptr) || a.W <= 0 || a.HW % a.W != 0 || a.ta.tiles <= 0 ||
+      (a.Cb != 0 && a.tb.tiles <= 0))
+    return false;
+  // every group must be a whole number of records of each source it touches, and records must not straddle the sources
+  const int ra = a.ta.rc, rb = a.Cb ? a.tb.rc : ra;
+  if ((ra != 2 && ra != 4) || (rb != 2 && rb != 4)) return false;
+  return cpg % ra == 0 && cpg % rb == 0 && a.Ca % ra == 0 && a.Ca % rb == 0;
 }
 
 int launch_gn_coef_from_sums(const GnArgs& a, hipStream_t stream) {

@@ -18,6 +18,7 @@ the hot path and raise.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -518,7 +519,12 @@ class PlDdim(_EvalMetrics, _Base):
     def sample_edm(self, h, u, sparams, return_last=True, guide_dx=False):
         """models/ddim.py:959-1051.  h, u: 'b h w c' normalised fields; returns [b, t, h, w, c] float64.
         The known region is rows < n_time_h of h and rows < n_time_u of u; every step runs n_repeat Heun updates with the
-        known region re-noised to the current level in between (RePaint)."""
+        known region re-noised to the current level in between (RePaint).
+
+        Noise: the initial ``randn_like(hu)`` is torch's; the per-step and per-loop draws (timesteps * n_repeat tensors in the
+        reference, :1004 / :1037) are generated INSIDE the re-noising kernels from a 64-bit seed drawn from torch's generator
+        (``self.noise_source = "device"``, the default: no noise tensors exist and the call replays from one HIP graph), or
+        drawn with torch.randn into two tensors (``"torch"``: what the golden tests inject into)."""
         if guide_dx:
             raise NotImplementedError("guide_dx=True (PDE guidance) is outside the built path")
         if self.edm_steps is None:
@@ -528,14 +534,26 @@ class PlDdim(_EvalMetrics, _Base):
         rd, keep = _lib.repaint_desc(sparams, self.edm_steps, self._alphas_ext(), self.h_ch, self.u_ch)
         hu_noise = torch.randn_like(hu)
         N, R = rd.timesteps, rd.n_repeat
-        t = _lib.repaint_schedule(rd)
-        # the reference draws a per-step tensor every step; it only matters where round_sigma(t_cur + gamma t_cur) > t_cur
-        churn = float(sparams.S_churn) > 0
-        step_noise = torch.randn((N,) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if churn else None
-        repeat_noise = torch.randn((N, R - 1) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if R > 1 else None
+        packed = net.packed_weights()
         with torch.no_grad():
-            return net.plan.repaint_sample(net.packed_weights(), rd, hu, hu_noise, step_noise, repeat_noise,
-                                           return_last=return_last, ws=self._sample_ws)
+            if getattr(self, "noise_source", "device") == "torch":
+                churn = float(sparams.S_churn) > 0
+                step_noise = torch.randn((N,) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if churn else None
+                repeat_noise = torch.randn((N, R - 1) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if R > 1 else None
+                return net.plan.repaint_sample(packed, rd, hu, hu_noise, step_noise, repeat_noise, return_last=return_last,
+                                               ws=self._sample_ws)
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)          # CPU generator: torch.manual_seed reproduces
+            eager = lambda x, nz, sd: net.plan.repaint_sample(packed, rd, x, nz, return_last=return_last, ws=self._sample_ws,
+                                                              rng_seed=sd.to(x.device))
+            if os.environ.get("MCEDM_HIP_GRAPH", "1") == "0":
+                return eager(hu, hu_noise, seed)
+            B = hu.shape[0]
+            key = (B, bool(return_last), packed.data_ptr(), hu.device.index, float(self.edm_steps[0]),
+                   tuple(getattr(rd, f) for f, _ in rd._fields_ if f not in ("edm_steps", "alphas_cumprod_ext")))
+            fn = _lib.graphed_or_eager(self._graphs, key, lambda: _lib.GraphedRepaint(net.plan, packed, rd, keep, B, return_last,
+                                                                                     ws=self._sample_ws), eager)
+            out = fn(hu, hu_noise, seed)
+            return out.clone() if fn is not eager else out
 
     # ---- evaluation loops (models/ddim.py:294-533): BASELINE config 5 is run through trainer.test -> test_step ------------
     def get_pde_loss(self, cond, x_denoised, x_gt_unnorm=None, noise_level=None, clamp_loss=True, do_rearrange=True,

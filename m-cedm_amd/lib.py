@@ -28,6 +28,7 @@ EXPORTS = [
     "mcedm_ddpm_plan_create", "mcedm_ddpm_plan_destroy", "mcedm_ddpm_param_count", "mcedm_ddpm_param_info",
     "mcedm_ddpm_packed_bytes", "mcedm_ddpm_pack_weights", "mcedm_ddpm_workspace_bytes", "mcedm_ddpm_forward",
     "mcedm_ddpm_denoise", "mcedm_repaint_schedule", "mcedm_repaint_workspace_bytes", "mcedm_repaint_sample",
+    "mcedm_repaint_sample_rng", "mcedm_normal_fill",
 ]
 
 
@@ -130,6 +131,8 @@ def load() -> C.CDLL:
     lib.mcedm_repaint_schedule.argtypes = [C.POINTER(RepaintDesc), C.POINTER(C.c_double)]
     lib.mcedm_repaint_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]
     lib.mcedm_repaint_sample.argtypes = [vp, vp, C.POINTER(RepaintDesc), f32p, f32p, f64p, f64p, f64p, i32, vp, sz, i32, vp]
+    lib.mcedm_repaint_sample_rng.argtypes = [vp, vp, C.POINTER(RepaintDesc), f32p, f32p, vp, f64p, i32, vp, sz, i32, vp]
+    lib.mcedm_normal_fill.argtypes = [f64p, sz, vp, C.c_uint64, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)          # AttributeError here == header/library drift
         if name not in ("mcedm_last_error", "mcedm_unet_plan_destroy", "mcedm_ddpm_plan_destroy"):
@@ -449,7 +452,10 @@ class DdpmPlan:
         return (D, F) if want_F else D
 
     def repaint_sample(self, packed, rd: RepaintDesc, hu, init_noise, step_noise=None, repeat_noise=None,
-                       return_last: bool = True, ws: Optional[Workspace] = None, out: Optional[torch.Tensor] = None):
+                       return_last: bool = True, ws: Optional[Workspace] = None, out: Optional[torch.Tensor] = None,
+                       rng_seed: Optional[torch.Tensor] = None):
+        """rng_seed (device int64 [1]): the per-step / per-loop noise is generated on the device from that seed
+        (mcedm_repaint_sample_rng) instead of being read from step_noise / repeat_noise."""
         self._check_x(hu)
         B = hu.shape[0]
         ws = ws or Workspace()
@@ -460,11 +466,25 @@ class DdpmPlan:
             out = torch.empty(shape, dtype=torch.float64, device=hu.device)
         elif tuple(out.shape) != shape:
             raise RuntimeError(f"repaint_sample: out has shape {tuple(out.shape)}, expected {shape}")
+        if rng_seed is not None:
+            if step_noise is not None or repeat_noise is not None:
+                raise RuntimeError("repaint_sample: give either noise tensors or rng_seed")
+            check(self._lib.mcedm_repaint_sample_rng(self._h, packed.data_ptr(), C.byref(rd), _ptr(hu), _ptr(init_noise),
+                                                     _ptr(rng_seed, torch.int64), _ptr(out, torch.float64), int(return_last),
+                                                     buf.data_ptr(), buf.numel(), B, _stream()), "repaint_sample_rng")
+            return out
         check(self._lib.mcedm_repaint_sample(self._h, packed.data_ptr(), C.byref(rd), _ptr(hu), _ptr(init_noise),
                                              _ptr(step_noise, torch.float64), _ptr(repeat_noise, torch.float64),
                                              _ptr(out, torch.float64), int(return_last), buf.data_ptr(), buf.numel(), B,
                                              _stream()), "repaint_sample")
         return out
+
+
+def normal_fill(out: torch.Tensor, rng_seed: torch.Tensor, draw: int) -> torch.Tensor:
+    """out (fp64, contiguous) <- draw number `draw` of the device generator keyed by rng_seed (int64 [1] on the device)."""
+    check(load().mcedm_normal_fill(_ptr(out, torch.float64), out.numel(), _ptr(rng_seed, torch.int64), int(draw), _stream()),
+          "normal_fill")
+    return out
 
 
 class _PinnedWorkspace:
@@ -530,6 +550,40 @@ class GraphedSampler:
                 raise RuntimeError(f"GraphedSampler: '{name}' presence differs from the captured call")
             if dst is not None:
                 dst.copy_(src)
+        self.graph.replay()
+        return self.out
+
+
+class GraphedRepaint:
+    """mcedm_repaint_sample_rng captured once and replayed: the whole RePaint call (timesteps x n_repeat Heun updates:
+    ~80 000 launches at BASELINE config 5) is one HIP graph.  The noise is generated on the device from the seed in
+    ``self.seed``, which the host rewrites before each replay, so every replay draws fresh noise."""
+
+    def __init__(self, plan: "DdpmPlan", packed: torch.Tensor, rd: RepaintDesc, keep, B: int, return_last: bool = True,
+                 ws: Optional[Workspace] = None):
+        dev = packed.device
+        self.plan, self.packed, self.rd, self._keep, self.return_last = plan, packed, rd, keep, return_last
+        S, Cc = plan.resolution, plan.in_channels
+        self.hu = torch.zeros((B, Cc, S, S), device=dev)
+        self.init = torch.zeros((B, Cc, S, S), device=dev)
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        T = 1 if return_last else rd.timesteps + 1
+        self.out = torch.empty((B, T, S, S, Cc), dtype=torch.float64, device=dev)
+        self.ws = _PinnedWorkspace(ws, plan.repaint_workspace_bytes(B), dev)
+        self.graph = _capture(self._run, dev)
+
+    def _run(self):
+        self.plan.repaint_sample(self.packed, self.rd, self.hu, self.init, None, None, self.return_last, self.ws, out=self.out,
+                                 rng_seed=self.seed)
+
+    def __call__(self, hu, init_noise, seed) -> torch.Tensor:
+        """seed: python int or int64 tensor.  Returns the instance's static output tensor."""
+        self.hu.copy_(hu)
+        self.init.copy_(init_noise)
+        if torch.is_tensor(seed):
+            self.seed.copy_(seed.reshape(1))
+        else:
+            self.seed.fill_(int(seed))
         self.graph.replay()
         return self.out
 

@@ -123,6 +123,7 @@ def test_plddim_module_golden(golden, monkeypatch):
         for n, p in m.ema_model.ma_model.named_parameters():
             p.copy_(P[n])
     m.set_test_sampler_params(sp)
+    m.noise_source = "torch"            # per-step / per-loop noise as torch tensors, so the reference's draws can be injected
     # the schedule tables are CPU tensor arithmetic of the host (like the reference's): same expression, last-bit
     # differences between hosts are possible, so they are compared to 2 ulp, not bitwise
     es, ae = torch.as_tensor(g["edm_steps"]), torch.as_tensor(g["alphas_ext"])
@@ -152,3 +153,77 @@ def test_plddim_module_golden(golden, monkeypatch):
     close(xs, ref, atol=1e-5 * float(ref.abs().max()), what="PlDdim.sample_edm")
     with pytest.raises(NotImplementedError):
         m.training_step(None, 0)
+
+
+def test_device_normal_generator_statistics(net):
+    """mcedm_normal_fill (Philox4x32-10 + Box-Muller, csrc/edm.hip): moments of N(0, 1), reproducible per (seed, draw),
+    different across draws and seeds, no correlation between the two values of a counter or between neighbouring draws."""
+    L = net[0]
+    n = 1 << 22
+    seed = torch.tensor([1234567], dtype=torch.int64, device="cuda")
+    a = L.normal_fill(torch.empty(n, dtype=torch.float64, device="cuda"), seed, 0)
+    b = L.normal_fill(torch.empty(n, dtype=torch.float64, device="cuda"), seed, 1)
+    assert torch.equal(a, L.normal_fill(torch.empty(n, dtype=torch.float64, device="cuda"), seed, 0))
+    c = L.normal_fill(torch.empty(n, dtype=torch.float64, device="cuda"), seed + 1, 0)
+    assert not torch.equal(a, b) and not torch.equal(a, c) and bool(torch.isfinite(a).all())
+    se = 1.0 / n ** 0.5
+    for x in (a, b, c):
+        m, v = float(x.mean()), float(x.var())
+        skew, kurt = float((x ** 3).mean()), float((x ** 4).mean())
+        assert abs(m) < 5 * se and abs(v - 1) < 5 * se * 2 ** 0.5 and abs(skew) < 5 * se * 15 ** 0.5 and abs(kurt - 3) < 5 * se * 96 ** 0.5, (m, v, skew, kurt)
+        assert float(x.abs().max()) > 4.5                      # the tails are there (P(|z| > 4.5) * n ~ 28)
+    corr = lambda x, y: float((x * y).mean())
+    assert abs(corr(a[0::2], a[1::2])) < 5 * (2.0 / n) ** 0.5 and abs(corr(a, b)) < 5 * se and abs(corr(a, c)) < 5 * se
+    # an odd length ends on the first value of a pair
+    odd = L.normal_fill(torch.empty(7, dtype=torch.float64, device="cuda"), seed, 0)
+    assert torch.equal(odd, a[:7])
+
+
+def test_repaint_device_noise_matches_materialised_draws(net):
+    """mcedm_repaint_sample_rng == mcedm_repaint_sample fed with the tensors mcedm_normal_fill produces for the same seed
+    (draw index i * n_repeat for the step noise, i * n_repeat + 1 + k between inner loops): the in-kernel generator is the
+    documented stream, and the noise-free plumbing is the golden-tested one."""
+    L, plan, packed, P = net
+    tag = "churn_r3"
+    N, R, churn, nth, ntu = fx.REPAINT_CASES[tag]
+    h, u, init, _, _ = fx.repaint_inputs(tag)
+    hu = torch.cat([h, u], dim=-1).permute(0, 3, 1, 2).contiguous().cuda()
+    rd, keep = repaint_desc(L, tag)
+    seed = torch.tensor([99], dtype=torch.int64, device="cuda")
+    shape = (fx.REPAINT_B, 2, CFG.resolution, CFG.resolution)
+    steps = torch.stack([L.normal_fill(torch.empty(shape, dtype=torch.float64, device="cuda"), seed, i * R) for i in range(N)])
+    reps = torch.stack([torch.stack([L.normal_fill(torch.empty(shape, dtype=torch.float64, device="cuda"), seed, i * R + 1 + k)
+                                     for k in range(R - 1)]) for i in range(N)])
+    want = plan.repaint_sample(packed, rd, hu, init.cuda(), steps, reps, return_last=False)
+    got = plan.repaint_sample(packed, rd, hu, init.cuda(), return_last=False, rng_seed=seed)
+    assert torch.equal(got, want)
+    other = plan.repaint_sample(packed, rd, hu, init.cuda(), return_last=False, rng_seed=seed + 1)
+    assert not torch.equal(other, want)
+
+
+def test_plddim_sample_edm_device_noise_graph_and_seed(monkeypatch):
+    """PlDdim.sample_edm in its default mode: noise generated on the device from a seed drawn from torch's generator, the
+    whole call replayed from one HIP graph.  Same torch seed -> same states; graph == eager launches; known rows exact."""
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd import lib as L
+    from mcedm_amd.ddim import PlDdim
+    N, R, nth, ntu = 4, 3, 0, 16
+    sp = wrap(dict(name="edm", type="edm", timesteps=N, sigma_min=0.002, sigma_max=80, rho=7, S_churn=15.0, S_min=0, S_max="inf",
+                   S_noise=1, n_samples=1, n_repeat=R, n_time_h=nth, n_time_u=ntu, return_last=True, guide_dx=False, w=0.0))
+    m = PlDdim(hparams(sp)).cuda()
+    P = dorc.make_params(CFG, 21)
+    with torch.no_grad():
+        for n, p in m.ema_model.ma_model.named_parameters():
+            p.copy_(P[n])
+    m.set_test_sampler_params(sp)
+    h, u = fx.randn("ddpm/dev/h", 3, 32, 32, 1).cuda(), fx.randn("ddpm/dev/u", 3, 32, 32, 1).cuda()
+
+    def run(seed):
+        torch.manual_seed(seed)
+        return m.sample_edm(h, u, sp, return_last=True)
+    a, b, c = run(5), run(5), run(6)
+    assert isinstance(next(iter(m._graphs.values())), L.GraphedRepaint) and len(m._graphs) == 1
+    assert torch.equal(a, b) and not torch.equal(a, c) and bool(torch.isfinite(a).all())
+    assert torch.equal(a[:, 0, :ntu, :, 1], u[:, :ntu, :, 0].double()), "known rows of u are the clean data"
+    monkeypatch.setenv("MCEDM_HIP_GRAPH", "0")
+    assert torch.equal(run(5), a), "graph replay and eager launches must agree bit for bit"

@@ -87,6 +87,7 @@ def test_plddim_test_step_golden(golden, monkeypatch, tag):
     m = PlDdim(ddpm_hparams(sp)).cuda()
     logs = _fill(m, dorc.make_params(fx.CFG_D, 21), fx.EVAL_DDPM_STATS, system)
     m.set_test_sampler_params(sp)
+    m.noise_source = "torch"            # the reference's draws are injected as torch tensors
     h, u, init, steps, reps, _ = fx.eval_ddpm_inputs(tag)
     queue = [init]
     _inject_repaint(monkeypatch, queue, steps, reps)
@@ -111,6 +112,7 @@ def test_plddim_validation_step_golden(golden, monkeypatch):
     m = PlDdim(ddpm_hparams(sp)).cuda()
     logs = _fill(m, dorc.make_params(fx.CFG_D, 21), fx.EVAL_DDPM_STATS, system)
     m.set_test_sampler_params(sp)          # builds edm_steps (the reference's run.py does this before fit / test too)
+    m.noise_source = "torch"
     h, u, init, steps, reps, u_noise = fx.eval_ddpm_inputs("val")
     queue = [u_noise, init]
     _inject_repaint(monkeypatch, queue, steps, reps)
