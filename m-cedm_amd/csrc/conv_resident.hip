@@ -35,6 +35,10 @@
 
 namespace mcedm {
 
+// the value, hidden from the optimiser: what is computed from it cannot be hoisted out of the enclosing loop (and kept
+// in registers across the K loop)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 static constexpr int SKC = 16;      // channels per K chunk of the folded projection (= the packed 1x1 table's chunk)
 
 // Tile configuration of the resident kernel: ConvCfg's members (the shared device code is written against them) with an
@@ -60,11 +64,16 @@ struct ResCfg {
   static constexpr int XL = KCI * PLANE, WL = TAPS * KCI * MT;
   static constexpr int NWAVE = WM * WN * KS;
   static constexpr int OCC = 2;
-  // wide staging: lanes per channel, channels per wave instruction
-  static constexpr int RSEG = PITCH / 4, LPC = ROWS * RSEG, CPW = 64 / LPC;
-  // transform pass on pairs of adjacent elements: pairs per row / channel, channels per workgroup step
-  static constexpr int PPR = HALO ? (PW + 4) / 2 : PW / 2, PC0 = HALO ? 2 : 0, PPC = ROWS * PPR, CPT = NT / PPC;
-  static_assert(NWAVE == 4 && TM >= 1 && TN >= 1 && PITCH % 4 == 0 && LPC <= 64 && CPW >= 1 && CPT >= 1, "tile shape");
+  // wide staging: lanes (float4 row segments) per channel tile; channels per wave instruction, or (BIG tiles, used for
+  // >= 64 x 64 images: the channel tile is larger than a wave) wave instructions per channel
+  static constexpr int RSEG = PITCH / 4, LPC = ROWS * RSEG;
+  static constexpr bool BIG = LPC > 64;
+  static constexpr int CPW = BIG ? 1 : 64 / LPC, NIC = (LPC + 63) / 64;
+  // transform pass on pairs of adjacent elements: pairs per row / channel; channels per workgroup step, or (BIG) pair
+  // positions per thread
+  static constexpr int PPR = HALO ? (PW + 4) / 2 : PW / 2, PC0 = HALO ? 2 : 0, PPC = ROWS * PPR;
+  static constexpr int CPT = BIG ? 1 : NT / PPC, NPP = (PPC + NT - 1) / NT;
+  static_assert(NWAVE == 4 && TM >= 1 && TN >= 1 && PITCH % 4 == 0 && CPW >= 1 && CPT >= 1 && (BIG || NPP == 1), "tile shape");
 };
 
 // A weight slab = a run of whole rows of the packed table ([tap][ci_local] rows of MT floats at column m0), global -> LDS by
@@ -96,9 +105,10 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   static_assert(C::NT == 256 && C::NWAVE == 4 && C::CPI == 1, "four compute waves");
   static_assert(SKC * C::MT / 4 <= C::NT && (SKC * C::MT / 4) % 64 == 0, "the projection's weight slab is one DMA step of whole waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int CPS = C::NT / C::PLANE;             // narrow staging: input channels per step of the workgroup
-  constexpr int CPD = C::NT / C::NPIX;              // narrow staging of the projection's input: channels per step
-  static_assert(CPS >= 1, "tile plane larger than the workgroup");
+  constexpr int CPS = C::BIG ? 1 : C::NT / C::PLANE;   // narrow staging: input channels per step of the workgroup
+  constexpr int CPD = C::BIG ? 1 : C::NT / C::NPIX;    // narrow staging of the projection's input: channels per step
+  static_assert(C::BIG || (C::NT / C::PLANE >= 1), "tile plane larger than the workgroup");
+  static_assert(!C::BIG || RS == RS_NONE, "big tiles stage by row segments only (un-resampled, aligned sources)");
   typedef SlabGeom<C, SPLIT> SG;
   float* wl = lds;                                  // [nslab][SL] ring of weight slabs (nslab = 3, or 2 when LDS is short)
   float* xl = lds + nslab * SG::SL;                 // [pass_c][PLANE] input tile of one pass: raw by DMA, then transformed in
@@ -185,10 +195,21 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     const bool inb = wlane && ((unsigned)y < (unsigned)p.H) && ((unsigned)xs < (unsigned)p.W);   // W % 4 == 0: all four or none
     wboff = 4u * ((unsigned)csub * (unsigned)src_plane + (inb ? (unsigned)(y * p.Ws + xs) : 0u));   // padding: clamped, masked later
   }
+  // BIG tiles: part k of a channel tile = its float4 segments [64 k, 64 k + 64): lane -> (row, segment), computed where it
+  // is used (once per pass: a few VALU instructions) instead of living in registers across the K loop, whose eight
+  // accumulator blocks leave no room for them
+  auto big_seg = [&](int k, unsigned& off) -> bool {
+    const int sg = k * 64 + opaque(lane), r = sg / C::RSEG, q = sg - r * C::RSEG;
+    const int y = y0 - C::HALO + r, xs = x0 - C::XM + 4 * q;
+    const bool in_tile = sg < C::LPC;
+    const bool inb = in_tile && ((unsigned)y < (unsigned)p.H) && ((unsigned)xs < (unsigned)p.W);
+    off = 4u * (inb ? (unsigned)(y * p.Ws + xs) : 0u);
+    return in_tile;
+  };
   // narrow (2x up-sampled or unaligned source): thread pos of the workgroup fetches element pos of channel c (+ chsub)
-  const bool nactive = tid < CPS * C::PLANE;
-  unsigned nboff;
-  {
+  const bool nactive = !C::BIG && tid < CPS * C::PLANE;
+  unsigned nboff = 0;
+  if constexpr (!C::BIG) {
     const int chsub = nactive ? tid / C::PLANE : 0, pos = nactive ? tid - chsub * C::PLANE : 0;
     const int r = pos / C::PITCH, c = pos - r * C::PITCH;
     const int y = y0 - C::HALO + r, x = x0 - C::XM + c;
@@ -200,7 +221,14 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   // requests channels [cb, cb + pc) of the (concatenated, possibly up-sampled) input
   auto request_main = [&](int cb, int pc) {
     const int cend = min(cb + pc, Cin);
-    if (wide) {                                     // the launcher checks Ca % CPW == 0 and Cin % CPW == 0
+    if constexpr (C::BIG) {                         // (channel, part) pairs round-robin over the waves; always wide
+      for (int idx = wave; idx < (cend - cb) * C::NIC; idx += 4) {
+        const int cl = idx / C::NIC, k = idx - cl * C::NIC, c0 = cb + cl;          // wave-uniform
+        const float* plane = (c0 < Ca ? pa : pb) + (size_t)c0 * src_plane;
+        unsigned off;
+        if (big_seg(k, off)) lds_dma16(plane, off, xl_base + 4u * (unsigned)(cl * C::PLANE + k * 256));
+      }
+    } else if (wide) {                              // the launcher checks Ca % CPW == 0 and Cin % CPW == 0
       for (int c0 = cb + wave * C::CPW; c0 < cend; c0 += 4 * C::CPW) {
         const float* plane = (c0 < Ca ? pa : pb) + (size_t)c0 * src_plane;
         if (wlane) lds_dma16(plane, wboff, xl_base + 4u * (unsigned)((c0 - cb) * C::PLANE));
@@ -217,10 +245,10 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   // GroupNorm / FiLM / SiLU and the zero padding, in place, on PAIRS of horizontally adjacent elements (one 8-byte LDS
   // read and write per pair; the per-element arithmetic is apply_coef's).  Thread (tsub, r, pj)
   // owns layout columns PC0 + 2 pj, + 1 of row r of channel c + tsub; after the barrier that follows the DMA wait.
-  const bool tactive = tid < C::CPT * C::PPC;
-  int tsub, tpos;
-  unsigned keep0, keep1;
-  {
+  const bool tactive = !C::BIG && tid < C::CPT * C::PPC;
+  int tsub = 0, tpos = 0;
+  unsigned keep0 = 0, keep1 = 0;
+  if constexpr (!C::BIG) {
     tsub = tactive ? tid / C::PPC : 0;
     const int prem = tactive ? tid - tsub * C::PPC : 0, r = prem / C::PPR, col = C::PC0 + 2 * (prem - r * C::PPR);
     const int y = y0 - C::HALO + r, x = x0 - C::XM + col;
@@ -231,6 +259,43 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   }
   auto transform_main = [&](int cb, int pc) {
     const int cend = min(cb + pc, Cin);
+    if constexpr (C::BIG) {
+      // every channel has more pairs than the workgroup has threads: this thread owns pair positions tid + k NT (recomputed
+      // per pass, see big_seg)
+      int bpos[C::NPP];
+      unsigned bkeep0[C::NPP], bkeep1[C::NPP];
+      bool bact[C::NPP];
+#pragma unroll
+      for (int k = 0; k < C::NPP; ++k) {
+        const int e = opaque(tid) + k * C::NT;
+        bact[k] = e < C::PPC;
+        const int prem = bact[k] ? e : 0, r = prem / C::PPR, col = C::PC0 + 2 * (prem - r * C::PPR);
+        const int y = y0 - C::HALO + r, x = x0 - C::XM + col;
+        const bool iny = (unsigned)y < (unsigned)p.H;
+        bkeep0[k] = (iny && (unsigned)x < (unsigned)p.W) ? 0xffffffffu : 0u;
+        bkeep1[k] = (iny && (unsigned)(x + 1) < (unsigned)p.W) ? 0xffffffffu : 0u;
+        bpos[k] = r * C::PITCH + col;
+      }
+      auto pass = [&](auto act_tag) {
+        constexpr bool ACT = decltype(act_tag)::value;
+        for (int c = cb; c < cend; ++c) {
+          const Coef cf = cfl[c];
+#pragma unroll
+          for (int k = 0; k < C::NPP; ++k) {
+            if (bact[k]) {
+              float* px = xl + (c - cb) * C::PLANE + bpos[k];
+              float v0 = (px[0] - cf.mean) * cf.scale + cf.offset;
+              float v1 = (px[1] - cf.mean) * cf.scale + cf.offset;
+              if (ACT) { v0 = silu_f(v0); v1 = silu_f(v1); }
+              px[0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v0) & bkeep0[k]);
+              px[1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v1) & bkeep1[k]);
+            }
+          }
+        }
+      };
+      if (p.act) pass(std::true_type{}); else pass(std::false_type{});
+      return;
+    }
     if (tactive) {
       auto pass = [&](auto act_tag) {
         constexpr bool ACT = decltype(act_tag)::value;
@@ -280,6 +345,22 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     const float* xc = xl + cl * C::KC * C::PLANE;
     const float* nb; int nv4;
     const int kind = unit_src(u + dist, nb, nv4);
+    if constexpr (C::KS == 1) {
+      // ONE copy of the MFMA chunk whatever the slab `dist` units ahead is: with the chunk duplicated in the arms of an
+      // if / else the accumulators get a second set of registers for the phi at the join (D != C in the first MFMA of
+      // every unit), which the 8-block tiles cannot afford (spills inside the K loop).  The tap hook branches instead
+      // (wave-uniform, one scalar compare per tap).
+      const bool stream = kind == 2;
+      const int slab = sn;
+      int issued = 0;
+      if (kind == 1 && wave * 64 < nv4) { dma_step(0, nb, nv4, slab); issued = 1; }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_chunk<C, true, false, T0, T1>(xc, wc, acc, aoff, boffm, [&](int t) {
+        if (stream && t < SG::ITU) dma_step(t, nb, nv4, slab);
+      });
+      finish_unit(stream ? SG::ITU : issued);
+      return;
+    }
     if (kind == 2) {
       // the common case: the slab dist units ahead is a weight slab and its ITU DMA instructions go out one per tap, in
       // the shadow of the MFMAs (issued in a block in front of them they cost ~90 cycles each: the memory pipeline
@@ -355,9 +436,18 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     const float* qa = p.sk_xa + (size_t)n * p.sk_Ca * plane;
     const float* qb = p.sk_xb + (size_t)n * p.sk_Cb * plane - (size_t)p.sk_Ca * plane;
     // narrow: one pixel per thread, CPD channels per step; wide: one float4 of a tile row per lane, CPQ channels per instruction
-    constexpr int SEG = C::PW / 4, LPQ = C::PH * SEG, CPQ = 64 / LPQ;
-    unsigned poff, qoff;
-    {
+    constexpr int SEG = C::PW / 4, LPQ = C::PH * SEG, CPQ = LPQ > 64 ? 1 : 64 / LPQ, NIQ = (LPQ + 63) / 64;
+    unsigned poff = 0, qoff = 0;
+    unsigned bqoff[LPQ > 64 ? NIQ : 1];
+    if constexpr (LPQ > 64) {                        // a channel's interior tile = NIQ wave instructions of float4 segments
+      static_assert(LPQ % 64 == 0, "whole waves per channel tile");
+#pragma unroll
+      for (int k = 0; k < NIQ; ++k) {
+        const int sg = k * 64 + lane, r = sg / SEG, q = sg - r * SEG;
+        const int yq = min(y0 + r, p.H - 1), xq = min(x0 + 4 * q, p.W - 4);
+        bqoff[k] = 4u * (unsigned)((size_t)yq * p.W + xq);
+      }
+    } else {
       const int pix = tid % C::NPIX, csub = tid / C::NPIX;
       const int y = min(y0 + pix / C::PW, p.H - 1), x = min(x0 + pix % C::PW, p.W - 1);   // clamped: such pixels are never stored
       poff = 4u * (unsigned)((size_t)csub * plane + (size_t)y * p.W + x);
@@ -367,7 +457,14 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     }
     for (int sb = 0; sb < Csk; sb += pass_c) {
       const int pc = min(pass_c, Csk - sb);         // multiple of SKC
-      if (wide) {                                   // the launcher checks sk_Ca % CPQ == 0
+      if constexpr (LPQ > 64) {
+        for (int idx = wave; idx < pc * NIQ; idx += 4) {
+          const int cl = idx / NIQ, k = idx - cl * NIQ, c0 = sb + cl;
+#pragma unroll
+          for (int kk = 0; kk < NIQ; ++kk)
+            if (kk == k) lds_dma16((c0 < p.sk_Ca ? qa : qb) + (size_t)c0 * plane, bqoff[kk], xl_base + 4u * (unsigned)(cl * C::NPIX + kk * 256));
+        }
+      } else if (wide) {                            // the launcher checks sk_Ca % CPQ == 0
         for (int c0 = sb + wave * CPQ; c0 < sb + pc; c0 += 4 * CPQ)
           lds_dma16((c0 < p.sk_Ca ? qa : qb) + (size_t)c0 * plane, qoff, xl_base + 4u * (unsigned)((c0 - sb) * C::NPIX));
       } else {
@@ -464,6 +561,17 @@ static int resident_level() {     // 0: off, > 0: on
 }
 
 static constexpr int LDS_MAX = 160 * 1024;
+// big-tile (>= 64 x 64 images) variants: MCEDM_RES_BIG=0 turns them off; MCEDM_RES_BIG_PASS = channels per pass (multiple of 16)
+static int big_level() {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_RES_BIG"); env = e ? atoi(e) : 1; }
+  return env;
+}
+static int big_pass() {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_RES_BIG_PASS"); env = (e && atoi(e) >= 16) ? atoi(e) / 16 * 16 : 1 << 20; }
+  return env;
+}
 
 // Launch plan of one conv: channels resident per pass (0: this conv is not served here), weight slabs in the ring.
 struct ResidentPlan { int pass_c = 0, nslab = 0, wide = 0; size_t lds = 0; };
@@ -477,7 +585,8 @@ static size_t resident_lds_bytes(const ConvArgs& a, int pass_c, int nslab) {
 // per pass as fit (a multiple of 16: whole K chunks of the conv and of the projection), at least min_pass.
 template <class C, bool SPLIT>
 static ResidentPlan resident_plan(const ConvArgs& a, size_t budget, int min_pass) {
-  constexpr int CPS = C::NT / C::PLANE, CPD = C::NT / C::NPIX, CPQ = 64 / (C::PH * (C::PW / 4));
+  constexpr int LPQ = C::PH * (C::PW / 4);
+  constexpr int CPS = C::BIG ? 1 : C::NT / C::PLANE, CPD = C::BIG ? 1 : C::NT / C::NPIX, CPQ = LPQ > 64 ? 1 : 64 / LPQ;
   ResidentPlan r;
   const int Cin = a.Ca + a.Cb, Csk = a.sk_wpk ? a.sk_Ca + a.sk_Cb : 0;
   if (!a.xa || a.Ca <= 0 || (a.Cb > 0 && !a.xb)) return r;
@@ -486,7 +595,7 @@ static ResidentPlan resident_plan(const ConvArgs& a, size_t budget, int min_pass
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
   r.wide = a.resample == RS_NONE && a.Ws % 4 == 0 && a.W % 4 == 0 && al16(a.xa) && al16(a.xb) && a.Ca % C::CPW == 0 && Cin % C::CPW == 0 &&
            (!Csk || (al16(a.sk_xa) && al16(a.sk_xb) && a.sk_Ca % CPQ == 0));
-  if (!r.wide && (a.Ca % CPS || Cin % CPS || (Csk && a.sk_Ca % CPD))) { r.wide = 0; return r; }
+  if (!r.wide && (C::BIG || a.Ca % CPS || Cin % CPS || (Csk && a.sk_Ca % CPD))) { r.wide = 0; return r; }   // big tiles: row segments only
   const int need = std::max(ceil_div(Cin, C::KC) * C::KC, Csk);      // channels of the longest input (padded to chunks)
   constexpr int G = C::KS * C::KC > 16 ? C::KS * C::KC : 16;         // a pass is whole K units of the conv and of the projection
   const int all = ceil_div(need, G) * G;
@@ -579,6 +688,24 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
       if (pass_env < 0) { const char* e = getenv("MCEDM_RES_PASS"); pass_env = e ? atoi(e) : 0; }
       if (pass_env >= 16 && pass_env % 16 == 0 && pass_env < pl.pass_c) pl.pass_c = pass_env;
       return a.resample == RS_UP ? launch_resident<M, RS_UP, true>(a, pl, stream) : launch_resident<M, RS_NONE, true>(a, pl, stream);
+    }
+    if ((long long)a.H * a.W >= 4096 && big_level() > 0 && a.resample == RS_NONE && cout_padded(a.Cout) == 64) {
+      // >= 64 x 64 images, convs with ONE 64-channel output tile (the ch = 64 networks: the reference's own
+      // adm_edm_mcedm_res32 and the DDPM U-Net): conv_mfma_kernel's <64, 8, 32> tile pays its staging (16 + 5 vector
+      // loads and ~11 transformed elements per thread and chunk, all of it matrix-pipe time on gfx950) against half the
+      // MFMAs of the 128-channel tile and holds 0.64 of peak.  Here the raw tile arrives by DMA as whole 16-byte row
+      // segments (6 instructions per wave and 16-channel pass), is transformed in place, and no staging registers exist, so
+      // a wave can own EIGHT accumulator blocks (64 channels x 16 x 32 pixels per workgroup) at two workgroups per CU.
+      // The pixel tile is a function of the image size only (batch-shard bit-identity).
+      if ((long long)a.H * a.W >= 16384) {
+        typedef ResCfg<64, 16, 32, 1, 4, 9, 8> B16;
+        ResidentPlan pl = resident_plan<B16, true>(a, half_cu, 16);
+        if (pl.pass_c && pl.nslab == 3 && pl.wide) { if (pl.pass_c > big_pass()) pl.pass_c = big_pass(); return launch_resident<B16, RS_NONE, true>(a, pl, stream); }
+      } else {
+        typedef ResCfg<64, 8, 32, 1, 4, 9, 8> B8;
+        ResidentPlan pl = resident_plan<B8, true>(a, half_cu, 16);
+        if (pl.pass_c && pl.nslab == 3 && pl.wide) { if (pl.pass_c > big_pass()) pl.pass_c = big_pass(); return launch_resident<B8, RS_NONE, true>(a, pl, stream); }
+      }
     }
     return -1;
   }

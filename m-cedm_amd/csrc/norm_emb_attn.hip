@@ -1,5 +1,6 @@
 // norm_emb_attn.hip -- K1 (GroupNorm statistics -> per-channel transform table), K6 (sigma
 // embedding MLP + every FiLM affine row) and K5 (fused softmax attention on fp32 MFMA).
+#include <cstdlib>
 #include "common.hpp"
 #include "prof.hpp"
 
@@ -371,11 +372,154 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
   }
 }
 
+// The same attention with the KEY range split over the KW waves of a workgroup (flash-decoding style).  One wave per 32
+// queries means B * heads * T / 32 waves per launch: 1024 at T = 1024, B = 32, one head (the 32 x 32 level of the ch = 64
+// networks), i.e. ONE wave per SIMD, and every K / V load latency and every MFMA -> softmax -> MFMA dependency sits exposed
+// (measured 47 TFLOP/s).  Here wave w of a workgroup takes the 32-key tiles w, w + KW, ... of the same 32 queries, so a
+// SIMD holds KW waves that cover each other's latencies; the partial (max, sum, output) triples meet in LDS and wave 0
+// merges them in wave order (fixed order: bitwise reproducible, independent of the batch size).  Scores are kept in the
+// log2 domain (q is pre-scaled by log2(e) / 8) so the exponentials are single v_exp_f32 instructions.
+template <int KW>
+__global__ __launch_bounds__(64 * KW) __attribute__((amdgpu_waves_per_eu(3, 3))) void attention_split_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T) {
+  __shared__ float part[KW > 1 ? (KW - 1) * 34 * 64 : 1];        // waves 1 .. KW-1: o[32], m, l per lane
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32;
+  const size_t bh = blockIdx.y;
+  const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
+  const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
+  const int q = q0 + l31;
+  const int qc = q < T ? q : T - 1;
+
+  // the query tile, scaled, in LDS: the KW waves of the workgroup share it (kept in registers it costs each wave 32 VGPRs,
+  // and the kernel must stay under 170 to run three waves per SIMD)
+  __shared__ float qs[64 * 32];
+  for (int e = threadIdx.x; e < 64 * 32; e += 64 * KW) {
+    const int c = e >> 5, qq = q0 + (e & 31);
+    qs[e] = Q[(size_t)c * T + (qq < T ? qq : T - 1)] * (0.125f * 1.44269504088896340736f);
+  }
+  __syncthreads();
+  const float* qrow = qs + h * 32 + l31;          // + 64 * st: channel 2 st + h, query l31
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+
+  for (int k0 = 32 * wave; k0 < T; k0 += 32 * KW) {
+    const bool full = (k0 + 32 <= T);
+    const int kk = k0 + l31;
+    const int kc = kk < T ? kk : T - 1;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    // K[2 st + h][kc]: scalar row base + one 32-bit per-lane byte offset (32 per-lane 64-bit row addresses would cost 64 VGPRs)
+    const unsigned koff = 4u * (unsigned)(h * T + kc);
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+      const float a = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(K + (size_t)(2 * st) * T) + koff);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qrow[64 * st], s, 0, 0, 0);
+    }
+    // s[r] = log2(e) * score(query l31, key k0 + (r&3) + 8*(r>>2) + 4*h)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (!full && key >= T) s[r] = -INFINITY;
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float p[16];
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+      rs += p[r];
+    }
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* vrow = V + (size_t)(32 * i + l31) * T;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v4[4];
+        const int kb = k0 + 8 * g + 4 * h;
+        if (full && (T & 3) == 0) {
+          const float4 t = *reinterpret_cast<const float4*>(vrow + kb);
+          v4[0] = t.x; v4[1] = t.y; v4[2] = t.z; v4[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = vrow[(kb + e) < T ? (kb + e) : T - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v4[e], p[4 * g + e], o[i], 0, 0, 0);
+      }
+    }
+  }
+  if (KW > 1) {
+    if (wave > 0) {
+      float* dst = part + (size_t)(wave - 1) * 34 * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(16 * i + r) * 64] = o[i][r];
+      dst[32 * 64] = m; dst[33 * 64] = l;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 1; w < KW; ++w) {            // a wave that saw no key tile holds m = -inf, l = 0: it merges to nothing
+      const float* src = part + (size_t)(w - 1) * 34 * 64 + lane;
+      const float mw = src[32 * 64], lw = src[33 * 64];
+      const float m_new = fmaxf(m, mw);
+      const float a0 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - m_new);
+      const float a1 = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - m_new);
+      l = l * a0 + lw * a1;
+      m = m_new;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + src[(16 * i + r) * 64] * a1;
+    }
+  }
+  if (q < T) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[(bh * 64 + c) * (size_t)T + q] = o[i][r] * inv;
+      }
+  }
+}
+
+static int attn_split_env() {          // MCEDM_ATTN_SPLIT=0: the one-wave-per-query-tile kernel everywhere (A/B runs)
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_ATTN_SPLIT"); env = e ? atoi(e) : 1; }
+  return env;
+}
+
 int launch_attention(const float* qkv, float* out, int B, int heads, int T, hipStream_t stream) {
   MCEDM_REQUIRE(B > 0 && heads > 0 && T > 0, "attention: empty shape");
   MCEDM_REQUIRE((long long)B * heads <= 65535, "attention: B*heads too large for grid.y");
   ProfScope ps("attention_kernel", 4.0 * B * heads * (double)T * T * 64, 4.0 * 4 * B * heads * 64.0 * T, stream);
-  hipLaunchKernelGGL(attention_kernel, dim3(ceil_div(T, 32), B * heads), dim3(64), 0, stream, qkv, out, T);
+  // the split factor is a function of T only (never of the batch size): results are identical under batch sharding
+  const dim3 grid(ceil_div(T, 32), B * heads);
+  if (attn_split_env() && T >= 256) hipLaunchKernelGGL(attention_split_kernel<4>, grid, dim3(256), 0, stream, qkv, out, T);
+  else if (attn_split_env() && T >= 128) hipLaunchKernelGGL(attention_split_kernel<2>, grid, dim3(128), 0, stream, qkv, out, T);
+  else hipLaunchKernelGGL(attention_kernel, grid, dim3(64), 0, stream, qkv, out, T);
   MCEDM_LAUNCH_CHECK("attention_kernel");
   return MCEDM_OK;
 }

@@ -200,6 +200,10 @@ def test_conv_every_tile_configuration(lib, tile, k):
     (2, 64, 64, 64, 32, 32, 3, 0, 0), (2, 64, 0, 64, 32, 32, 3, 1, 1), (2, 64, 0, 192, 8, 8, 1, 0, 0), (1, 128, 0, 384, 16, 16, 1, 0, 0),
     (2, 64, 0, 64, 16, 16, 1, 0, 0), (2, 24, 12, 64, 12, 10, 3, 0, 0), (3, 72, 0, 64, 8, 8, 3, 0, 0), (2, 40, 24, 96, 6, 8, 3, 0, 0),
     (5, 128, 128, 128, 8, 8, 3, 0, 1), (2, 64, 0, 2, 32, 32, 3, 0, 0), (3, 128, 0, 3, 24, 32, 3, 0, 0), (1, 72, 0, 64, 28, 30, 3, 0, 0), (2, 256, 0, 128, 16, 16, 3, 0, 0), (1, 320, 64, 64, 16, 16, 3, 0, 0), (2, 128, 128, 128, 32, 32, 3, 0, 0),
+    # big tiles (>= 64 x 64 images, one 64-channel output tile): 8 x 32 pixels at 64^2, 16 x 32 at 128^2; multi-pass K,
+    # virtual concat, ragged height, padded last chunk, residual at the output / half / double resolution
+    (2, 64, 0, 64, 64, 64, 3, 0, 0), (2, 64, 64, 64, 64, 64, 3, 0, 2), (1, 64, 0, 64, 128, 128, 3, 0, 0), (1, 64, 64, 64, 128, 128, 3, 0, 1),
+    (1, 72, 0, 64, 60, 72, 3, 0, 0), (1, 40, 24, 64, 136, 128, 3, 0, 0), (2, 4, 0, 64, 128, 128, 3, 0, 0),
 ])
 def test_conv_resident_kernel_is_bit_identical_to_the_tiled_one(lib, shape):
     """conv_resident.hip (whole K extent of the tile in LDS, DMA weight stream) against conv_mfma_kernel on the same tile
