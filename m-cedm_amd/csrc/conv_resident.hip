@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   float* wl = lds;                                  // [nslab][SL] ring of weight slabs (nslab = 3, or 2 when LDS is short)
   float* xl = lds + nslab * SG::SL;                 // [pass_c][PLANE] input tile of one pass: raw by DMA, then transformed in
                                                     // place; the projection's passes reuse it as [pass_c][NPIX], raw
-  Coef* cfl = reinterpret_cast<Coef*>(xl + pass_c * C::PLANE);      // this sample's Ca + Cb transform rows
+  // BIG tiles hold TWO pass tiles: the raw tile of pass p + 1 streams in by DMA under the MFMAs of pass p (a big-image
+  // launch is rounds of two workgroups per CU that run in lockstep, so nothing else would cover that latency)
+  constexpr int NBUF = C::BIG ? 2 : 1;
+  Coef* cfl = reinterpret_cast<Coef*>(xl + NBUF * pass_c * C::PLANE);      // this sample's Ca + Cb transform rows
+  int xoff = 0;                                     // float offset of the pass tile in use (0 / pass_c * PLANE)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -219,28 +223,29 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     nboff = 4u * ((unsigned)chsub * (unsigned)src_plane + o);
   }
   // requests channels [cb, cb + pc) of the (concatenated, possibly up-sampled) input
-  auto request_main = [&](int cb, int pc) {
+  auto request_main = [&](int cb, int pc, int dst) {           // dst: float offset of the destination tile inside xl
     const int cend = min(cb + pc, Cin);
+    const unsigned xl_dst = xl_base + 4u * (unsigned)dst;
     if constexpr (C::BIG) {                         // (channel, part) pairs round-robin over the waves; always wide
       for (int idx = wave; idx < (cend - cb) * C::NIC; idx += 4) {
         const int cl = idx / C::NIC, k = idx - cl * C::NIC, c0 = cb + cl;          // wave-uniform
         const float* plane = (c0 < Ca ? pa : pb) + (size_t)c0 * src_plane;
         unsigned off;
-        if (big_seg(k, off)) lds_dma16(plane, off, xl_base + 4u * (unsigned)(cl * C::PLANE + k * 256));
+        if (big_seg(k, off)) lds_dma16(plane, off, xl_dst + 4u * (unsigned)(cl * C::PLANE + k * 256));
       }
     } else if (wide) {                              // the launcher checks Ca % CPW == 0 and Cin % CPW == 0
       for (int c0 = cb + wave * C::CPW; c0 < cend; c0 += 4 * C::CPW) {
         const float* plane = (c0 < Ca ? pa : pb) + (size_t)c0 * src_plane;
-        if (wlane) lds_dma16(plane, wboff, xl_base + 4u * (unsigned)((c0 - cb) * C::PLANE));
+        if (wlane) lds_dma16(plane, wboff, xl_dst + 4u * (unsigned)((c0 - cb) * C::PLANE));
       }
     } else if (wave * 64 < CPS * C::PLANE) {        // Ca % CPS == 0 and Cin % CPS == 0; waves without an element issue nothing
       for (int c0 = cb; c0 < cend; c0 += CPS) {
         const float* plane = (c0 < Ca ? pa : pb) + (size_t)c0 * src_plane;
-        if (nactive) lds_dma4(plane, nboff, xl_base + 4u * (unsigned)((c0 - cb) * C::PLANE + wave * 64));
+        if (nactive) lds_dma4(plane, nboff, xl_dst + 4u * (unsigned)((c0 - cb) * C::PLANE + wave * 64));
       }
     }
     // channels that pad the last chunk: zeros (their packed weights are zero too, but LDS garbage may be NaN)
-    for (int e = (cend - cb) * C::PLANE + tid; e < pc * C::PLANE; e += C::NT) xl[e] = 0.f;
+    for (int e = (cend - cb) * C::PLANE + tid; e < pc * C::PLANE; e += C::NT) xl[dst + e] = 0.f;
   };
   // GroupNorm / FiLM / SiLU and the zero padding, in place, on PAIRS of horizontally adjacent elements (one 8-byte LDS
   // read and write per pair; the per-element arithmetic is apply_coef's).  Thread (tsub, r, pj)
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
 #pragma unroll
           for (int k = 0; k < C::NPP; ++k) {
             if (bact[k]) {
-              float* px = xl + (c - cb) * C::PLANE + bpos[k];
+              float* px = xl + xoff + (c - cb) * C::PLANE + bpos[k];
               float v0 = (px[0] - cf.mean) * cf.scale + cf.offset;
               float v1 = (px[1] - cf.mean) * cf.scale + cf.offset;
               if (ACT) { v0 = silu_f(v0); v1 = silu_f(v1); }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
 #pragma unroll 4
         for (int c = cb + tsub; c < cend; c += C::CPT) {
           const Coef cf = cfl[c];
-          float* px = xl + (c - cb) * C::PLANE + tpos;          // 8-byte aligned: one ds_read_b64 / ds_write_b64
+          float* px = xl + xoff + (c - cb) * C::PLANE + tpos;   // 8-byte aligned: one ds_read_b64 / ds_write_b64
           float v0 = (px[0] - cf.mean) * cf.scale + cf.offset;
           float v1 = (px[1] - cf.mean) * cf.scale + cf.offset;
           if (ACT) { v0 = silu_f(v0); v1 = silu_f(v1); }
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
     constexpr int T0 = decltype(t0_tag)::value, T1 = decltype(t1_tag)::value;
     const int cl = C::KS * ul + ks;
     const float* wc = wl + sc * SG::SL + ks * (SG::CROWS * C::MT);
-    const float* xc = xl + cl * C::KC * C::PLANE;
+    const float* xc = xl + xoff + cl * C::KC * C::PLANE;
     const float* nb; int nv4;
     const int kind = unit_src(u + dist, nb, nv4);
     if constexpr (C::KS == 1) {
@@ -390,8 +395,8 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   // passes the CU count, so the two workgroups that share a CU differ) takes a short FIRST pass.  Its matrix phase then
   // starts while its CU partner is still staging, and from there on one of them computes while the other re-stages.
   // The K sum visits the chunks in the same order either way.
-  const int first_c = (stagger > 0 && cin_pad > pass_c && ((blockIdx.x / stagger) & 1)) ? 16 : pass_c;
-  request_main(0, min(first_c, cin_pad));
+  const int first_c = (!C::BIG && stagger > 0 && cin_pad > pass_c && ((blockIdx.x / stagger) & 1)) ? 16 : pass_c;
+  request_main(0, min(first_c, cin_pad), 0);
   // accumulators = bias (+ residual), transform rows: under the first pass's DMA
   if (ks == 0) {
     if (m0 + C::MT <= p.Cout) {
@@ -414,11 +419,13 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   stage_coef_rows<C::NT>(p, n, cfl, tid);
   for (int cb = 0, pc = 0; cb < cin_pad; cb += pc) {
     pc = min(cb == 0 ? first_c : pass_c, cin_pad - cb);
-    if (cb > 0) request_main(cb, pc);               // (the barrier that ended the previous unit freed xl)
+    if (NBUF == 1 && cb > 0) request_main(cb, pc, 0);   // (the barrier that ended the previous unit freed xl)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's share of the tile (and every older DMA) has landed
     __syncthreads();                                // ... and everybody else's; first pass: transform rows visible
     transform_main(cb, pc);
     __syncthreads();
+    if (NBUF == 2 && cb + pc < cin_pad)             // the next pass's raw tile -> the other buffer, under this pass's MFMAs
+      request_main(cb + pc, min(pass_c, cin_pad - cb - pc), xoff ? 0 : pass_c * C::PLANE);
     if (cb == 0 && p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
     const int cmax = pc / C::KC;                    // chunks of this pass (the launcher makes passes whole units)
     for (int ul = 0; ul * C::KS < cmax; ++ul) {
@@ -429,6 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
         weight_unit(ul, cmax, std::integral_constant<int, 0>{}, std::integral_constant<int, C::TAPS>{});
       }
     }
+    if (NBUF == 2) xoff = xoff ? 0 : pass_c * C::PLANE;
   }
   // ---- passes over the folded projection's input: raw interior pixels, [channel][NPIX]
   if (Csk) {
@@ -455,8 +463,9 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
       const int yq = min(y0 + r, p.H - 1), xq = min(x0 + 4 * q, p.W - 4);
       qoff = 4u * (unsigned)((size_t)cq * plane + (size_t)yq * p.W + xq);
     }
-    for (int sb = 0; sb < Csk; sb += pass_c) {
-      const int pc = min(pass_c, Csk - sb);         // multiple of SKC
+    const int sk_pass = C::BIG ? (NBUF * pass_c * C::PLANE / C::NPIX) / SKC * SKC : pass_c;   // the launcher checks sk_pass >= SKC
+    for (int sb = 0; sb < Csk; sb += sk_pass) {
+      const int pc = min(sk_pass, Csk - sb);        // multiple of SKC
       if constexpr (LPQ > 64) {
         for (int idx = wave; idx < pc * NIQ; idx += 4) {
           const int cl = idx / NIQ, k = idx - cl * NIQ, c0 = sb + cl;
@@ -561,7 +570,7 @@ static int resident_level() {     // 0: off, > 0: on
 }
 
 static constexpr int LDS_MAX = 160 * 1024;
-// big-tile (>= 64 x 64 images) variants: MCEDM_RES_BIG=0 turns them off; MCEDM_RES_BIG_PASS = channels per pass (multiple of 16)
+// big-tile (>= 64 x 64 images) variants: MCEDM_RES_BIG=0 turns them off; MCEDM_RES_BIG_PASS = channels per pass (multiple of 8)
 static int big_level() {
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_RES_BIG"); env = e ? atoi(e) : 1; }
@@ -569,7 +578,7 @@ static int big_level() {
 }
 static int big_pass() {
   static int env = -1;
-  if (env < 0) { const char* e = getenv("MCEDM_RES_BIG_PASS"); env = (e && atoi(e) >= 16) ? atoi(e) / 16 * 16 : 1 << 20; }
+  if (env < 0) { const char* e = getenv("MCEDM_RES_BIG_PASS"); env = (e && atoi(e) >= 8) ? atoi(e) / 8 * 8 : 1 << 20; }
   return env;
 }
 
@@ -578,7 +587,7 @@ struct ResidentPlan { int pass_c = 0, nslab = 0, wide = 0; size_t lds = 0; };
 
 template <class C, bool SPLIT>
 static size_t resident_lds_bytes(const ConvArgs& a, int pass_c, int nslab) {
-  return sizeof(float) * ((size_t)nslab * SlabGeom<C, SPLIT>::SL + (size_t)pass_c * C::PLANE) + sizeof(Coef) * (size_t)(a.Ca + a.Cb);
+  return sizeof(float) * ((size_t)nslab * SlabGeom<C, SPLIT>::SL + (size_t)(C::BIG ? 2 : 1) * pass_c * C::PLANE) + sizeof(Coef) * (size_t)(a.Ca + a.Cb);
 }
 
 // Everything resident in one pass with a ring of 3 slabs when that fits `budget` bytes of LDS; otherwise as many channels
@@ -597,12 +606,15 @@ static ResidentPlan resident_plan(const ConvArgs& a, size_t budget, int min_pass
            (!Csk || (al16(a.sk_xa) && al16(a.sk_xb) && a.sk_Ca % CPQ == 0));
   if (!r.wide && (C::BIG || a.Ca % CPS || Cin % CPS || (Csk && a.sk_Ca % CPD))) { r.wide = 0; return r; }   // big tiles: row segments only
   const int need = std::max(ceil_div(Cin, C::KC) * C::KC, Csk);      // channels of the longest input (padded to chunks)
-  constexpr int G = C::KS * C::KC > 16 ? C::KS * C::KC : 16;         // a pass is whole K units of the conv and of the projection
+  // a pass is whole K units of the conv and of the projection; big tiles: whole chunks (their projection passes are sized
+  // separately in the kernel: both pass buffers together hold >= SKC channels of interior pixels)
+  constexpr int G = C::BIG ? C::KC : (C::KS * C::KC > 16 ? C::KS * C::KC : 16);
+  static_assert(!C::BIG || 2 * C::KC * C::PLANE >= SKC * C::NPIX, "projection chunk fits the two pass buffers");
   const int all = ceil_div(need, G) * G;
   for (int nslab = 3; nslab >= 2; --nslab) {
     const size_t fixed = resident_lds_bytes<C, SPLIT>(a, 0, nslab);
     if (fixed >= budget) continue;
-    int pc = (int)((budget - fixed) / (sizeof(float) * C::PLANE)) / G * G;
+    int pc = (int)((budget - fixed) / (sizeof(float) * C::PLANE * (C::BIG ? 2 : 1))) / G * G;
     if (pc > all) pc = all;
     if (pc >= std::min(min_pass, all)) { r.pass_c = pc; r.nslab = nslab; r.lds = resident_lds_bytes<C, SPLIT>(a, pc, nslab); return r; }
   }
@@ -699,11 +711,11 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
       // The pixel tile is a function of the image size only (batch-shard bit-identity).
       if ((long long)a.H * a.W >= 16384) {
         typedef ResCfg<64, 16, 32, 1, 4, 9, 8> B16;
-        ResidentPlan pl = resident_plan<B16, true>(a, half_cu, 16);
+        ResidentPlan pl = resident_plan<B16, true>(a, half_cu, 8);
         if (pl.pass_c && pl.nslab == 3 && pl.wide) { if (pl.pass_c > big_pass()) pl.pass_c = big_pass(); return launch_resident<B16, RS_NONE, true>(a, pl, stream); }
       } else {
         typedef ResCfg<64, 8, 32, 1, 4, 9, 8> B8;
-        ResidentPlan pl = resident_plan<B8, true>(a, half_cu, 16);
+        ResidentPlan pl = resident_plan<B8, true>(a, half_cu, 8);
         if (pl.pass_c && pl.nslab == 3 && pl.wide) { if (pl.pass_c > big_pass()) pl.pass_c = big_pass(); return launch_resident<B8, RS_NONE, true>(a, pl, stream); }
       }
     }
