@@ -95,7 +95,9 @@ struct SlabGeom {
   static_assert(C::NT % V4 == 0 && (ROWS_MAX * V4) % 64 == 0 && ROWS_MAX * V4 >= C::NT, "whole rows per step, whole waves");
   static_assert(!SPLIT || (C::KS == 1 && C::TAPS == 9 && ((C::TAPS - TSPLIT) * C::KC * V4) % 64 == 0), "split slabs are for 3x3");
   static_assert((CROWS * V4) % 64 == 0, "a chunk is whole waves of float4");
-  static_assert(ITU <= (SPLIT ? C::TAPS - TSPLIT : C::TAPS), "one DMA step per tap of a unit");
+  // one DMA step per tap of a unit; a unit with fewer taps than steps (the 128-channel tile's second half: 4 taps, 5 steps)
+  // issues the rest behind its last tap
+  static_assert(ITU <= (SPLIT ? C::TAPS - TSPLIT : C::TAPS) + 1, "DMA steps per unit");
 };
 
 template <class C, int RS, bool SPLIT>
@@ -103,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
                                                               int coutp, int nslab, int wide, int stagger) {
   static_assert(RS == RS_NONE || RS == RS_UP, "resampling modes of the resident kernel");
   static_assert(C::NT == 256 && C::NWAVE == 4 && C::CPI == 1, "four compute waves");
-  static_assert(SKC * C::MT / 4 <= C::NT && (SKC * C::MT / 4) % 64 == 0, "the projection's weight slab is one DMA step of whole waves");
+  // (the 128-channel tile does not take folded projections: the launcher sends those convs to conv_mfma_kernel)
+  static_assert(C::MT > 64 || (SKC * C::MT / 4 <= C::NT && (SKC * C::MT / 4) % 64 == 0), "the projection's weight slab is one DMA step of whole waves");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CPS = C::BIG ? 1 : C::NT / C::PLANE;   // narrow staging: input channels per step of the workgroup
   constexpr int CPD = C::BIG ? 1 : C::NT / C::NPIX;    // narrow staging of the projection's input: channels per step
@@ -362,6 +365,9 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
       __builtin_amdgcn_sched_barrier(0);
       mfma_chunk<C, true, false, T0, T1>(xc, wc, acc, aoff, boffm, [&](int t) {
         if (stream && t < SG::ITU) dma_step(t, nb, nv4, slab);
+        if constexpr (SG::ITU > T1 - T0) {
+          if (stream && t == T1 - T0 - 1) dma_step(T1 - T0, nb, nv4, slab);
+        }
       });
       finish_unit(stream ? SG::ITU : issued);
       return;
@@ -576,6 +582,11 @@ static int big_level() {
   if (env < 0) { const char* e = getenv("MCEDM_RES_BIG"); env = e ? atoi(e) : 1; }
   return env;
 }
+static int big128_level() {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_RES_BIG128"); env = e ? atoi(e) : 0; }
+  return env;
+}
 static int big_pass() {
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_RES_BIG_PASS"); env = (e && atoi(e) >= 8) ? atoi(e) / 8 * 8 : 1 << 20; }
@@ -718,6 +729,13 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
         ResidentPlan pl = resident_plan<B8, true>(a, half_cu, 8);
         if (pl.pass_c && pl.nslab == 3 && pl.wide) { if (pl.pass_c > big_pass()) pl.pass_c = big_pass(); return launch_resident<B8, RS_NONE, true>(a, pl, stream); }
       }
+    }
+    if ((long long)a.H * a.W >= 4096 && big128_level() > 0 && a.resample == RS_NONE && cout_padded(a.Cout) % 128 == 0 && !a.sk_wpk) {
+      // the same for 128-channel output tiles (ch = 128 networks: BASELINE config 3), 8 x 32 pixels, eight accumulator
+      // blocks per wave.  MCEDM_RES_BIG128: 0 off, 1 on
+      typedef ResCfg<128, 8, 32, 1, 4, 9, 8> B128;
+      ResidentPlan pl = resident_plan<B128, true>(a, half_cu, 8);
+      if (pl.pass_c && pl.wide) { if (pl.pass_c > big_pass()) pl.pass_c = big_pass(); return launch_resident<B128, RS_NONE, true>(a, pl, stream); }
     }
     return -1;
   }
