@@ -59,8 +59,13 @@ def build(force=False, verbose=True):
             f.write(dig)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(compile_one, jobs))
+    try:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            objs = list(ex.map(compile_one, jobs))
+    except subprocess.CalledProcessError:
+        if os.path.exists(LIB):
+            os.remove(LIB)          # never leave a library behind that is older than the sources it claims to be built from
+        raise
     if force or not os.path.exists(LIB) or any(not j[5] for j in jobs):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -182,25 +182,27 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
     if ((rc = dgrad(c, b.proj, dz, H, W, c.G(bl.a)))) return rc;
     if ((rc = launch_attention_bwd(c.T(bl.qkv), c.T(bl.a), c.G(bl.a), c.G(bl.qkv), c.X(c.S.lse), B, b.heads, H * W, c.s))) return rc;
     // qkv = conv1x1(norm2(y))   (rows in packed order)
-    WgradArgs wq{c.G(bl.qkv), c.T(bl.y), nullptr, b.cout, 0, c.CF(bl.coef2), 1, 0, RS_NONE, H, W, H, W, 3 * b.cout, B, wg, nullptr};
-    if ((rc = launch_wgrad(wq, 1, c.grads[b.qkv.w], c.grads[b.qkv.b], b.heads, c.X(c.S.xact), c.s))) return rc;
+    // order: data gradient -> GroupNorm backward (which also writes the conv's normalised input, the weight gradient's
+    // operand: no separate materialisation pass) -> weight gradient
     if ((rc = dgrad(c, b.qkv, c.G(bl.qkv), H, W, dact))) return rc;
     GnBwdArgs g2{dact, RS_NONE, c.T(bl.y), nullptr, b.cout, 0, H, W, B, b.norm2.groups, c.CF(bl.coef2), c.T(bl.stats2),
-                 c.pk + b.norm2.gamma, nullptr, 0, 0, 0, c.G(bl.y), nullptr, 0, dz, 1, b.cout, c.X(c.S.ab)};
+                 c.pk + b.norm2.gamma, nullptr, 0, 0, 0, c.G(bl.y), nullptr, 0, dz, 1, b.cout, c.X(c.S.ab), c.X(c.S.xact)};
     if ((rc = launch_gn_bwd(g2, c.s))) return rc;     // g[y] = dz (residual) + norm2 path
     if ((rc = norm_param_grads(c, b.norm2, nullptr, 0, nullptr))) return rc;
+    WgradArgs wq{c.G(bl.qkv), c.T(bl.y), nullptr, b.cout, 0, c.CF(bl.coef2), 1, 0, RS_NONE, H, W, H, W, 3 * b.cout, B, wg, nullptr};
+    if ((rc = launch_wgrad(wq, 1, c.grads[b.qkv.w], c.grads[b.qkv.b], b.heads, c.X(c.S.xact), c.s, true))) return rc;
     dy = c.G(bl.y);
   }
   // y = conv1(silu(film(norm1(h)))) + skip(x)
-  WgradArgs w1{dy, c.T(bl.h), nullptr, b.cout, 0, c.CF(bl.coef1), 1, 1, RS_NONE, H, W, H, W, b.cout, B, wg, nullptr};
-  if ((rc = launch_wgrad(w1, 9, c.grads[b.conv1.w], c.grads[b.conv1.b], 0, c.X(c.S.xact), c.s))) return rc;
   if ((rc = dgrad(c, b.conv1, dy, H, W, dact))) return rc;
   const float* film = reinterpret_cast<const float*>(c.act + c.L.t[c.L.film].off) + b.film_row0;
   GnBwdArgs g1{dact, RS_NONE, c.T(bl.h), nullptr, b.cout, 0, H, W, B, b.norm1.groups, c.CF(bl.coef1), c.T(bl.stats1),
                c.pk + b.norm1.gamma, film, c.n_noise > 1 ? 1 : 0, c.P.film_rows, 1, c.G(bl.h), nullptr, 0, nullptr, 0, 0,
-               c.X(c.S.ab)};
+               c.X(c.S.ab), c.X(c.S.xact)};
   if ((rc = launch_gn_bwd(g1, c.s))) return rc;
   if ((rc = norm_param_grads(c, b.norm1, film, c.P.film_rows, c.X(c.S.dfilm) + b.film_row0))) return rc;
+  WgradArgs w1{dy, c.T(bl.h), nullptr, b.cout, 0, c.CF(bl.coef1), 1, 1, RS_NONE, H, W, H, W, b.cout, B, wg, nullptr};
+  if ((rc = launch_wgrad(w1, 9, c.grads[b.conv1.w], c.grads[b.conv1.b], 0, c.X(c.S.xact), c.s, true))) return rc;
   // skip path -> extra gradient for x
   const float* add = dy;
   int add_mode = 1;
@@ -214,11 +216,13 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
     add_mode = 2;     // resample-only skip: map dy back through the same resampling
   }
   // h = conv0(resample(silu(norm0(x))))
+  const bool fuse0 = rs == RS_NONE;        // the un-resampled conv's operand comes out of the GroupNorm backward
   WgradArgs w0{c.G(bl.h), xa, xb, Ca, Cb, c.CF(bl.coef0), 1, 1, rs, bl.Hin, bl.Win, H, W, b.cout, B, wg, nullptr};
-  if ((rc = launch_wgrad(w0, 9, c.grads[b.conv0.w], c.grads[b.conv0.b], 0, c.X(c.S.xact), c.s))) return rc;
+  if (!fuse0 && (rc = launch_wgrad(w0, 9, c.grads[b.conv0.w], c.grads[b.conv0.b], 0, c.X(c.S.xact), c.s))) return rc;
   if ((rc = dgrad(c, b.conv0, c.G(bl.h), H, W, dact))) return rc;
   GnBwdArgs g0{dact, rs, xa, xb, Ca, Cb, bl.Hin, bl.Win, B, b.norm0.groups, c.CF(bl.coef0), c.T(bl.stats0),
-               c.pk + b.norm0.gamma, nullptr, 0, 0, 1, c.G(bl.xa), c.G(bl.xb), 0, add, add_mode, b.cin, c.X(c.S.ab)};
+               c.pk + b.norm0.gamma, nullptr, 0, 0, 1, c.G(bl.xa), c.G(bl.xb), 0, add, add_mode, b.cin, c.X(c.S.ab),
+               fuse0 ? c.X(c.S.xact) : nullptr};
   // both halves of a concat input share one accumulate flag: run the kernel once per distinct state
   const bool ha = c.have[bl.xa] != 0, hb = bl.xb >= 0 ? c.have[bl.xb] != 0 : ha;
   if (bl.xb >= 0 && ha != hb) {
@@ -233,6 +237,7 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
   c.have[bl.xa] = 1;
   if (bl.xb >= 0) c.have[bl.xb] = 1;
   if ((rc = norm_param_grads(c, b.norm0, nullptr, 0, nullptr))) return rc;
+  if (fuse0 && (rc = launch_wgrad(w0, 9, c.grads[b.conv0.w], c.grads[b.conv0.b], 0, c.X(c.S.xact), c.s, true))) return rc;
   // this block's affine layer (film = emb Waff^T + baff): dWaff[r][k] = sum_n dfilm[n][r] emb[n][k], dbaff[r] = sum_n dfilm[n][r].
   // Done here, not after the last block, so that the block's whole parameter range is complete (gradient buckets).
   const int ch = c.P.desc.ch, R = c.P.film_rows;

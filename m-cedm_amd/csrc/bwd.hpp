@@ -16,8 +16,10 @@ struct WgradArgs {
 };
 size_t wgrad_scratch_floats(int Cout, int Cin, int taps);
 // dw [Cout][Cin][kh][kw], db [Cout] (may be null).  qkv_heads > 0: dy rows are in packed qkv order.
-// act_tmp: scratch of B * (Ca+Cb) * H * W floats for the materialised conv input
-int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s);
+// act_tmp: scratch of B * (Ca+Cb) * H * W floats for the materialised conv input; have_act: act_tmp already holds it (written
+// by the GroupNorm backward of the same input, GnBwdArgs::xact: one pass over x less)
+int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s,
+                 bool have_act = false);
 // the materialisation step alone: out[B, Ca+Cb, H, W] = resample(act(coef(cat(xa, xb)))); dy / Cout / dwp are not read
 int launch_act_materialize(const WgradArgs& a, float* out, hipStream_t s);
 
@@ -39,6 +41,7 @@ struct GnBwdArgs {
   int add_mode;        // 1: [B, C, Hs, Ws] (source resolution); 2: conv resolution, mapped back like dact
   int add_C;           // channel count of `add` when add_mode == 2 (== C)
   float* ab;           // out [B][C][2]: sum(dt), sum(dt * xhat) per (sample, channel)
+  float* xact;         // optional out [B, C, Hs, Ws]: act(coef(x)), the conv's (un-resampled) input for its weight gradient
 };
 int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s);
 

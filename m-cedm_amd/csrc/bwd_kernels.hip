@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
     float* dx = (in_a ? a.dxa : a.dxb) + xo;
     const float* dpl = a.dact + ((size_t)n * C + c) * HWc;
     const float* addp = a.add ? a.add + ((size_t)n * C + c) * (a.add_mode == 2 ? HWc : HWs) : nullptr;
+    float* xq = a.xact ? a.xact + ((size_t)n * C + c) * HWs : nullptr;      // act(coef(x)): the conv's weight-gradient operand
     const Coef cf = a.coef[(size_t)n * C + c];
     if (vec) {
       const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
@@ -117,17 +118,25 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
       f32x4* o4 = reinterpret_cast<f32x4*>(dx);
       for (int p = tid; p < HWs / 4; p += 256) {
         const f32x4 xv = x4[p], dv = d4[p];
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        f32x4 o = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
         if (addp) o = a4[p];
         if (a.accumulate) { const f32x4 old = o4[p]; o += old; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float dt = dv[e];
-          if (a.act) dt *= dsilu((xv[e] - cf.mean) * cf.scale + cf.offset);
+          const float tt = (xv[e] - cf.mean) * cf.scale + cf.offset;
+          if (a.act) {
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-tt));     // dsilu and silu from one sigmoid
+            dt *= sg * (1.0f + tt * (1.0f - sg));
+            u[e] = tt * sg;
+          } else {
+            u[e] = tt;
+          }
           const float xh = (xv[e] - mean) * rstd;
           o[e] += cf.scale * dt - rstd * (m1 + xh * m2);
         }
         o4[p] = o;
+        if (xq) reinterpret_cast<f32x4*>(xq)[p] = u;
       }
       continue;
     }
@@ -135,12 +144,19 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
       const int ys = p / a.Ws, xs = p - ys * a.Ws;
       const float xv = x[p];
       float dt = fetch_resampled(dpl, a.resample, ys, xs, a.Ws);
-      if (a.act) dt *= dsilu((xv - cf.mean) * cf.scale + cf.offset);
+      const float tt = (xv - cf.mean) * cf.scale + cf.offset;
+      float uu = tt;
+      if (a.act) {
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-tt));
+        dt *= sg * (1.0f + tt * (1.0f - sg));
+        uu = tt * sg;
+      }
       const float xh = (xv - mean) * rstd;
       float v = cf.scale * dt - rstd * (m1 + xh * m2);      // cf.scale == rstd * g_c
       if (addp) v += (a.add_mode == 2) ? fetch_resampled(addp, a.resample, ys, xs, a.Ws) : addp[p];
       if (a.accumulate) v += dx[p];
       dx[p] = v;
+      if (xq) xq[p] = uu;
     }
   }
 }
@@ -150,6 +166,7 @@ int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
   MCEDM_REQUIRE(a.groups > 0 && C % a.groups == 0 && C / a.groups <= GN_MAX_CPG, "gn_bwd: bad groups (C=%d groups=%d)", C, a.groups);
   MCEDM_REQUIRE(a.dact && a.xa && a.coef && a.stats && a.gamma && a.dxa && a.ab && (a.Cb == 0 || (a.xb && a.dxb)), "gn_bwd: null pointer");
   MCEDM_REQUIRE(a.resample != RS_DOWN || (a.Hs % 2 == 0 && a.Ws % 2 == 0), "gn_bwd: odd source size for a 2x2 mean");
+  MCEDM_REQUIRE(!a.xact || a.resample == RS_NONE, "gn_bwd: the activated input is emitted for un-resampled convs only");
   ProfScope ps("gn_bwd_kernel", 20.0 * a.B * (double)C * a.Hs * a.Ws, 4.0 * 3 * a.B * (double)C * a.Hs * a.Ws, s);
   hipLaunchKernelGGL(gn_bwd_kernel, dim3(a.B * a.groups), dim3(256), 0, s, a);
   MCEDM_LAUNCH_CHECK("gn_bwd_kernel");
@@ -213,9 +230,39 @@ __global__ void small_gemm_kernel(const float* __restrict__ A, const float* __re
   *o = acc ? *o + s : s;
 }
 
+// the same with the K loop spread over the 64 lanes of a wave (one wave per output element, fixed-order butterfly): for
+// the long contractions of the embedding backward (K = all affine rows: 3840 at ch = 128), where one thread per output
+// is a chain of K dependent loads on 4096 threads
+__global__ __launch_bounds__(256) void small_gemm_wave_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                              float* __restrict__ Cm, int M, int N, int K, int lda, int ldb,
+                                                              int ldc, int tA, int tB, int acc) {
+  const size_t i = blockIdx.x * (size_t)4 + (threadIdx.x >> 6);
+  if (i >= (size_t)M * N) return;
+  const int lane = threadIdx.x & 63;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float av = tA ? A[(size_t)k * lda + m] : A[(size_t)m * lda + k];
+    const float bv = tB ? Bm[(size_t)n * ldb + k] : Bm[(size_t)k * ldb + n];
+    s = fmaf(av, bv, s);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) {
+    float* o = Cm + (size_t)m * ldc + n;
+    *o = acc ? *o + s : s;
+  }
+}
+
 int launch_small_gemm(const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc,
                       int transA, int transB, int accumulate, hipStream_t s) {
   const size_t total = (size_t)M * N;
+  if (K >= 256) {
+    hipLaunchKernelGGL(small_gemm_wave_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, A, Bm, Cm, M, N, K, lda, ldb,
+                       ldc, transA, transB, accumulate);
+    MCEDM_LAUNCH_CHECK("small_gemm_wave_kernel");
+    return MCEDM_OK;
+  }
   hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, Bm, Cm, M, N, K, lda,
                      ldb, ldc, transA, transB, accumulate);
   MCEDM_LAUNCH_CHECK("small_gemm_kernel");

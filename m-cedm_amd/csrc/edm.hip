@@ -316,6 +316,43 @@ __global__ void noise_inputs_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+// ---- deterministic grid-wide sums (loss, gradient norm) ---------------------------------------------------------
+// Every block stores its partial sum (fp64) in a slot of a library-owned device array, takes a ticket, and the block that
+// draws the LAST ticket adds the slots in index order: the value does not depend on the order the blocks ran in (an
+// atomicAdd of the partials would make the loss, the clip factor and with them the whole training run differ in the last
+// bits from run to run).  One array per kernel; calls on ONE stream at a time per device (the library's contract:
+// one process per GPU, one stream), the ticket is back at zero when the kernel ends.
+constexpr int RED_MAX = 4096;
+__device__ double g_red_part[2][RED_MAX];
+__device__ unsigned g_red_ticket[2];
+
+// block_sum: this block's partial in thread 0.  Returns true in every thread of the LAST block, with the total in *total
+// (thread 0 only).
+__device__ __forceinline__ bool grid_sum_fixed_order(int which, double block_sum, unsigned bid, unsigned nblocks, double* total) {
+  __shared__ unsigned s_last;
+  __shared__ double s_red[4];
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&g_red_part[which][bid], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = (atomicAdd(&g_red_ticket[which], 1u) == nblocks - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return false;
+  __threadfence();
+  double t = 0.0;
+  for (unsigned i = threadIdx.x; i < nblocks; i += blockDim.x)      // fixed assignment of slots to threads
+    t += __hip_atomic_load(&g_red_part[which][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *total = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    g_red_ticket[which] = 0u;
+  }
+  return true;
+}
+
 // loss = mean_b sum_chw w_b*(D*m - x*m)^2 ; dD = (2 w_b / B) * (D*m - x*m) * m   (mcedm.py:278, losses.py:48-53)
 __global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__ D, const float* __restrict__ x,
                                                        const float* __restrict__ mask, const float* __restrict__ sigma,
@@ -338,7 +375,10 @@ __global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__
   __shared__ double red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)B));
+  double total;
+  if (grid_sum_fixed_order(0, (red[0] + red[1]) + (red[2] + red[3]), blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, &total) &&
+      threadIdx.x == 0)
+    *loss = (float)(total / (double)B);
 }
 
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, double* __restrict__ out) {
@@ -356,7 +396,8 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   __shared__ double red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+  double total;
+  if (grid_sum_fixed_order(1, (red[0] + red[1]) + (red[2] + red[3]), blockIdx.x, gridDim.x, &total) && threadIdx.x == 0) *out = total;
 }
 
 // torch.optim.Adam (no amsgrad) on clipped grads, then EmaModel.update (ddim_blocks.py:44-54).
@@ -407,9 +448,10 @@ extern "C" int mcedm_edm_loss(const float* D, const float* x, const float* mask,
   MCEDM_REQUIRE(D && x && sigma && loss_out, "edm_loss: null pointer");
   MCEDM_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0, "edm_loss: bad shape");
   const size_t per = (size_t)C * H * W;
-  MCEDM_HIP_TRY(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
+  MCEDM_REQUIRE(B <= RED_MAX, "edm_loss: batch %d exceeds the reduction table (%d)", B, RED_MAX);
   int gx = (int)((per + 255) / 256);
   if (gx > 64) gx = 64;
+  if (gx > RED_MAX / B) gx = RED_MAX / B;            // one slot of the fixed-order reduction per block
   hipLaunchKernelGGL(edm_loss_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, D, x, mask, sigma,
                      (float)sigma_data, B, per, loss_out, dD_out);
   MCEDM_LAUNCH_CHECK("edm_loss_kernel");
@@ -418,9 +460,10 @@ extern "C" int mcedm_edm_loss(const float* D, const float* x, const float* mask,
 
 extern "C" int mcedm_sqnorm(const float* g, size_t n, double* sqnorm_out, void* stream) {
   MCEDM_REQUIRE(g && sqnorm_out, "sqnorm: null pointer");
-  MCEDM_HIP_TRY(hipMemsetAsync(sqnorm_out, 0, sizeof(double), (hipStream_t)stream));
-  if (n == 0) return MCEDM_OK;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm_out);
+  if (n == 0) { MCEDM_HIP_TRY(hipMemsetAsync(sqnorm_out, 0, sizeof(double), (hipStream_t)stream)); return MCEDM_OK; }
+  int blocks = grid_for(n);
+  if (blocks > RED_MAX) blocks = RED_MAX;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm_out);
   MCEDM_LAUNCH_CHECK("sqnorm_kernel");
   return MCEDM_OK;
 }

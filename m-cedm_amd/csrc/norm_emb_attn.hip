@@ -390,7 +390,6 @@ __global__ __launch_bounds__(64 * KW) __attribute__((amdgpu_waves_per_eu(3, 3)))
   const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
   const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
   const int q = q0 + l31;
-  const int qc = q < T ? q : T - 1;
 
   // the query tile, scaled, in LDS: the KW waves of the workgroup share it (kept in registers it costs each wave 32 VGPRs,
   // and the kernel must stay under 170 to run three waves per SIMD)

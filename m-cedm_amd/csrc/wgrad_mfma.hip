@@ -7,10 +7,11 @@
 // Two steps: (1) X' is materialised once by an elementwise kernel at HBM speed; (2) the GEMM kernel stages plain rows.
 // GEMM view per tap: D[co][ci] += A[co][pixel] * B[pixel][ci]; the contraction runs over pixels (2 per MFMA).
 // A workgroup owns a 64 (co) x 64 (ci) block of dW for all taps (4 waves x one 32x32 tile x TAPS accumulators)
-// and walks a strided subset of the 64-pixel tiles of the batch (split-K); partial sums are added into a
-// [tap][CoP][CiP] fp32 scratch with float atomics (ci contiguous: two 128-B segments per wave-instruction), which
-// wgrad_finish_kernel converts to the reference [co][ci][kh][kw] layout.  The block with ci-tile 0 also sums its
-// dY tiles over pixels: that is the bias gradient.
+// and walks a contiguous run of the 64-pixel tiles of the batch (split-K).  NO ATOMICS: every split stores its partial
+// block into its own slice of a [split][tap][CoP][CiP] fp32 scratch (ci contiguous: two 128-B segments per
+// wave-instruction) and wgrad_reduce_kernel adds the slices in split order in fp64 and writes the reference
+// [co][ci][kh][kw] layout, so the gradients (and with them a training run) are bitwise reproducible.  The block with
+// ci-tile 0 also sums its dY tiles over pixels: that is the bias gradient, reduced the same way.
 #include "common.hpp"
 #include "prof.hpp"
 #include "bwd.hpp"
@@ -287,58 +288,82 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, const float*
     }
     __syncthreads();
   }
-  // ---- add the partial block into the [tap][CoP][CiP] scratch
+  // ---- this split's partial block -> its own slice of the [split][tap][CoP][CiP] scratch (plain stores)
   const int ci = ci0 + ni * 32 + l31;
+  float* slice = p.dwp + (size_t)split * C::TAPS * cop * cip;
 #pragma unroll
   for (int tap = 0; tap < C::TAPS; ++tap)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (co < p.Cout && ci < Cin) atomicAdd(p.dwp + ((size_t)tap * cop + co) * cip + ci, acc[tap][r]);
+      if (co < p.Cout && ci < Cin) slice[((size_t)tap * cop + co) * cip + ci] = acc[tap][r];
     }
-  if (it == 0 && tid < C::CT && co0 + tid < p.Cout && p.dbp) atomicAdd(p.dbp + co0 + tid, bsum);
+  if (it == 0 && tid < C::CT && co0 + tid < p.Cout && p.dbp) p.dbp[(size_t)split * cop + co0 + tid] = bsum;
 }
 
-// grads in the reference layout: dW[co][ci][tap] = scratch[tap][perm(co)][ci]; db[co] = scratch_b[perm(co)].
+// Fixed-order reduction of the split slices and conversion to the reference layout:
+//   dW[co][ci][tap] = sum_s scratch[s][tap][perm(co)][ci]   (s = 0 .. nact-1 in order, fp64);  db[co] = sum_s scratch_b[s][perm(co)].
+// One thread per scratch element (ci fastest: the nact reads of a wave are whole 256-byte segments).
 // qkv_heads > 0: scratch rows are in packed (head, {q,k,v}, c) order, the parameter in (head, c, {q,k,v}) order.
-__global__ void wgrad_finish_kernel(const float* __restrict__ dwp, const float* __restrict__ dbp, float* __restrict__ dw,
-                                    float* __restrict__ db, int Cout, int Cin, int taps, int cop, int cip,
+__global__ void wgrad_reduce_kernel(const float* __restrict__ dwp, const float* __restrict__ dbp, float* __restrict__ dw,
+                                    float* __restrict__ db, int Cout, int Cin, int taps, int cop, int cip, int nact,
                                     int qkv_heads) {
-  const size_t total = (size_t)Cout * Cin * taps;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total + Cout; i += (size_t)gridDim.x * blockDim.x) {
-    const bool is_b = i >= total;
-    const int co = is_b ? (int)(i - total) : (int)(i / ((size_t)Cin * taps));
-    int cp = co;       // packed row holding reference row `co`
+  const size_t block = (size_t)taps * cop * cip;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < block + cop; i += (size_t)gridDim.x * blockDim.x) {
+    const bool is_b = i >= block;
+    const int cp = is_b ? (int)(i - block) : (int)((i / cip) % cop);       // packed row
+    if (cp >= Cout) continue;
+    int co = cp;                                                            // reference row held by packed row cp
     if (qkv_heads > 0) {
       const int per = Cout / qkv_heads, d = per / 3;
-      const int hh = co / per, rr = co % per, c = rr / 3, which = rr % 3;
-      cp = hh * per + which * d + c;
+      const int hh = cp / per, rr = cp % per, which = rr / d, c = rr % d;
+      co = hh * per + c * 3 + which;
     }
     if (is_b) {
-      if (db) db[co] = dbp[cp];
+      if (!db) continue;
+      double sum = 0.0;
+      for (int sp = 0; sp < nact; ++sp) sum += (double)dbp[(size_t)sp * cop + cp];
+      db[co] = (float)sum;
     } else {
-      const size_t rem = i % ((size_t)Cin * taps);
-      const int ci = (int)(rem / taps), tap = (int)(rem % taps);
-      dw[i] = dwp[((size_t)tap * cop + cp) * cip + ci];
+      const int ci = (int)(i % cip), tap = (int)(i / ((size_t)cop * cip));
+      if (ci >= Cin) continue;
+      // four interleaved chains (slices s = j mod 4), combined in a fixed order: the loads of a chain step are independent
+      // and stay in flight together
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int sp = 0;
+      for (; sp + 4 <= nact; sp += 4) {
+        const float v0 = dwp[(size_t)sp * block + i], v1 = dwp[(size_t)(sp + 1) * block + i];
+        const float v2 = dwp[(size_t)(sp + 2) * block + i], v3 = dwp[(size_t)(sp + 3) * block + i];
+        s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+      }
+      for (; sp < nact; ++sp) s0 += (double)dwp[(size_t)sp * block + i];
+      dw[((size_t)co * Cin + ci) * taps + tap] = (float)((s0 + s1) + (s2 + s3));
     }
   }
 }
 
+// split slices: at most 512 workgroups per launch, each with its own [taps][64][64] block (+ 64 bias partials)
+static int wgrad_nsplit_max(int Cout, int Cin) {
+  const int blocks = ceil_div(Cout, 64) * ceil_div(Cin, 64);
+  return blocks >= 512 ? 1 : 512 / blocks;
+}
 size_t wgrad_scratch_floats(int Cout, int Cin, int taps) {
   const size_t cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
-  return taps * cop * cip + cop;
+  return (size_t)wgrad_nsplit_max(Cout, Cin) * (taps * cop * cip + cop);
 }
 
 template <class C>
-static int launch_wg(const WgradArgs& a, const float* xact, hipStream_t s) {
+static int launch_wg(const WgradArgs& a, const float* xact, int* nact, hipStream_t s) {
   const int tiles_x = ceil_div(a.W, C::PW), tiles_y = ceil_div(a.H, C::PH);
   const int ctiles = ceil_div(a.Cout, C::CT), itiles = ceil_div(a.Ca + a.Cb, C::IT);
   const int ntiles = a.B * tiles_x * tiles_y;
-  // one full round of resident workgroups (256 CUs x 2): a 1.5-round grid wastes a quarter of the machine
-  int nsplit = 512 / (ctiles * itiles);
+  // one full round of resident workgroups (256 CUs x 2): a 1.5-round grid wastes a quarter of the machine.
+  // The split factor depends on the conv's shape and the tile count only: same shapes -> same bits.
+  int nsplit = wgrad_nsplit_max(a.Cout, a.Ca + a.Cb);
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
   const int cop = ctiles * 64, cip = itiles * 64;
+  if (nact) *nact = ceil_div(ntiles, ceil_div(ntiles, nsplit));     // splits that own at least one tile (the others do not store)
   char name[64] = "";
   if (prof_enabled()) snprintf(name, sizeof(name), "wgrad_kernel<WgCfg<%d, %d, %d>>", C::PH, C::PW, C::TAPS);
   const double flops = 2.0 * a.B * a.H * (double)a.W * a.Cout * (a.Ca + a.Cb) * C::TAPS;
@@ -368,31 +393,31 @@ int launch_act_materialize(const WgradArgs& a, float* out, hipStream_t s) {
 }
 
 // act_tmp: B * Cin * H * W floats (the materialised conv input)
-int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s) {
+int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s, bool have_act) {
   MCEDM_REQUIRE(taps == 9 || taps == 1, "wgrad: taps must be 9 or 1");
   MCEDM_REQUIRE(a.dy && a.dwp && dw && act_tmp, "wgrad: null pointer");
   const int Cin = a.Ca + a.Cb;
   const size_t cop = (a.Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
   WgradArgs b = a;
-  b.dbp = a.dwp + taps * cop * cip;
-  MCEDM_HIP_TRY(hipMemsetAsync(a.dwp, 0, wgrad_scratch_floats(a.Cout, Cin, taps) * sizeof(float), s));
-  int rc;
-  if ((rc = launch_act_materialize(a, act_tmp, s))) return rc;
+  b.dbp = a.dwp + (size_t)wgrad_nsplit_max(a.Cout, Cin) * taps * cop * cip;      // [split][CoP] bias partials behind the slices
+  int rc, nact = 1;
+  if (!have_act && (rc = launch_act_materialize(a, act_tmp, s))) return rc;
   if (taps == 9) {
-    if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 9>>(b, act_tmp, s);
-    else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 9>>(b, act_tmp, s);
-    else rc = launch_wg<WgCfg<8, 8, 9>>(b, act_tmp, s);
+    if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 9>>(b, act_tmp, &nact, s);
+    else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 9>>(b, act_tmp, &nact, s);
+    else rc = launch_wg<WgCfg<8, 8, 9>>(b, act_tmp, &nact, s);
   } else {
-    if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 1>>(b, act_tmp, s);
-    else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 1>>(b, act_tmp, s);
-    else rc = launch_wg<WgCfg<8, 8, 1>>(b, act_tmp, s);
+    if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 1>>(b, act_tmp, &nact, s);
+    else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 1>>(b, act_tmp, &nact, s);
+    else rc = launch_wg<WgCfg<8, 8, 1>>(b, act_tmp, &nact, s);
   }
   if (rc) return rc;
-  const size_t total = (size_t)a.Cout * Cin * taps + a.Cout;
-  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(256), 0, s, a.dwp, b.dbp, dw, db, a.Cout, Cin, taps, (int)cop,
-                     (int)cip, qkv_heads);
-  MCEDM_LAUNCH_CHECK("wgrad_finish_kernel");
+  const size_t total = (size_t)taps * cop * cip + cop;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  ProfScope ps("wgrad_reduce_kernel", (double)nact * total, 4.0 * ((double)nact + 1.0) * total, s);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.dwp, b.dbp, dw, db, a.Cout, Cin, taps, (int)cop,
+                     (int)cip, nact, qkv_heads);
+  MCEDM_LAUNCH_CHECK("wgrad_reduce_kernel");
   return MCEDM_OK;
 }
 

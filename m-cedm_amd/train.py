@@ -14,12 +14,14 @@ One process per GPU.  Per step (models/mcedm.py:254-281 + Lightning's DDP / clip
 The flat layout is the parameter order of ``DhariwalUNet.state_dict()``; each ``nn.Parameter`` of the model (and of the
 EMA copy) is re-pointed to a view of the flat buffer, so ``state_dict()`` / checkpoints are unchanged.
 
-Reproducibility: the weight-gradient kernel accumulates its split-K partial sums with fp32 atomics
-(csrc/wgrad_mfma.hip), so TRAINING gradients differ in the last bits from run to run and between shardings; only the
-inference / sampling path is bit-identical under batch sharding (tests/test_hip_fullsize.py).
+Reproducibility: no kernel of the step uses atomics -- the weight-gradient kernel's split-K partial blocks are stored per
+split and reduced in a fixed order (csrc/wgrad_mfma.hip) -- so the same inputs give the same bits, run after run
+(tests/test_hip_backward.py::test_training_step_is_bitwise_reproducible); inference / sampling is additionally
+bit-identical under batch sharding (tests/test_hip_fullsize.py).
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -153,16 +155,66 @@ class FlatTrainState:
         self.packed = packed
         self.world = _world()
         self.sync = GradSync(self.flat_g, [t.numel() for t in tens], plan.grad_buckets(max_buckets if self.world > 1 else 1))
+        self.use_graph = os.environ.get("MCEDM_TRAIN_GRAPH", "1") != "0"
+        self._graph = None
 
-    def step(self, x, cond_in, mask, noise, rnd_normal):
-        """One optimisation step on this rank's shard (all tensors NCHW fp32 on the device). Returns the local loss."""
+    def _forward_backward(self, x, cond_in, mask, noise, rnd_normal):
+        """pack -> noise -> denoise(training) -> loss -> backward into the flat gradient buffer; returns the loss tensor."""
         plan = self.plan
         self.packed = plan.pack(self.pviews, self.packed)
         x_noise, sigma = _lib.edm_noise_inputs(x, mask, noise, rnd_normal.reshape(-1).contiguous(), self.P_mean, self.P_std)
         D = plan.denoise(self.packed, x_noise, sigma, cond=cond_in, ws=self.ws, training=True, sigma_data=self.sigma_data)
         loss, dD = _lib.edm_loss(D, x, mask, sigma, sigma_data=self.sigma_data, want_grad=True)
+        multi = self.world > 1             # bucket events only where a side stream waits for them
         plan.denoise_backward(self.packed, self.pviews, x_noise, sigma, cond_in, dD, self.grad_views, self.ws,
-                              sigma_data=self.sigma_data, bucket_first=self.sync.bucket_first, bucket_events=self.sync.events)
+                              sigma_data=self.sigma_data, bucket_first=self.sync.bucket_first if multi else None,
+                              bucket_events=self.sync.events if multi else None)
+        return loss
+
+    def _graphed_forward_backward(self, x, cond_in, mask, noise, rnd_normal):
+        """Single-GPU steps replay the ~300 launches of the forward + backward from ONE HIP graph (the library never
+        allocates or synchronises, every scalar of these kernels is shape-derived): inputs are copied into static buffers,
+        the loss comes back in a static tensor.  Kept per input shape; a failed capture falls back to eager launches.
+        (Multi-rank steps stay eager: the bucket events and the side-stream all-reduce are issued around the backward.)"""
+        ins = (x, cond_in, mask, noise, rnd_normal)
+        key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in ins)
+        if self._graph is None or self._graph[0] != key:
+            self._graph = None
+            static = [torch.empty_like(t) if t is not None else None for t in ins]
+            for d, t in zip(static, ins):
+                if d is not None:
+                    d.copy_(t)
+            holder = {}
+
+            def run():
+                holder["loss"] = self._forward_backward(*static)
+            try:
+                self.packed = self.plan.pack(self.pviews, self.packed)         # allocated outside the capture
+                self.ws.get(self.plan.workspace_bytes(x.shape[0], x.shape[2], x.shape[3], True), x.device)
+                g = _lib._capture(run, x.device)
+            except RuntimeError as e:                                          # pragma: no cover - needs a capture failure
+                import warnings
+                warnings.warn(f"HIP-graph capture of the training step failed ({str(e)[:200]}); launching it eagerly")
+                torch.cuda.synchronize()
+                self._graph = (key, None, None, None)
+                return self._forward_backward(*ins)
+            self._graph = (key, g, static, holder["loss"])
+        _, g, static, loss = self._graph
+        if g is None:
+            return self._forward_backward(*ins)
+        for d, t in zip(static, ins):
+            if d is not None:
+                d.copy_(t)
+        g.replay()
+        return loss
+
+    def step(self, x, cond_in, mask, noise, rnd_normal):
+        """One optimisation step on this rank's shard (all tensors NCHW fp32 on the device). Returns the local loss (a
+        tensor that the next step overwrites when the step is graph-replayed)."""
+        if self.use_graph and self.world == 1 and x.is_cuda:
+            loss = self._graphed_forward_backward(x, cond_in, mask, noise, rnd_normal)
+        else:
+            loss = self._forward_backward(x, cond_in, mask, noise, rnd_normal)
         self.sync.launch()                 # bucketed sum all-reduce, overlapping the tail of the backward
         self.sync.join()
         self.step_count += 1

@@ -256,3 +256,26 @@ def test_inference_forward_wide_multipliers_vs_oracle(lib):
     with torch.no_grad():
         ref = orc.model_precond(P, CFG_M, x, sigma, cond)
     close(D, ref, what="denoised (config M)")
+
+
+def test_training_step_is_bitwise_reproducible(lib):
+    """No atomics anywhere in the step (wgrad stores one partial block per split and reduces them in a fixed order): the same
+    batch gives the same loss and the same gradients, bit for bit, run after run -- at a size where the split-K is wide
+    (ch = 128, 64 x 64: 128 splits per conv)."""
+    cfg = fx.CFG_W
+    B, H, W = 4, 64, 64
+    tag = "t/bwd/repro"
+    P = orc.make_params(cfg, 3)
+    xc = fx.randn(tag + "/x", B, 2, H, W)
+    mc = torch.zeros(B, 2, H, W)
+    mc[:, 1] = 1
+    cond_in = xc * (1 - mc) + fx.randn(tag + "/cn", B, 2, H, W) * mc
+    noise = fx.randn(tag + "/noise", B, 2, H, W)
+    rnd_normal = fx.randn(tag + "/rnd", B, 1, 1, 1)
+    runs = [run_training_step(lib, cfg, P, xc, cond_in, mc, noise, rnd_normal) for _ in range(3)]
+    plan, loss0, g0 = runs[0]
+    for _, loss, g in runs[1:]:
+        assert torch.equal(loss, loss0)
+        for n in plan.param_names:
+            assert torch.equal(g[n], g0[n]), n
+    assert all(bool(torch.isfinite(v).all()) for v in g0.values())
