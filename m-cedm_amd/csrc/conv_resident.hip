@@ -49,9 +49,13 @@ static constexpr int SKC = 16;      // channels per K chunk of the folded projec
 // KS-th K chunk each; the partial accumulators meet in LDS before the epilogue.  It makes the tile small enough
 // (32 channels x 4 x 8 pixels) for 8 x 8 images to spread over 256 workgroups instead of 64, with a quarter of the
 // dependent MFMA chain per wave.
-template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_, int KS_ = 1>
+// DB: the pass tile is double-buffered (two tiles of pass_c channels: the raw tile of pass p + 1 arrives by DMA under the
+// MFMAs of pass p) and the passes are kept short, so the K loop starts after the first 16 channels have landed instead of
+// after all of them; the K sum runs in the same order.
+template <int MT_, int PH_, int PW_, int WM_, int WN_, int TAPS_, int KC_, int KS_ = 1, int DB_ = 0>
 struct ResCfg {
   static constexpr int MT = MT_, PH = PH_, PW = PW_, WM = WM_, WN = WN_, TAPS = TAPS_, KC = KC_, KS = KS_;
+  static constexpr bool DB = DB_ != 0;
   static constexpr int CPI = 1, KCI = KC_, NT = 256;
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
   static constexpr int XL0 = HALO ? 3 : 0;                  // layout column of tile column -HALO
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
                                                     // place; the projection's passes reuse it as [pass_c][NPIX], raw
   // BIG tiles hold TWO pass tiles: the raw tile of pass p + 1 streams in by DMA under the MFMAs of pass p (a big-image
   // launch is rounds of two workgroups per CU that run in lockstep, so nothing else would cover that latency)
-  constexpr int NBUF = C::BIG ? 2 : 1;
+  constexpr int NBUF = (C::BIG || C::DB) ? 2 : 1;
   Coef* cfl = reinterpret_cast<Coef*>(xl + NBUF * pass_c * C::PLANE);      // this sample's Ca + Cb transform rows
   int xoff = 0;                                     // float offset of the pass tile in use (0 / pass_c * PLANE)
 
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
   // passes the CU count, so the two workgroups that share a CU differ) takes a short FIRST pass.  Its matrix phase then
   // starts while its CU partner is still staging, and from there on one of them computes while the other re-stages.
   // The K sum visits the chunks in the same order either way.
-  const int first_c = (!C::BIG && stagger > 0 && cin_pad > pass_c && ((blockIdx.x / stagger) & 1)) ? 16 : pass_c;
+  const int first_c = (NBUF == 1 && stagger > 0 && cin_pad > pass_c && ((blockIdx.x / stagger) & 1)) ? 16 : pass_c;
   request_main(0, min(first_c, cin_pad), 0);
   // accumulators = bias (+ residual), transform rows: under the first pass's DMA
   if (ks == 0) {
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
       const int yq = min(y0 + r, p.H - 1), xq = min(x0 + 4 * q, p.W - 4);
       qoff = 4u * (unsigned)((size_t)cq * plane + (size_t)yq * p.W + xq);
     }
-    const int sk_pass = C::BIG ? (NBUF * pass_c * C::PLANE / C::NPIX) / SKC * SKC : pass_c;   // the launcher checks sk_pass >= SKC
+    const int sk_pass = NBUF == 2 ? (NBUF * pass_c * C::PLANE / C::NPIX) / SKC * SKC : pass_c;   // >= SKC: pass_c * PLANE >= 16 * NPIX / 2
     for (int sb = 0; sb < Csk; sb += sk_pass) {
       const int pc = min(sk_pass, Csk - sb);        // multiple of SKC
       if constexpr (LPQ > 64) {
@@ -582,6 +586,11 @@ static int big_level() {
   if (env < 0) { const char* e = getenv("MCEDM_RES_BIG"); env = e ? atoi(e) : 1; }
   return env;
 }
+static int db_level() {          // MCEDM_RES_DB=1: double-buffered short passes at <= 32 x 32 (experiment)
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_RES_DB"); env = e ? atoi(e) : 0; }
+  return env;
+}
 static int big128_level() {
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_RES_BIG128"); env = e ? atoi(e) : 0; }
@@ -598,7 +607,7 @@ struct ResidentPlan { int pass_c = 0, nslab = 0, wide = 0; size_t lds = 0; };
 
 template <class C, bool SPLIT>
 static size_t resident_lds_bytes(const ConvArgs& a, int pass_c, int nslab) {
-  return sizeof(float) * ((size_t)nslab * SlabGeom<C, SPLIT>::SL + (size_t)(C::BIG ? 2 : 1) * pass_c * C::PLANE) + sizeof(Coef) * (size_t)(a.Ca + a.Cb);
+  return sizeof(float) * ((size_t)nslab * SlabGeom<C, SPLIT>::SL + (size_t)((C::BIG || C::DB) ? 2 : 1) * pass_c * C::PLANE) + sizeof(Coef) * (size_t)(a.Ca + a.Cb);
 }
 
 // Everything resident in one pass with a ring of 3 slabs when that fits `budget` bytes of LDS; otherwise as many channels
@@ -625,7 +634,7 @@ static ResidentPlan resident_plan(const ConvArgs& a, size_t budget, int min_pass
   for (int nslab = 3; nslab >= 2; --nslab) {
     const size_t fixed = resident_lds_bytes<C, SPLIT>(a, 0, nslab);
     if (fixed >= budget) continue;
-    int pc = (int)((budget - fixed) / (sizeof(float) * C::PLANE * (C::BIG ? 2 : 1))) / G * G;
+    int pc = (int)((budget - fixed) / (sizeof(float) * C::PLANE * ((C::BIG || C::DB) ? 2 : 1))) / G * G;
     if (pc > all) pc = all;
     if (pc >= std::min(min_pass, all)) { r.pass_c = pc; r.nslab = nslab; r.lds = resident_lds_bytes<C, SPLIT>(a, pc, nslab); return r; }
   }
@@ -657,8 +666,8 @@ static int launch_resident(const ConvArgs& a_in, const ResidentPlan& plan, hipSt
   }
   char name[96] = "";
   if (prof_enabled())
-    snprintf(name, sizeof(name), "conv_resident_kernel<ResCfg<%d, %d, %d, %d, %d, %d, %d, %d>, %d, %s>", C::MT, C::PH, C::PW, C::WM, C::WN,
-             C::TAPS, C::KC, C::KS, RS, SPLIT ? "true" : "false");
+    snprintf(name, sizeof(name), "conv_resident_kernel<ResCfg<%d, %d, %d, %d, %d, %d, %d, %d%s>, %d, %s>", C::MT, C::PH, C::PW, C::WM, C::WN,
+             C::TAPS, C::KC, C::KS, C::DB ? ", 1" : "", RS, SPLIT ? "true" : "false");
   const double px = (double)a.B * a.H * a.W;
   const double skc = a.sk_wpk ? (double)(a.sk_Ca + a.sk_Cb) : 0.0;
   const double flops = 2.0 * px * a.Cout * ((double)(a.Ca + a.Cb) * C::TAPS + skc);
@@ -692,6 +701,11 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
     }
     if (small) {          // <= 256 workgroups per 64 samples: one per CU, the whole LDS
       if (cout_padded(a.Cout) % 64 != 0) return -1;
+      if (db_level() > 0 && a.resample == RS_NONE) {     // short double-buffered passes: the K loop starts after 32 channels
+        typedef ResCfg<64, 8, 8, 2, 2, 9, 8, 1, 1> SD;
+        ResidentPlan pd = resident_plan<SD, false>(a, whole_cu, 32);
+        if (pd.pass_c && pd.nslab == 3) { if (pd.pass_c > 32) pd.pass_c = 32; return launch_resident<SD, RS_NONE>(a, pd, stream); }
+      }
       const ResidentPlan pl = resident_plan<S, false>(a, whole_cu, 64);
       if (!pl.pass_c) return -1;
       return a.resample == RS_UP ? launch_resident<S, RS_UP>(a, pl, stream) : launch_resident<S, RS_NONE>(a, pl, stream);
@@ -704,6 +718,11 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
         const ResidentPlan p32 = resident_plan<M32, true>(a, half_cu, 32);
         if (!p32.pass_c || p32.nslab != 3 || a.resample != RS_NONE) return -1;
         return launch_resident<M32, RS_NONE, true>(a, p32, stream);
+      }
+      if (db_level() > 0 && a.resample == RS_NONE) {     // 16-channel double-buffered passes
+        typedef ResCfg<64, 8, 16, 1, 4, 9, 8, 1, 1> MD;
+        ResidentPlan pd = resident_plan<MD, true>(a, half_cu, 16);
+        if (pd.pass_c && pd.nslab == 3 && pd.wide) { if (pd.pass_c > 16) pd.pass_c = 16; return launch_resident<MD, RS_NONE, true>(a, pd, stream); }
       }
       ResidentPlan pl = resident_plan<M, true>(a, half_cu, 32);
       if (!pl.pass_c || pl.nslab != 3) return -1;

@@ -405,8 +405,11 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
     lb.drop(bl.coef0); lb.drop(bl.xd);
     bl.coef1 = lb.coef(b.cout);
     if (training) bl.stats1 = lb.stats(b.norm1.groups);
-    // inference folds the 1x1 skip projection into conv1 (ConvArgs::sk_*): the projected tensor exists in training only
-    if (b.skip_kernel == 1 && (training || b.up || b.down)) bl.sk = lb.act(b.cout, bl.H, bl.W);
+    // the 1x1 skip projection is folded into conv1 (ConvArgs::sk_*) in inference AND in training: the backward never reads
+    // the projected tensor (its weight gradient takes dy and the block input, its data gradient dy alone), so it only
+    // exists for the resampling blocks, which the fold does not serve
+    (void)training;
+    if (b.skip_kernel == 1 && (b.up || b.down)) bl.sk = lb.act(b.cout, bl.H, bl.W);
     bl.y = lb.act(b.cout, bl.H, bl.W);
     give_sums(bl.y);
     lb.drop(bl.h); lb.drop(bl.coef1); lb.drop(bl.sk);

@@ -401,15 +401,18 @@ int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_hea
   WgradArgs b = a;
   b.dbp = a.dwp + (size_t)wgrad_nsplit_max(a.Cout, Cin) * taps * cop * cip;      // [split][CoP] bias partials behind the slices
   int rc, nact = 1;
-  if (!have_act && (rc = launch_act_materialize(a, act_tmp, s))) return rc;
+  // an un-transformed single-source input (the attention projection's) IS the operand: no copy
+  const bool plain = !have_act && !a.coef && !a.act && a.resample == RS_NONE && a.Cb == 0 && a.xa;
+  const float* xact = plain ? a.xa : act_tmp;
+  if (!have_act && !plain && (rc = launch_act_materialize(a, act_tmp, s))) return rc;
   if (taps == 9) {
-    if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 9>>(b, act_tmp, &nact, s);
-    else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 9>>(b, act_tmp, &nact, s);
-    else rc = launch_wg<WgCfg<8, 8, 9>>(b, act_tmp, &nact, s);
+    if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 9>>(b, xact, &nact, s);
+    else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 9>>(b, xact, &nact, s);
+    else rc = launch_wg<WgCfg<8, 8, 9>>(b, xact, &nact, s);
   } else {
-    if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 1>>(b, act_tmp, &nact, s);
-    else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 1>>(b, act_tmp, &nact, s);
-    else rc = launch_wg<WgCfg<8, 8, 1>>(b, act_tmp, &nact, s);
+    if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 1>>(b, xact, &nact, s);
+    else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 1>>(b, xact, &nact, s);
+    else rc = launch_wg<WgCfg<8, 8, 1>>(b, xact, &nact, s);
   }
   if (rc) return rc;
   const size_t total = (size_t)taps * cop * cip + cop;
