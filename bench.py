@@ -26,7 +26,9 @@ Workloads (BASELINE.json `configs`):
   s128l3  the same with the literal ch_mult [1,1,1] (attention only in the bottleneck block, SURVEY.md 8d "both ways")
   s32     SWE-periodic 32x32, ch=64, ch_mult [1,1,1], 64 states / GPU                                    (config 2)
   ref128  the reference's own adm_edm_mcedm_res32 network (ch=64) on 128x128 fields, 32 states / GPU
-The default run also reports s32 / ref128 / s128l3 as `secondary` entries (a few seconds each).
+  darcy128  the single-task conditional EDM (1 + 1 -> 1 channels, ch=128) on 128x128 Darcy-sized fields, 32 states / GPU (config 4)
+  repaint128  RePaint-style EDM sampling of the DDPM U-Net, 18 steps x 32 resampling loops, 32 states / GPU       (config 5)
+The default run also reports s32 / ref128 / s128l3 / darcy128 / repaint128 as `secondary` entries.
 """
 import argparse
 import hashlib
@@ -51,6 +53,10 @@ WORKLOADS = {
                 name="SWE-periodic 32x32, EDM U-Net ch=64 ch_mult=[1,1,1] (BASELINE config 2)"),
     "ref128": dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32,
                    name="SWE-periodic 128x128, reference adm_edm_mcedm_res32 U-Net ch=64"),
+    # BASELINE config 4 read as the single-task model (configs/model/adm_edm_cond_h_res32.yaml: a -> u, 1 + 1 -> 1 channels,
+    # PlCondEdm.sample_edm, no mask): 2 inputs x n_samples = 16 draws = 32 states per GPU
+    "darcy128": dict(ch=128, ch_mult=(1, 1, 1, 1), attn=(16,), H=128, W=128, batch=32, single=True,
+                     name="Darcy 128x128 conditional EDM (single-task U-Net ch=128, n_samples=16 x 2 inputs; BASELINE config 4)"),
 }
 # BASELINE config 5: RePaint-style EDM sampling of the joint DDPM (PlDdim.sample_edm, models/ddim.py:959-1051) with
 # configs/model/ddim_res32.yaml (DDPM U-Net ch=64, attention at 32^2) on 128x128 fields: u known for the first 64 time
@@ -227,16 +233,20 @@ class Runner:
         self.lib, self.torch = lib, torch
         wl = WORKLOADS[key]
         self.wl, self.B, self.H, self.W = wl, B or wl["batch"], wl["H"], wl["W"]
-        self.plan = lib.Plan(2, 2, 2, wl["ch"], wl["ch_mult"], 1, wl["attn"], 128)
+        single = bool(wl.get("single"))
+        nc = 1 if single else 2
+        self.plan = lib.Plan(nc, nc, nc, wl["ch"], wl["ch_mult"], 1, wl["attn"], 128)
         self.params = synth_params(self.plan, 7, device)
         self.packed = self.plan.pack(self.params)
         self.cond, self.mask, self.init = synth_inputs(self.B, self.H, self.W, 1000 + rank, device)
+        if single:      # conditioning field a (observed), state u generated everywhere: no mask (models/ddim.py:1532-1601)
+            self.cond, self.mask, self.init = self.cond[:, :1].contiguous(), None, self.init[:, :1].contiguous()
 
         class SP:      # configs/diff_sampler/edm_sampler.yaml with S_churn = 0 (deterministic Heun), w = 0
             timesteps, sigma_min, sigma_max, rho, S_churn, S_min, S_max, S_noise, w = STEPS, 0.002, 80.0, 7.0, 0.0, 0.0, float("inf"), 1.0, 0.0
         self.sd = lib.sampler_desc(SP)
         self.ws = lib.Workspace()
-        self.graph = lib.GraphedSampler(self.plan, self.packed, self.sd, self.B, self.H, self.W) if use_graph else None
+        self.graph = lib.GraphedSampler(self.plan, self.packed, self.sd, self.B, self.H, self.W, masked=not single) if use_graph else None
 
     def step(self):
         if self.graph is not None:
@@ -386,8 +396,9 @@ def main():
     repaint = args.workload == "repaint128"
     run = RepaintRunner(args.batch, device, rank, not args.no_graph) if repaint else Runner(args.workload, args.batch, device, rank, not args.no_graph)
     wl, B, H, W = run.wl, run.B, run.H, run.W
-    if repaint:
-        args.no_train = True
+    if repaint or wl.get("single"):
+        args.no_train = True          # the training and CPU legs are defined on the joint-model workloads
+        args.no_cpu_baseline = True
 
     def barrier():
         if world > 1:
@@ -484,7 +495,7 @@ def main():
     if not args.no_secondary and world == 1 and args.workload == "s128" and not args.batch:
         del run.graph
         torch.cuda.empty_cache()
-        for key in ("s32", "ref128", "s128l3"):
+        for key in ("s32", "ref128", "s128l3", "darcy128"):
             r2 = Runner(key, 0, device, 0, not args.no_graph)
             r2.step()
             torch.cuda.synchronize()

@@ -53,7 +53,24 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
     if (vec) {            // no resampling, HW % 4 == 0: 16-byte loads
       const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
       const f32x4* d4 = reinterpret_cast<const f32x4*>(dpl);
-      for (int p = tid; p < HWs / 4; p += 256) {
+      // four independent 16-byte load pairs in flight per thread (the loop is latency-bound otherwise: 2.4 TB/s)
+      const int n4 = HWs / 4;
+      int p = tid;
+      for (; p + 768 < n4; p += 1024) {
+        f32x4 xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xv[u] = x4[p + 256 * u]; dv[u] = d4[p + 256 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float dt = dv[u][e];
+            if (a.act) dt *= dsilu((xv[u][e] - cf.mean) * cf.scale + cf.offset);
+            pa += dt;
+            pb += dt * ((xv[u][e] - mean) * rstd);
+          }
+      }
+      for (; p < n4; p += 256) {
         const f32x4 xv = x4[p], dv = d4[p];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -116,6 +133,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs a) {
       const f32x4* d4 = reinterpret_cast<const f32x4*>(dpl);
       const f32x4* a4 = reinterpret_cast<const f32x4*>(addp);
       f32x4* o4 = reinterpret_cast<f32x4*>(dx);
+#pragma unroll 2
       for (int p = tid; p < HWs / 4; p += 256) {
         const f32x4 xv = x4[p], dv = d4[p];
         f32x4 o = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
@@ -326,9 +344,33 @@ __global__ __launch_bounds__(64) void attn_bwd_stats_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
-                                                         const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
-  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+// KW waves per workgroup split the streamed axis (keys for dq, queries for dk / dv: tiles w, w + KW, ...) of the SAME output
+// tile; the partial outputs are plain sums and meet in LDS, added by wave 0 in wave order (fixed order, no atomics).  One
+// wave per tile means B * heads * T / 32 waves per launch (512 at T = 256, B = 32, two heads): half a wave per SIMD with
+// every load latency exposed.
+template <int NREG>
+__device__ __forceinline__ bool merge_wave_partials(float (&v)[NREG], float* part, int wave, int lane, int KW) {
+  if (KW == 1) return true;
+  if (wave > 0) {
+    float* dst = part + (size_t)(wave - 1) * NREG * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) dst[r * 64] = v[r];
+  }
+  __syncthreads();
+  if (wave > 0) return false;
+  for (int w = 1; w < KW; ++w) {
+    const float* src = part + (size_t)(w - 1) * NREG * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) v[r] += src[r * 64];
+  }
+  return true;
+}
+
+template <int KW>
+__global__ __launch_bounds__(64 * KW) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
+                                                              const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
+  __shared__ float part[KW > 1 ? (KW - 1) * 32 * 64 : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * 32;
   const size_t bh = blockIdx.y;
   const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
@@ -348,15 +390,18 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  for (int k0 = 0; k0 < T; k0 += 32) {
+  for (int k0 = 32 * wave; k0 < T; k0 += 32 * KW) {
     const int kk = k0 + l31, kc = kk < T ? kk : T - 1;
     f32x16 sc, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+    const unsigned koff = 4u * (unsigned)(h * T + kc);        // scalar row base + one per-lane offset (see attention_split_kernel)
 #pragma unroll
     for (int st = 0; st < 32; ++st) {
-      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(K[(size_t)(2 * st + h) * T + kc], qreg[st], sc, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(V[(size_t)(2 * st + h) * T + kc], dareg[st], dp, 0, 0, 0);
+      const float kv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(K + (size_t)(2 * st) * T) + koff);
+      const float vv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(V + (size_t)(2 * st) * T) + koff);
+      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qreg[st], sc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, dareg[st], dp, 0, 0, 0);
     }
     float ds[16];
 #pragma unroll
@@ -376,18 +421,26 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
       }
     }
   }
+  float flat[32];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) flat[16 * i + r] = o[i][r];
+  if (!merge_wave_partials<32>(flat, part, wave, lane, KW)) return;
   if (q < T) {
     float* dQ = dqkv + (bh * 3 + 0) * 64 * (size_t)T;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dQ[(size_t)(32 * i + MCEDM_KEY_OF(r, h)) * T + q] = o[i][r] * 0.125f;
+      for (int r = 0; r < 16; ++r) dQ[(size_t)(32 * i + MCEDM_KEY_OF(r, h)) * T + q] = flat[16 * i + r] * 0.125f;
   }
 }
 
-__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
-                                                          const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
-  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+template <int KW>
+__global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
+                                                               const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
+  __shared__ float part[KW > 1 ? (KW - 1) * 64 * 64 : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int k0 = blockIdx.x * 32;
   const size_t bh = blockIdx.y;
   const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
@@ -406,7 +459,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restric
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ok[i][r] = 0.f; ov[i][r] = 0.f; }
-  for (int q0 = 0; q0 < T; q0 += 32) {
+  for (int q0 = 32 * wave; q0 < T; q0 += 32 * KW) {
     const int qq = q0 + l31, qc = qq < T ? qq : T - 1;
     // S[q][k] and dP[q][k]: rows = queries (registers), column = this lane's key
     f32x16 sc, dp;
@@ -439,6 +492,12 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restric
       }
     }
   }
+  float flat[64];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { flat[16 * i + r] = ok[i][r]; flat[32 + 16 * i + r] = ov[i][r]; }
+  if (!merge_wave_partials<64>(flat, part, wave, lane, KW)) return;
   if (key < T) {
     float* dK = dqkv + (bh * 3 + 1) * 64 * (size_t)T;
     float* dV = dqkv + (bh * 3 + 2) * 64 * (size_t)T;
@@ -447,8 +506,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const size_t c = 32 * i + MCEDM_KEY_OF(r, h);
-        dK[c * T + key] = ok[i][r] * 0.125f;
-        dV[c * T + key] = ov[i][r];
+        dK[c * T + key] = flat[16 * i + r] * 0.125f;
+        dV[c * T + key] = flat[32 + 16 * i + r];
       }
   }
 }
@@ -461,9 +520,20 @@ int launch_attention_bwd(const float* qkv, const float* a, const float* da, floa
   ProfScope ps("attention_bwd", 10.0 * B * heads * (double)T * T * 64, 4.0 * 8 * B * heads * 64.0 * T, s);
   hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(64), 0, s, qkv, a, da, lse, T);
   MCEDM_LAUNCH_CHECK("attn_bwd_stats_kernel");
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64), 0, s, qkv, da, lse, dqkv, T);
-  MCEDM_LAUNCH_CHECK("attn_bwd_dq_kernel");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64), 0, s, qkv, da, lse, dqkv, T);
+  // split factor: a function of T only (never of the batch size)
+  if (T >= 128) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, dim3(256), 0, s, qkv, da, lse, dqkv, T);
+    MCEDM_LAUNCH_CHECK("attn_bwd_dq_kernel");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, grid, dim3(256), 0, s, qkv, da, lse, dqkv, T);
+  } else if (T >= 64) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, dim3(128), 0, s, qkv, da, lse, dqkv, T);
+    MCEDM_LAUNCH_CHECK("attn_bwd_dq_kernel");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, grid, dim3(128), 0, s, qkv, da, lse, dqkv, T);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(64), 0, s, qkv, da, lse, dqkv, T);
+    MCEDM_LAUNCH_CHECK("attn_bwd_dq_kernel");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<1>, grid, dim3(64), 0, s, qkv, da, lse, dqkv, T);
+  }
   MCEDM_LAUNCH_CHECK("attn_bwd_dkv_kernel");
   return MCEDM_OK;
 }

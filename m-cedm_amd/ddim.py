@@ -324,8 +324,20 @@ class PlCondEdm(_EvalMetrics, _Base):
         churn = any((min(sd.S_churn / N, math.sqrt(2) - 1) if sd.S_min <= t[i] <= sd.S_max else 0) > 0 for i in range(N))
         step_noise = torch.randn((N,) + tuple(init.shape), dtype=torch.float64, device=init.device) if churn else None
         with torch.no_grad():
-            return net.plan.sample(net.packed_weights(), sd, h, None, init, step_noise, return_last=return_last,
-                                   ws=self._sample_ws, guidance=guidance)
+            packed = net.packed_weights()
+            eager = lambda c, m_, i, sn: net.plan.sample(packed, sd, c, None, i, sn, return_last=return_last, ws=self._sample_ws,
+                                                         guidance=guidance)
+            if guidance is not None or os.environ.get("MCEDM_HIP_GRAPH", "1") == "0":
+                return eager(h, None, init, step_noise)
+            # the unguided call replays from one HIP graph, like PlMcedm.sample_edm (the evaluation loops repeat it)
+            B, _, H, W = init.shape
+            key = (B, H, W, bool(return_last), churn, packed.data_ptr(), init.device.index,
+                   tuple(getattr(sd, f) for f, _ in sd._fields_))
+            fn = _lib.graphed_or_eager(self._graphs, key, lambda: _lib.GraphedSampler(
+                net.plan, packed, sd, B, H, W, masked=False, has_cond=True, churn=churn, return_last=return_last,
+                ws=self._sample_ws), eager)
+            out = fn(h, None, init, step_noise)
+            return out.clone() if fn is not eager else out
 
     # ---- evaluation loops (models/ddim.py:1154-1319): sampling on the device, metric bookkeeping on the host ----------
     def get_pde_loss(self, cond, x_denoised, x_gt_unnorm=None, noise_level=None, clamp_loss=True, do_rearrange=True,
