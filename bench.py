@@ -209,12 +209,16 @@ def csrc_digest():
 
 
 def committed_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py writes
-    profiles/r2_traffic.json with the digest of the kernel sources it was taken on); refused when the sources changed."""
-    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
-    try:
-        tr = json.load(open(path))
-    except Exception:
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (tools/rocpd_summary.py traffic writes
+    profiles/r3_traffic.json with the digest of the kernel sources it was taken on); refused when the sources changed."""
+    tr = None
+    for name in ("r3_traffic.json", "r2_traffic.json"):       # newest committed pass first
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+            break
+        except Exception:
+            continue
+    if tr is None:
         return None, "no committed PMC pass"
     if tr.get("csrc_digest") != csrc_digest():
         return None, f"stale: PMC pass taken at csrc {tr.get('csrc_digest')}, sources are now {csrc_digest()}"
