@@ -347,24 +347,26 @@ __device__ __forceinline__ float swish_d(float v) { return v * (1.0f / (1.0f + e
 
 // get_timestep_embedding (ddim_blocks.py:12-30: [sin | cos] of t * freqs) -> dense0 -> swish -> dense1 (:413-416), then
 // for every block row r: out[r] = temb_proj_r . swish(temb) + temb_proj.bias[r] + conv1.bias[r] (:149-151).
-// grid = nsplit workgroups; each recomputes the small MLP and writes its slice of the rows (one wave per row).
-__global__ __launch_bounds__(256) void ddpm_temb_kernel(float t, int ch, const float* __restrict__ freqs,
-                                                        const float* __restrict__ w0, const float* __restrict__ b0,
-                                                        const float* __restrict__ w1, const float* __restrict__ b1,
-                                                        const float* __restrict__ wp, const float* __restrict__ bp,
-                                                        const float* __restrict__ c1b, int rows, float* __restrict__ out) {
+// grid = nsplit workgroups of 16 waves; each recomputes the small MLP (one wave per row, 16 rows in flight: the kernel is a
+// chain of three dependent mat-vec products and runs once per U-Net evaluation) and writes its slice of the rows.
+constexpr int TEMB_NT = 1024, TEMB_NW = TEMB_NT / 64;
+__global__ __launch_bounds__(TEMB_NT) void ddpm_temb_kernel(float t, int ch, const float* __restrict__ freqs,
+                                                            const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ wp, const float* __restrict__ bp,
+                                                            const float* __restrict__ c1b, int rows, float* __restrict__ out) {
   extern __shared__ float sm[];
   const int temb = 4 * ch, half = ch / 2;
   float* e0 = sm;              // [ch]
   float* e1 = sm + ch;         // [temb]
   float* e2 = e1 + temb;       // [temb]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int k = tid; k < ch; k += 256) {
+  for (int k = tid; k < ch; k += TEMB_NT) {
     const float arg = t * freqs[k < half ? k : k - half];
     e0[k] = (k < half) ? sinf(arg) : cosf(arg);
   }
   __syncthreads();
-  for (int j = wave; j < temb; j += 4) {
+  for (int j = wave; j < temb; j += TEMB_NW) {
     float s = 0.f;
     for (int k = lane; k < ch; k += 64) s = fmaf(e0[k], w0[(size_t)j * ch + k], s);
 #pragma unroll
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256) void ddpm_temb_kernel(float t, int ch, const f
     if (lane == 0) e1[j] = swish_d(s + b0[j]);
   }
   __syncthreads();
-  for (int j = wave; j < temb; j += 4) {
+  for (int j = wave; j < temb; j += TEMB_NW) {
     float s = 0.f;
     for (int k = lane; k < temb; k += 64) s = fmaf(e1[k], w1[(size_t)j * temb + k], s);
 #pragma unroll
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void ddpm_temb_kernel(float t, int ch, const f
   __syncthreads();
   const int per = (rows + gridDim.x - 1) / gridDim.x;
   const int r1 = min(rows, (int)(blockIdx.x + 1) * per);
-  for (int r = blockIdx.x * per + wave; r < r1; r += 4) {
+  for (int r = blockIdx.x * per + wave; r < r1; r += TEMB_NW) {
     float s = 0.f;
     for (int k = lane; k < temb; k += 64) s = fmaf(e2[k], wp[(size_t)r * temb + k], s);
 #pragma unroll
@@ -557,9 +559,9 @@ static int ddpm_forward(const mcedm_ddpm_plan& P, bool dry, const float* pk, con
   const int R = d.resolution, L = d.n_levels;
   int rc;
   if (!dry) {
-    int nsplit = P.rows / 64; if (nsplit < 1) nsplit = 1; if (nsplit > 64) nsplit = 64;
+    int nsplit = P.rows / 32; if (nsplit < 1) nsplit = 1; if (nsplit > 64) nsplit = 64;
     const int ch = d.ch;
-    hipLaunchKernelGGL(ddpm_temb_kernel, dim3(nsplit), dim3(256), (size_t)(ch + 8 * ch) * sizeof(float), s, t, ch, pk + P.freqs,
+    hipLaunchKernelGGL(ddpm_temb_kernel, dim3(nsplit), dim3(TEMB_NT), (size_t)(ch + 8 * ch) * sizeof(float), s, t, ch, pk + P.freqs,
                        pk + P.w0, pk + P.b0, pk + P.w1, pk + P.b1, pk + P.tproj_w, pk + P.tproj_b, pk + P.c1bias, P.rows, bias_table);
     MCEDM_LAUNCH_CHECK("ddpm_temb_kernel");
   }
