@@ -362,6 +362,29 @@ int mcedm_repaint_sample_rng(const mcedm_ddpm_plan* plan, const void* packed, co
 /* out[0 .. n) = the N(0, 1) values of draw `draw` of that generator (fp64). */
 int mcedm_normal_fill(double* out, size_t n, const uint64_t* rng_seed, uint64_t draw, void* stream);
 
+/* Model.forward(x, t, x_self_cond) with the self-conditioning tensor given (ddim_blocks.py:417-420; NULL = zeros, i.e.
+ * mcedm_ddpm_forward).  x_self_cond [B, in_channels, R, R]. */
+int mcedm_ddpm_forward_sc(const mcedm_ddpm_plan* plan, const void* packed, const float* x, const float* x_self_cond, float t,
+                          float* out, void* workspace, size_t workspace_bytes, int B, void* stream);
+/* PlDdim.sample_with_repeat (models/ddim.py:808-913): the DDIM sampler with RePaint-style inner loops, guide_dx False,
+ * dx_cond False.  Everything is fp32 like the reference.
+ *  timesteps, skip_type (0 uniform, 1 quad: ddim.py:823-830), eta, n_repeat, n_time_h / n_time_u / h_ch / u_ch as in
+ *  mcedm_repaint_desc; alphas_cumprod_ext: host table cumprod(1 - cat(0, betas)) with num_diffusion_timesteps + 1 entries.
+ *  hu, init_noise  [B, C, R, R]      normalised joint state; randn_like(hu) (:832)
+ *  eta_noise       [timesteps][B, C, R, R] or NULL: the torch.rand_like draws of :893 (UNIFORM in the reference), eta != 0 only
+ *  self_cond       1: the previous x0 prediction is fed back as x_self_cond (hparams.model.self_cond), 0: never
+ *  xs_out, x0_out  fp32 [B, 1 or timesteps + 1, R, R, C] / [B, 1 or timesteps, R, R, C] ('b t h w c', as the reference returns) */
+typedef struct mcedm_ddim_desc {
+  int32_t timesteps, skip_type;
+  double eta;
+  int32_t n_repeat, n_time_h, n_time_u, h_ch, u_ch, num_diffusion_timesteps, self_cond;
+  const float* alphas_cumprod_ext;
+} mcedm_ddim_desc;
+int mcedm_ddim_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* bytes);
+int mcedm_ddim_repaint_sample(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_ddim_desc* sp, const float* hu,
+                              const float* init_noise, const float* eta_noise, float* xs_out, float* x0_out, int return_last,
+                              void* workspace, size_t workspace_bytes, int B, void* stream);
+
 /* ---- PDE residuals (forward) ----------------------------------------------
  * Replace the tensor-op bodies of models/pde_loss.py; results are bit-identical to the PyTorch CPU path.
  * All tensors are fp32, channel-last (b, t, x, 2) = (h, u) for SWE and (b, s, s, 2) = (a, u) for Darcy.

@@ -739,7 +739,9 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
       // segments (6 instructions per wave and 16-channel pass), is transformed in place, and no staging registers exist, so
       // a wave can own EIGHT accumulator blocks (64 channels x 16 x 32 pixels per workgroup) at two workgroups per CU.
       // The pixel tile is a function of the image size only (batch-shard bit-identity).
-      if ((long long)a.H * a.W >= 16384) {
+      static int b16_min = -1;      // MCEDM_RES_B16_MIN: smallest image (pixels) that takes the 16 x 32 tile (experiments)
+      if (b16_min < 0) { const char* e = getenv("MCEDM_RES_B16_MIN"); b16_min = e ? atoi(e) : 16384; }
+      if ((long long)a.H * a.W >= b16_min) {
         typedef ResCfg<64, 16, 32, 1, 4, 9, 8> B16;
         ResidentPlan pl = resident_plan<B16, true>(a, half_cu, 8);
         if (pl.pass_c && pl.nslab == 3 && pl.wide) { if (pl.pass_c > big_pass()) pl.pass_c = big_pass(); return launch_resident<B16, RS_NONE, true>(a, pl, stream); }

@@ -554,7 +554,8 @@ static DHeader dheader(const mcedm_ddpm_plan& P, int B, int H, int W) {
 // Model.forward (ddim_blocks.py:410-470) with cond None, dx None, x_self_cond None; x is scaled by the rows of coef_in
 // (null = identity) while conv_in stages it.  `act` = start of the activation region.  Returns the peak bytes in *peak.
 static int ddpm_forward(const mcedm_ddpm_plan& P, bool dry, const float* pk, const float* x, const Coef* coef_in, float t,
-                        float* bias_table, float* out, char* act, int B, hipStream_t s, size_t* peak) {
+                        float* bias_table, float* out, char* act, int B, hipStream_t s, size_t* peak,
+                        const float* x_self_cond = nullptr) {
   const mcedm_ddpm_desc& d = P.desc;
   const int R = d.resolution, L = d.n_levels;
   int rc;
@@ -573,7 +574,7 @@ static int ddpm_forward(const mcedm_ddpm_plan& P, bool dry, const float* pk, con
   {
     const int h0 = E.act(d.ch, R, R, true);
     ConvArgs ci{};
-    ci.xa = nullptr; ci.Ca = n_self; ci.xb = x; ci.Cb = d.in_channels;
+    ci.xa = x_self_cond; ci.Ca = n_self; ci.xb = x; ci.Cb = d.in_channels;       // a null self-conditioning source reads as zeros
     if (n_self == 0) { ci.xa = x; ci.Ca = d.in_channels; ci.xb = nullptr; ci.Cb = 0; }
     ci.coef = coef_in; ci.coef_batch = 0; ci.act = 0;
     ci.Hs = R; ci.Ws = R; ci.H = R; ci.W = R;
@@ -699,6 +700,18 @@ extern "C" int mcedm_ddpm_forward(const mcedm_ddpm_plan* plan, const void* packe
   if (hd.total + act > workspace_bytes) { set_error("ddpm_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, hd.total + act); return MCEDM_ERR_WORKSPACE; }
   return ddpm_forward(*plan, false, (const float*)packed, x, nullptr, t, at<float>(workspace, hd.bias), out,
                       at<char>(workspace, hd.total), B, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int mcedm_ddpm_forward_sc(const mcedm_ddpm_plan* plan, const void* packed, const float* x, const float* x_self_cond,
+                                     float t, float* out, void* workspace, size_t workspace_bytes, int B, void* stream) {
+  MCEDM_REQUIRE(plan && packed && x && out && workspace, "ddpm_forward_sc: null argument");
+  MCEDM_REQUIRE(!x_self_cond || plan->desc.self_cond, "ddpm_forward_sc: the network was built without self-conditioning channels");
+  DHeader hd; size_t act = 0;
+  int rc = ddpm_sizes(*plan, B, &hd, &act);
+  if (rc) return rc;
+  if (hd.total + act > workspace_bytes) { set_error("ddpm_forward_sc: workspace too small (%zu < %zu bytes)", workspace_bytes, hd.total + act); return MCEDM_ERR_WORKSPACE; }
+  return ddpm_forward(*plan, false, (const float*)packed, x, nullptr, t, at<float>(workspace, hd.bias), out,
+                      at<char>(workspace, hd.total), B, (hipStream_t)stream, nullptr, x_self_cond);
 }
 
 extern "C" int mcedm_ddpm_denoise(const mcedm_ddpm_plan* plan, const void* packed, const float* x, float sigma, float c_noise,
@@ -881,5 +894,114 @@ static int mcedm::repaint_impl(const mcedm_ddpm_plan* plan, const void* packed, 
     if (!return_last && (rc = launch_heun_store(x, C, hw, i + 1, Tout, total, out, s))) return rc;
   }
   if (return_last && (rc = launch_heun_store(x, C, hw, 0, 1, total, out, s))) return rc;
+  return MCEDM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// PlDdim.sample_with_repeat (models/ddim.py:808-913): DDIM steps with RePaint inner loops, fp32 throughout
+// ------------------------------------------------------------------------------------------
+namespace mcedm {
+struct DdimBufs { size_t xt, x0, et, mask, total; };
+static DdimBufs ddim_bufs(const mcedm_ddpm_plan& P, int B) {
+  DdimBufs r; size_t cur = 0;
+  auto take = [&](size_t bytes) { size_t o = cur; cur += align_up(bytes, 256); return o; };
+  const size_t n = (size_t)B * P.desc.in_channels * P.desc.resolution * P.desc.resolution;
+  r.xt = take(n * 4); r.x0 = take(n * 4); r.et = take(n * 4); r.mask = take(n * 4);
+  r.total = cur;
+  return r;
+}
+}  // namespace mcedm
+
+extern "C" int mcedm_ddim_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* bytes) {
+  MCEDM_REQUIRE(plan && bytes, "ddim_workspace_bytes: null argument");
+  size_t u = 0;
+  int rc = mcedm_ddpm_workspace_bytes(plan, B, &u);
+  if (rc) return rc;
+  *bytes = ddim_bufs(*plan, B).total + u;
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_ddim_repaint_sample(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_ddim_desc* sp,
+                                         const float* hu, const float* init_noise, const float* eta_noise, float* xs_out,
+                                         float* x0_out, int return_last, void* workspace, size_t workspace_bytes, int B,
+                                         void* stream) {
+  MCEDM_REQUIRE(plan && packed && sp && hu && init_noise && xs_out && workspace, "ddim_repaint_sample: null argument");
+  const mcedm_ddpm_plan& P = *plan;
+  MCEDM_REQUIRE(P.desc.in_channels == P.desc.out_channels, "ddim_repaint_sample: in_channels != out_channels");
+  const int n = sp->num_diffusion_timesteps, N = sp->timesteps, R = sp->n_repeat;
+  MCEDM_REQUIRE(sp->alphas_cumprod_ext && n >= 2 && N >= 1 && N <= n && R >= 1, "ddim_repaint_sample: bad schedule (timesteps=%d of %d, n_repeat=%d)", N, n, R);
+  MCEDM_REQUIRE(sp->skip_type == 0 || sp->skip_type == 1, "ddim_repaint_sample: skip_type must be 0 (uniform) or 1 (quad)");
+  MCEDM_REQUIRE(sp->h_ch >= 0 && sp->u_ch >= 0 && sp->h_ch + sp->u_ch <= P.desc.in_channels, "ddim_repaint_sample: h_ch + u_ch exceeds the state channels");
+  MCEDM_REQUIRE(!sp->self_cond || P.desc.self_cond, "ddim_repaint_sample: self-conditioning asked of a network built without it");
+  const bool stochastic = std::fabs(sp->eta) > 1e-10;                   // ddim.py:884
+  MCEDM_REQUIRE(!stochastic || eta_noise != nullptr, "ddim_repaint_sample: eta != 0 needs eta_noise");
+  // the timestep sequence (ddim.py:823-830) and its predecessor list (:845)
+  std::vector<int> seq;
+  if (sp->skip_type == 0) {
+    const int skip = n / N;
+    for (int v = 0; v < n; v += skip) seq.push_back(v);                 // range(0, num_timesteps, skip): may hold more than N entries
+  } else {
+    const double hi = std::sqrt(n * 0.8);
+    for (int i = 0; i < N; ++i) { const double v = (N > 1 ? hi * i / (N - 1) : 0.0); seq.push_back((int)(v * v)); }
+  }
+  const int S = (int)seq.size();
+  DHeader hd; size_t act = 0;
+  int rc;
+  if ((rc = ddpm_sizes(P, B, &hd, &act))) return rc;
+  const DdimBufs db = ddim_bufs(P, B);
+  if (db.total + hd.total + act > workspace_bytes) {
+    set_error("ddim_repaint_sample: workspace too small (%zu < %zu bytes)", workspace_bytes, db.total + hd.total + act);
+    return MCEDM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const float* pk = (const float*)packed;
+  float* xt = at<float>(workspace, db.xt);
+  float* x0 = at<float>(workspace, db.x0);
+  float* et = at<float>(workspace, db.et);
+  float* mask = at<float>(workspace, db.mask);
+  void* uws = at<char>(workspace, db.total);
+  const int res = P.desc.resolution, C = P.desc.in_channels;
+  const size_t hw = (size_t)res * res, total = (size_t)B * C * hw;
+  const int Txs = return_last ? 1 : S + 1, Tx0 = return_last ? 1 : S;
+  auto alpha = [&](int t) -> float { return sp->alphas_cumprod_ext[t + 1]; };      // compute_alpha(t): index t + 1 (ddim.py:700-704)
+
+  hipLaunchKernelGGL(repaint_mask_kernel, dim3(2048 < (total + 255) / 256 ? 2048 : (unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                     mask, C, res, res, sp->h_ch, sp->u_ch, sp->n_time_h, sp->n_time_u, total);
+  MCEDM_LAUNCH_CHECK("repaint_mask_kernel");
+  {   // x = (hu * a[-1].sqrt() + hu_noise * (1 - a[-1]).sqrt()) * mask + hu_noise * (1 - mask)   (:837-838); a[-1] = alpha(n - 1)
+    const float aT = alpha(n - 1);
+    if ((rc = launch_ddim_init(hu, init_noise, mask, sqrtf(aT), sqrtf(1.0f - aT), total, xt, s))) return rc;
+  }
+  if (!return_last && (rc = launch_store_f32(xt, C, hw, 0, Txs, total, xs_out, s))) return rc;
+  bool have_x0 = false;
+  for (int step = 0; step < S; ++step) {
+    const int i = seq[S - 1 - step], j = (S - 1 - step) > 0 ? seq[S - 2 - step] : -1;
+    const float a_t = alpha(i), at_next = alpha(j);
+    const float s0 = sqrtf(a_t), s1 = sqrtf(1.0f - a_t);
+    for (int k = 0; k < R; ++k) {
+      const float* sc = (sp->self_cond && have_x0) ? x0 : nullptr;      // x_self_cond = x0_t if self_condition else None (:863)
+      if ((rc = ddpm_forward(P, false, pk, xt, nullptr, (float)i, at<float>(uws, hd.bias), et, at<char>(uws, hd.total), B, s, nullptr, sc))) return rc;
+      if ((rc = launch_ddim_x0(xt, et, hu, mask, s0, s1, k < R - 1 ? 1 : 0, total, x0, s))) return rc;
+      have_x0 = true;
+    }
+    float c1 = 0.f, c2;
+    if (stochastic) {        // c1 = eta * sqrt((1 - at / at_next) * (1 - at_next) / (1 - at)); c2 = sqrt((1 - at_next) - c1^2), fp32 like the tensors
+      c1 = (float)sp->eta * sqrtf((1.0f - a_t / at_next) * (1.0f - at_next) / (1.0f - a_t));
+      c2 = sqrtf((1.0f - at_next) - c1 * c1);
+    } else {
+      c2 = sqrtf(1.0f - at_next);
+    }
+    if ((rc = launch_ddim_next(x0, et, hu, init_noise, mask, stochastic ? eta_noise + (size_t)step * total : nullptr, sqrtf(at_next), c1,
+                               c2, total, xt, s))) return rc;
+    if (!return_last) {
+      if ((rc = launch_store_f32(xt, C, hw, step + 1, Txs, total, xs_out, s))) return rc;
+      if (x0_out && (rc = launch_store_f32(x0, C, hw, step, Tx0, total, x0_out, s))) return rc;
+    }
+  }
+  if (return_last) {
+    if ((rc = launch_store_f32(xt, C, hw, 0, 1, total, xs_out, s))) return rc;
+    if (x0_out && (rc = launch_store_f32(x0, C, hw, 0, 1, total, x0_out, s))) return rc;
+  }
   return MCEDM_OK;
 }

@@ -302,6 +302,64 @@ int launch_repaint_known(double* x, const float* hu, const float* noise, const f
   return MCEDM_OK;
 }
 
+// ---- DDIM sampler with RePaint loops (PlDdim.sample_with_repeat, models/ddim.py:808-913): fp32 like the reference ----
+__global__ void ddim_x0_kernel(float* __restrict__ xt, const float* __restrict__ et, const float* __restrict__ hu,
+                               const float* __restrict__ mask, float s0, float s1, int renoise, size_t total,
+                               float* __restrict__ x0) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float e = et[i], m = mask[i];
+    float v = (xt[i] - e * s1) / s0;                                   // (xt - et * (1 - at).sqrt()) / at.sqrt()
+    v = hu[i] * m + v * (1.0f - m);                                    // add known part (:878-879)
+    x0[i] = v;
+    if (renoise) xt[i] = s0 * v + s1 * e;                              // at.sqrt() * x0_t + (1 - at).sqrt() * et (:881-882)
+  }
+}
+int launch_ddim_x0(float* xt, const float* et, const float* hu, const float* mask, float s0, float s1, int renoise, size_t total,
+                   float* x0, hipStream_t s) {
+  hipLaunchKernelGGL(ddim_x0_kernel, dim3(grid_for(total)), dim3(256), 0, s, xt, et, hu, mask, s0, s1, renoise, total, x0);
+  MCEDM_LAUNCH_CHECK("ddim_x0_kernel");
+  return MCEDM_OK;
+}
+__global__ void ddim_next_kernel(const float* __restrict__ x0, const float* __restrict__ et, const float* __restrict__ hu,
+                                 const float* __restrict__ hn, const float* __restrict__ mask, const float* __restrict__ noise,
+                                 float sa, float c1, float c2, size_t total, float* __restrict__ xt) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float m = mask[i];
+    float v = noise ? (sa * x0[i] + c1 * noise[i]) + c2 * et[i] : sa * x0[i] + c2 * et[i];      // (:891-895)
+    const float known = sa * hu[i] + c2 * hn[i];                                                // at_next.sqrt() * hu + c2 * hu_noise
+    xt[i] = known * m + v * (1.0f - m);
+  }
+}
+int launch_ddim_next(const float* x0, const float* et, const float* hu, const float* hn, const float* mask, const float* noise,
+                     float sa, float c1, float c2, size_t total, float* xt, hipStream_t s) {
+  hipLaunchKernelGGL(ddim_next_kernel, dim3(grid_for(total)), dim3(256), 0, s, x0, et, hu, hn, mask, noise, sa, c1, c2, total, xt);
+  MCEDM_LAUNCH_CHECK("ddim_next_kernel");
+  return MCEDM_OK;
+}
+__global__ void ddim_init_kernel(const float* __restrict__ hu, const float* __restrict__ hn, const float* __restrict__ mask,
+                                 float sa, float sb, size_t total, float* __restrict__ xt) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float m = mask[i], nz = hn[i];
+    xt[i] = (hu[i] * sa + nz * sb) * m + nz * (1.0f - m);             // ddim.py:837-838
+  }
+}
+int launch_ddim_init(const float* hu, const float* hn, const float* mask, float sa, float sb, size_t total, float* xt, hipStream_t s) {
+  hipLaunchKernelGGL(ddim_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, hu, hn, mask, sa, sb, total, xt);
+  MCEDM_LAUNCH_CHECK("ddim_init_kernel");
+  return MCEDM_OK;
+}
+__global__ void store_f32_kernel(const float* __restrict__ x, int C, size_t hw, int t, int T, size_t total, float* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = i % C, p = (i / C) % hw, b = i / (C * hw);
+    out[((b * T + t) * hw + p) * C + c] = x[(b * C + c) * hw + p];
+  }
+}
+int launch_store_f32(const float* x, int C, size_t hw, int t, int T, size_t total, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(store_f32_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, C, hw, t, T, total, out);
+  MCEDM_LAUNCH_CHECK("store_f32_kernel");
+  return MCEDM_OK;
+}
+
 // ---- training-side elementwise ----------------------------------------------------------------
 // sigma = exp(rnd*P_std + P_mean) (mcedm.py:271); x_noise = x + mask*noise*sigma (mcedm.py:216)
 __global__ void noise_inputs_kernel(const float* __restrict__ x, const float* __restrict__ mask,

@@ -54,4 +54,16 @@ int launch_repaint_init(const float* hu, const float* noise, const float* mask, 
 int launch_repaint_known(double* x, const float* hu, const float* noise, const float* mask, float sa, float sb, int final_clean,
                          size_t total, float* x32, hipStream_t s);
 
+// ---- DDIM sampler with RePaint loops (PlDdim.sample_with_repeat, models/ddim.py:808-913), all fp32
+// x0 = (xt - et * s1) / s0;  x0 = hu * m + x0 * (1 - m);  renoise: xt = s0 * x0 + s1 * et     (:873-882)
+int launch_ddim_x0(float* xt, const float* et, const float* hu, const float* mask, float s0, float s1, int renoise, size_t total,
+                   float* x0, hipStream_t s);
+// xt_next = sa * x0 + [c1 * noise +] c2 * et;  xt_next = (sa * hu + c2 * hn) * m + xt_next * (1 - m)   (:884-895)
+int launch_ddim_next(const float* x0, const float* et, const float* hu, const float* hn, const float* mask, const float* noise,
+                     float sa, float c1, float c2, size_t total, float* xt, hipStream_t s);
+// x = (hu * sa + hn * sb) * m + hn * (1 - m)   (:837-838)
+int launch_ddim_init(const float* hu, const float* hn, const float* mask, float sa, float sb, size_t total, float* xt, hipStream_t s);
+// 'b c h w -> b t h w c' for one time slot, fp32
+int launch_store_f32(const float* x, int C, size_t hw, int t, int T, size_t total, float* out, hipStream_t s);
+
 }  // namespace mcedm

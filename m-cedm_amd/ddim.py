@@ -429,7 +429,8 @@ class PlDdim(_EvalMetrics, _Base):
     """models/ddim.py:16-1051, the part BASELINE config 5 exercises: EDM / RePaint sampling of the joint (h, u) DDPM.
     Constructor, buffers (``betas``, ``logvar``), attributes and the signatures of ``set_test_sampler_params``,
     ``get_edm_steps``, ``compute_alpha``, ``round_sigma``, ``get_denoised`` and ``sample_edm`` follow the reference.
-    DDPM training, the DDIM ``sample`` / ``sample_with_repeat`` loops and PDE guidance are not built and raise."""
+    ``sample_with_repeat`` (the DDIM sampler with RePaint loops, the default ``diff_sampler: ddim_sampler``) runs on the device
+    too (round 3).  DDPM training, the h -> u ``sample`` loop and PDE guidance are not built and raise."""
 
     def __init__(self, hparams):
         super().__init__()
@@ -582,10 +583,11 @@ class PlDdim(_EvalMetrics, _Base):
             err = err / (noise_level.reshape(-1, 1, 1, 1) + 1.0)
         return err.sum() if reduce else err
 
-    def _require_edm(self, sp):
-        if sp.type != "edm":
-            raise NotImplementedError("only the EDM / RePaint sampler (type 'edm') is built; the DDIM loops are not "
-                                      "(models/ddim.py:706-913)")
+    def _sample_eval(self, h, u, sp, return_last):
+        """models/ddim.py:309-312, 391-394: the EDM / RePaint sampler for type 'edm', the DDIM RePaint sampler otherwise."""
+        if sp.type == "edm":
+            return self.sample_edm(h, u, sp, return_last=return_last, guide_dx=sp.guide_dx)
+        return self.sample_with_repeat(h, u, sp, return_last=return_last, guide_dx=sp.guide_dx)[0]
 
     def validation_step(self, val_batch, batch_idx):
         if (self.current_epoch + 1) % 100 != 0 and self.current_epoch != 0:
@@ -595,9 +597,8 @@ class PlDdim(_EvalMetrics, _Base):
         state_gt = self.data_transform(h_unnorm, u_unnorm)
         h, u = state_gt[..., :h_ch], state_gt[..., h_ch:h_ch + u_ch]
         sp = self.sparams
-        self._require_edm(sp)
         # the reference hands NOISE in as the u field here (models/ddim.py:306-309): rows < n_time_u of it count as known
-        xs = self.sample_edm(h, torch.randn_like(u), sp, return_last=True, guide_dx=sp.guide_dx)
+        xs = self._sample_eval(h, torch.randn_like(u), sp, True)
         last = xs[:, -1]
         h_last, u_last = last[..., :h_ch], last[..., h_ch:h_ch + u_ch]
         loss_h, loss_u = _l1(h_last, h), _l1(u_last, u)
@@ -624,11 +625,10 @@ class PlDdim(_EvalMetrics, _Base):
         state_gt = self.data_transform(h_unnorm, u_unnorm)
         h, u = state_gt[..., hs], state_gt[..., us]
         sp = self.test_sparams
-        self._require_edm(sp)
         n, nb = sp.n_samples, len(h_unnorm)
         rep = state_gt.repeat(n, 1, 1, 1)
         n_all, n_time_h, n_time_u = h.shape[1], sp.n_time_h, sp.n_time_u
-        xs = self.sample_edm(rep[..., hs], rep[..., us], sp, return_last=sp.return_last, guide_dx=sp.guide_dx)
+        xs = self._sample_eval(rep[..., hs], rep[..., us], sp, sp.return_last)
         xs_mean = xs.reshape(n, nb, *xs.shape[1:]).mean(dim=0)               # '(n b) t h w c -> n b t h w c', mean over n
         h_last, u_last = xs_mean[:, -1, :, :, hs], xs_mean[:, -1, :, :, us]
         loss_h, loss_u = _l1(h_last, h), _l1(u_last, u)
@@ -685,10 +685,26 @@ class PlDdim(_EvalMetrics, _Base):
                 "gt": gt_scaled if sp.plot_scaled else state_gt}
 
     def sample(self, *a, **k):
-        raise NotImplementedError("the DDIM sampler (models/ddim.py:706-806) is not built; use sample_edm")
+        raise NotImplementedError("the h -> u DDIM sampler (models/ddim.py:706-806) is not built; PlDdim's evaluation loops "
+                                  "use sample_with_repeat / sample_edm")
 
-    def sample_with_repeat(self, *a, **k):
-        raise NotImplementedError("the DDIM RePaint sampler (models/ddim.py:808-913) is not built; use sample_edm")
+    def sample_with_repeat(self, h, u, sparams, return_last=True, guide_dx=False):
+        """models/ddim.py:808-913: DDIM steps (eta, uniform / quad skipping) with n_repeat RePaint-style inner loops per step
+        and the previous x0 prediction fed back as x_self_cond; the loop runs in mcedm_ddim_repaint_sample (csrc/ddpm.hip).
+        h, u: 'b h w c' normalised fields.  Returns (xs, x0_preds), fp32 'b t h w c' like the reference."""
+        if guide_dx:
+            raise NotImplementedError("guide_dx=True (PDE guidance) is outside the built path")
+        net = self._net(self.ema_model if self.ema_model is not None else self.model)
+        hu = _nchw(torch.cat([h, u], dim=-1)).float()
+        dd, keep = _lib.ddim_desc(sparams, self._alphas_ext(), self.h_ch, self.u_ch, net.self_condition)
+        hu_noise = torch.randn_like(hu)
+        eta_noise = None
+        if abs(float(sparams.eta)) > 1e-10:        # the reference draws torch.rand_like (UNIFORM) here, models/ddim.py:893
+            S = len(range(0, self.num_timesteps, self.num_timesteps // dd.timesteps)) if dd.skip_type == 0 else dd.timesteps
+            eta_noise = torch.rand((S,) + tuple(hu.shape), dtype=torch.float32, device=hu.device)
+        with torch.no_grad():
+            return net.plan.ddim_repaint_sample(net.packed_weights(), dd, hu, hu_noise, eta_noise, return_last=return_last,
+                                                ws=self._sample_ws)
 
     def training_step(self, *a, **k):
         raise NotImplementedError("DDPM (epsilon-prediction) training is not built: SURVEY.md section 8 f1 covers EDM sampling "

@@ -178,11 +178,14 @@ class Model(nn.Module):
         return self._packed
 
     def forward(self, x, t, cond=None, x_self_cond=None, dx=None):
-        if cond is not None or x_self_cond is not None or dx is not None:
-            raise NotImplementedError("cond / x_self_cond / dx are outside the built path (sample_edm passes None for all three)")
+        if cond is not None or dx is not None:
+            raise NotImplementedError("cond / dx are outside the built path (the samplers pass None for both)")
+        if x_self_cond is not None and not self.self_condition:
+            raise RuntimeError("x_self_cond given to a network built with self_cond: False")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("the DDPM U-Net is built for inference (RePaint sampling); call it under torch.no_grad()")
         t = torch.as_tensor(t).reshape(-1)
         if t.numel() != 1 and not bool((t == t[0]).all()):
             raise NotImplementedError("one timestep for the whole batch (what the sampler evaluates)")
-        return self.plan.forward(self.packed_weights(), x.to(torch.float32).contiguous(), float(t[0]), ws=self._ws)
+        sc = None if x_self_cond is None else x_self_cond.to(torch.float32).contiguous()
+        return self.plan.forward(self.packed_weights(), x.to(torch.float32).contiguous(), float(t[0]), ws=self._ws, x_self_cond=sc)

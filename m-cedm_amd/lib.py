@@ -28,7 +28,8 @@ EXPORTS = [
     "mcedm_ddpm_plan_create", "mcedm_ddpm_plan_destroy", "mcedm_ddpm_param_count", "mcedm_ddpm_param_info",
     "mcedm_ddpm_packed_bytes", "mcedm_ddpm_pack_weights", "mcedm_ddpm_workspace_bytes", "mcedm_ddpm_forward",
     "mcedm_ddpm_denoise", "mcedm_repaint_schedule", "mcedm_repaint_workspace_bytes", "mcedm_repaint_sample",
-    "mcedm_repaint_sample_rng", "mcedm_normal_fill",
+    "mcedm_repaint_sample_rng", "mcedm_normal_fill", "mcedm_ddpm_forward_sc", "mcedm_ddim_workspace_bytes",
+    "mcedm_ddim_repaint_sample",
 ]
 
 
@@ -64,6 +65,12 @@ class RepaintDesc(C.Structure):
                 ("w", C.c_double), ("n_repeat", C.c_int32), ("n_time_h", C.c_int32), ("n_time_u", C.c_int32),
                 ("h_ch", C.c_int32), ("u_ch", C.c_int32), ("num_diffusion_timesteps", C.c_int32),
                 ("edm_steps", C.POINTER(C.c_float)), ("alphas_cumprod_ext", C.POINTER(C.c_float))]
+
+
+class DdimDesc(C.Structure):
+    _fields_ = [("timesteps", C.c_int32), ("skip_type", C.c_int32), ("eta", C.c_double), ("n_repeat", C.c_int32),
+                ("n_time_h", C.c_int32), ("n_time_u", C.c_int32), ("h_ch", C.c_int32), ("u_ch", C.c_int32),
+                ("num_diffusion_timesteps", C.c_int32), ("self_cond", C.c_int32), ("alphas_cumprod_ext", C.POINTER(C.c_float))]
 
 
 _lib = None
@@ -133,6 +140,9 @@ def load() -> C.CDLL:
     lib.mcedm_repaint_sample.argtypes = [vp, vp, C.POINTER(RepaintDesc), f32p, f32p, f64p, f64p, f64p, i32, vp, sz, i32, vp]
     lib.mcedm_repaint_sample_rng.argtypes = [vp, vp, C.POINTER(RepaintDesc), f32p, f32p, vp, f64p, i32, vp, sz, i32, vp]
     lib.mcedm_normal_fill.argtypes = [f64p, sz, vp, C.c_uint64, vp]
+    lib.mcedm_ddpm_forward_sc.argtypes = [vp, vp, f32p, f32p, C.c_float, f32p, vp, sz, i32, vp]
+    lib.mcedm_ddim_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]
+    lib.mcedm_ddim_repaint_sample.argtypes = [vp, vp, C.POINTER(DdimDesc), f32p, f32p, f32p, f32p, f32p, i32, vp, sz, i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)          # AttributeError here == header/library drift
         if name not in ("mcedm_last_error", "mcedm_unet_plan_destroy", "mcedm_ddpm_plan_destroy"):
@@ -355,6 +365,17 @@ def repaint_desc(sp, edm_steps: torch.Tensor, alphas_ext: torch.Tensor, h_ch: in
     return d, (es, ae)
 
 
+def ddim_desc(sp, alphas_ext: torch.Tensor, h_ch: int, u_ch: int, self_cond: bool):
+    """C description of PlDdim.sample_with_repeat's parameters (configs/diff_sampler/ddim_sampler*.yaml).  Returns (desc, keepalive)."""
+    ae = alphas_ext.detach().to("cpu", torch.float32).contiguous()
+    skip = {"uniform": 0, "quad": 1}.get(str(sp.skip_type))
+    if skip is None:
+        raise NotImplementedError(f"skip_type {sp.skip_type}")             # models/ddim.py:829-830
+    d = DdimDesc(int(sp.timesteps), skip, float(sp.eta), int(sp.n_repeat), int(sp.n_time_h), int(sp.n_time_u), int(h_ch), int(u_ch),
+                 int(ae.numel() - 1), int(bool(self_cond)), C.cast(ae.data_ptr(), C.POINTER(C.c_float)))
+    return d, ae
+
+
 def repaint_schedule(rd: RepaintDesc) -> List[float]:
     arr = (C.c_double * (rd.timesteps + 1))()
     check(load().mcedm_repaint_schedule(C.byref(rd), arr), "repaint_schedule")
@@ -430,15 +451,43 @@ class DdpmPlan:
             raise RuntimeError(f"input {tuple(x.shape)} != [B, {self.in_channels}, {self.resolution}, {self.resolution}] "
                                "(the network asserts input size == resolution, ddim_blocks.py:411)")
 
-    def forward(self, packed, x, t: float, ws: Optional[Workspace] = None) -> torch.Tensor:
+    def forward(self, packed, x, t: float, ws: Optional[Workspace] = None, x_self_cond: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._check_x(x)
         B = x.shape[0]
         ws = ws or Workspace()
         buf = ws.get(self.workspace_bytes(B), x.device)
         out = torch.empty((B, self.out_channels, self.resolution, self.resolution), dtype=torch.float32, device=x.device)
+        if x_self_cond is not None:
+            if tuple(x_self_cond.shape) != tuple(x.shape):
+                raise RuntimeError("x_self_cond must have the shape of x")
+            check(self._lib.mcedm_ddpm_forward_sc(self._h, packed.data_ptr(), _ptr(x), _ptr(x_self_cond), float(t), _ptr(out),
+                                                  buf.data_ptr(), buf.numel(), B, _stream()), "ddpm_forward_sc")
+            return out
         check(self._lib.mcedm_ddpm_forward(self._h, packed.data_ptr(), _ptr(x), float(t), _ptr(out), buf.data_ptr(),
                                            buf.numel(), B, _stream()), "ddpm_forward")
         return out
+
+    def ddim_workspace_bytes(self, B: int) -> int:
+        sz = C.c_size_t()
+        check(self._lib.mcedm_ddim_workspace_bytes(self._h, B, C.byref(sz)), "ddim_workspace_bytes")
+        return sz.value
+
+    def ddim_repaint_sample(self, packed, dd: "DdimDesc", hu, init_noise, eta_noise=None, return_last: bool = True,
+                            ws: Optional[Workspace] = None):
+        """PlDdim.sample_with_repeat on the device -> (xs, x0_preds), both fp32 'b t h w c'."""
+        self._check_x(hu)
+        B = hu.shape[0]
+        ws = ws or Workspace()
+        buf = ws.get(self.ddim_workspace_bytes(B), hu.device)
+        n = dd.num_diffusion_timesteps
+        S = len(range(0, n, n // dd.timesteps)) if dd.skip_type == 0 else dd.timesteps
+        R = self.resolution
+        xs = torch.empty((B, 1 if return_last else S + 1, R, R, self.in_channels), dtype=torch.float32, device=hu.device)
+        x0 = torch.empty((B, 1 if return_last else S, R, R, self.in_channels), dtype=torch.float32, device=hu.device)
+        check(self._lib.mcedm_ddim_repaint_sample(self._h, packed.data_ptr(), C.byref(dd), _ptr(hu), _ptr(init_noise),
+                                                  _ptr(eta_noise), _ptr(xs), _ptr(x0), int(return_last), buf.data_ptr(),
+                                                  buf.numel(), B, _stream()), "ddim_repaint_sample")
+        return xs, x0
 
     def denoise(self, packed, x, sigma: float, c_noise: float, ws: Optional[Workspace] = None, want_F: bool = False):
         self._check_x(x)

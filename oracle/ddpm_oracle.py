@@ -326,11 +326,77 @@ def sample_edm_repaint(P, cfg: DdpmConfig, hu: Tensor, sp: RepaintParams, init_n
     return torch.stack(xs, dim=0).permute(1, 0, 3, 4, 2).contiguous()
 
 
+@dataclass
+class DdimParams:
+    """configs/diff_sampler/ddim_sampler*.yaml (fields PlDdim.sample_with_repeat reads)."""
+    timesteps: int = 50
+    skip_type: str = "uniform"
+    eta: float = 0.0
+    n_repeat: int = 5
+    n_time_h: int = 128
+    n_time_u: int = 0
+
+
+def ddim_sequence(num_timesteps: int, sp: DdimParams) -> List[int]:
+    """models/ddim.py:823-830."""
+    if sp.skip_type == "uniform":
+        return list(range(0, num_timesteps, num_timesteps // sp.timesteps))
+    if sp.skip_type == "quad":
+        return [int(v) for v in (np.linspace(0, np.sqrt(num_timesteps * 0.8), sp.timesteps) ** 2)]
+    raise NotImplementedError(sp.skip_type)
+
+
+def sample_with_repeat(P, cfg: DdpmConfig, hu: Tensor, sp: DdimParams, init_noise: Tensor,
+                       eta_noise: Optional[Sequence[Tensor]] = None, h_ch: int = 1, u_ch: int = 1,
+                       return_last: bool = True) -> Tuple[Tensor, Tensor]:
+    """PlDdim.sample_with_repeat, models/ddim.py:808-913 (guide_dx False, dx_cond False; w irrelevant without dx).  ``hu``
+    [B, C, H, W] normalised joint state, ``init_noise`` replaces randn_like(hu) (:832), ``eta_noise[step]`` the rand_like of
+    :893.  The previous x0 prediction is the network's x_self_cond when cfg.self_cond.  Returns (xs, x0_preds) 'b t h w c'."""
+    betas = betas_of(cfg)
+    aext = alphas_ext_of(betas)
+    a = (1 - betas).cumprod(dim=0)
+    seq = ddim_sequence(cfg.num_timesteps, sp)
+    mask = torch.ones_like(hu)
+    mask[:, 0:h_ch, sp.n_time_h:, :] = 0.0
+    mask[:, h_ch:h_ch + u_ch, sp.n_time_u:, :] = 0.0
+    hu_noise = init_noise
+    x = (hu * a[-1].sqrt() + hu_noise * (1.0 - a[-1]).sqrt()) * mask + hu_noise * (1.0 - mask)
+    n = hu.shape[0]
+    seq_next = [-1] + list(seq[:-1])
+    xs, x0_preds, x0_t = [x], [], None
+    for step, (i, j) in enumerate(zip(reversed(seq), reversed(seq_next))):
+        t = torch.ones(n) * i
+        at = aext.index_select(0, t.long() + 1).view(-1, 1, 1, 1)
+        at_next = aext.index_select(0, (torch.ones(n) * j).long() + 1).view(-1, 1, 1, 1)
+        xt = xs[-1]
+        for k in range(sp.n_repeat):
+            et = model_forward(P, cfg, xt, t, x_self_cond=x0_t if cfg.self_cond else None)
+            x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
+            x0_t = hu * mask + x0_t * (1.0 - mask)
+            if k < sp.n_repeat - 1:
+                xt = at.sqrt() * x0_t + (1 - at).sqrt() * et
+        if abs(sp.eta) > 1e-10:
+            c1 = sp.eta * ((1 - at / at_next) * (1 - at_next) / (1 - at)).sqrt()
+            c2 = ((1 - at_next) - c1 ** 2).sqrt()
+            xt_next = at_next.sqrt() * x0_t + c1 * eta_noise[step] + c2 * et
+        else:
+            c2 = (1 - at_next).sqrt()
+            xt_next = at_next.sqrt() * x0_t + c2 * et
+        xt_next = (at_next.sqrt() * hu + c2 * hu_noise) * mask + xt_next * (1.0 - mask)
+        if return_last:
+            x0_preds, xs = [x0_t], [xt_next]
+        else:
+            x0_preds.append(x0_t)
+            xs.append(xt_next)
+    return (torch.stack(xs, dim=0).permute(1, 0, 3, 4, 2).contiguous(),
+            torch.stack(x0_preds, dim=0).permute(1, 0, 3, 4, 2).contiguous())
+
+
 # --------------------------------------------------------------------------- #
 # evaluation loops of PlDdim (models/ddim.py:294-533): what `trainer.test` runs for BASELINE config 5
 # --------------------------------------------------------------------------- #
-def eval_test_step(P, cfg: DdpmConfig, h: Tensor, u: Tensor, norm_stats, sp: RepaintParams, n_samples: int, system: str,
-                   init: Tensor, step_noise, repeat_noise) -> Dict[str, Tensor]:
+def eval_test_step(P, cfg: DdpmConfig, h: Tensor, u: Tensor, norm_stats, sp, n_samples: int, system: str,
+                   init: Tensor, step_noise=None, repeat_noise=None) -> Dict[str, Tensor]:
     """PlDdim.test_step, models/ddim.py:372-533 with type 'edm', return_last True, select_by_pde False, plot_scaled False.
     h, u: un-normalised 'b t x 1'; norm_stats = (input mean, std, target mean, std); the noises replace the draws of
     sample_edm (:969, :1004, :1037) on the (n b) batch.  Logged scalars are returned under 'log::<name>'."""
@@ -340,7 +406,10 @@ def eval_test_step(P, cfg: DdpmConfig, h: Tensor, u: Tensor, norm_stats, sp: Rep
     state_gt = torch.cat([hn, un], dim=-1)
     nb, n_all = len(h), h.shape[1]
     hu = state_gt.repeat(n_samples, 1, 1, 1).permute(0, 3, 1, 2)
-    xs = sample_edm_repaint(P, cfg, hu, sp, init, step_noise, repeat_noise, return_last=True)
+    if isinstance(sp, DdimParams):       # sparams.type != 'edm': the DDIM sampler with RePaint loops (ddim.py:393-394), fp32 states
+        xs = sample_with_repeat(P, cfg, hu, sp, init, step_noise, return_last=True)[0]
+    else:
+        xs = sample_edm_repaint(P, cfg, hu, sp, init, step_noise, repeat_noise, return_last=True)
     xs_mean = xs.reshape(n_samples, nb, *xs.shape[1:]).mean(dim=0)
     h_last, u_last = xs_mean[:, -1, :, :, 0:1], xs_mean[:, -1, :, :, 1:2]
     out = {"loss_h": mo.l1(h_last, hn), "loss": mo.l1(u_last, un)}

@@ -349,3 +349,20 @@ def eval_cond_inputs(tag: str):
     h = randn(f"evalcond/{tag}/h", B, T, X, 1) * st[1] + st[0]
     u = randn(f"evalcond/{tag}/u", B, T, X, 1) * st[3] + st[2]
     return h, u, randn(f"evalcond/{tag}/init", n * B, T, X, 1)
+
+
+# ---- DDIM sampler with RePaint loops (PlDdim.sample_with_repeat, models/ddim.py:808-913) on the res-32 DDPM U-Net -------------
+# tag -> (timesteps, skip_type, eta, n_repeat, n_time_h, n_time_u)
+DDIM_CASES = {"uni_r2": (5, "uniform", 0.0, 2, 0, 16), "quad_eta_r3": (4, "quad", 0.01, 3, 8, 0)}
+EVAL_DDIM = ("swe_per", 2, 4, "uniform", 0.0, 2, 0, 16)          # system, n_samples, then as above: PlDdim.test_step with type 'ddim'
+
+
+def ddim_inputs(tag: str, B: int = REPAINT_B):
+    """h, u 'b h w c', initial noise (NCHW) and the per-step UNIFORM draws of models/ddim.py:893 (used when eta != 0)."""
+    N = (EVAL_DDIM[2] if tag == "eval" else DDIM_CASES[tag][0])
+    S = CFG_D.resolution
+    h = randn(f"ddim/{tag}/h", B, S, S, 1)
+    u = randn(f"ddim/{tag}/u", B, S, S, 1)
+    init = randn(f"ddim/{tag}/init", B, 2, S, S)
+    eta = [torch.from_numpy(_rng(f"ddim/{tag}/eta{i}").random(size=(B, 2, S, S)).astype(np.float32)) for i in range(max(N, 8))]
+    return h, u, init, eta

@@ -94,6 +94,38 @@ def main():
         known[:, ntu:, :, 1] = False
         assert torch.equal(xs[:, -1][known], torch.cat([h, u], dim=-1).double()[known])
         out[f"{tag}_xs"] = xs
+    # Model.forward with a self-conditioning tensor (ddim_blocks.py:417-420)
+    m, P = build(cfg, 21, sampler_dict())
+    xsc = fx.randn("ddpm/x_self_cond", B, 2, S, S)
+    with torch.no_grad():
+        y = m.model(x, fx.DDPM_T, x_self_cond=xsc)
+        mg.check("Model.forward x_self_cond", dorc.model_forward(P, cfg, x, fx.DDPM_T, x_self_cond=xsc), y, rtol=1e-4, atol=1e-5)
+    out["F_selfcond"] = y
+    # the DDIM sampler with RePaint loops (models/ddim.py:808-913): uniform / quad skipping, eta = 0 and eta != 0 (the
+    # reference's torch.rand_like draw injected), the x0 prediction fed back as x_self_cond
+    for tag, (N, skip, eta, R, nth, ntu) in fx.DDIM_CASES.items():
+        sp = sampler_dict(type="ddim", skip_type=skip, eta=eta, timesteps=N, n_repeat=R, n_time_h=nth, n_time_u=ntu)
+        m, P = build(cfg, 21, sp)
+        h, u, init, etas = fx.ddim_inputs(tag)
+        spo = dorc.DdimParams(timesteps=N, skip_type=skip, eta=eta, n_repeat=R, n_time_h=nth, n_time_u=ntu)
+        nseq = len(dorc.ddim_sequence(cfg.num_timesteps, spo))
+        queue = list(etas)
+        real_rand_like = torch.rand_like
+        torch.rand_like = lambda t_, **k: queue.pop(0).to(t_.dtype)
+        try:
+            with torch.no_grad(), mg._Inject([init]) as inj:
+                xs, x0s = m.sample_with_repeat(h, u, mg._wrap(sp), return_last=False)
+        finally:
+            torch.rand_like = real_rand_like
+        assert not inj.like_queue and xs.dtype == torch.float32 and tuple(xs.shape) == (fx.REPAINT_B, nseq + 1, S, S, 2)
+        assert tuple(x0s.shape) == (fx.REPAINT_B, nseq, S, S, 2) and len(queue) == len(etas) - (nseq if abs(eta) > 1e-10 else 0)
+        hu = torch.cat([h, u], dim=-1).permute(0, 3, 1, 2)
+        with torch.no_grad():
+            xo, x0o = dorc.sample_with_repeat(P, cfg, hu, spo, init, etas, return_last=False)
+        scale = float(xs.abs().max())
+        mg.check(f"PlDdim.sample_with_repeat {tag} xs", xo, xs, rtol=1e-4, atol=1e-5 * scale)
+        mg.check(f"PlDdim.sample_with_repeat {tag} x0", x0o, x0s, rtol=1e-4, atol=1e-5 * float(x0s.abs().max()))
+        out[f"ddim_{tag}_xs"], out[f"ddim_{tag}_x0"] = xs, x0s
     mg.save("ddpm.npz", seed=21, **out)
 
 

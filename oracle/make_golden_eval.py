@@ -75,6 +75,27 @@ def ddpm_cases(out):
         _compare(f"PlDdim.test_step[{tag}]", o, res, logs, out, f"ddpm_{tag}")
         assert tuple(res["traj"].shape) == (fx.EVAL_B, 1, cfg.resolution, cfg.resolution, n, 2)
 
+    # the same loop with the default sampler type: diff_sampler: ddim_sampler -> sample_with_repeat (models/ddim.py:393-394)
+    system, n, N, skip, eta, R, nth, ntu = fx.EVAL_DDIM
+    sp = mgd.sampler_dict(type="ddim", skip_type=skip, eta=eta, timesteps=N, n_repeat=R, n_time_h=nth, n_time_u=ntu, n_samples=n)
+    m, P = mgd.build(cfg, 21, sp)
+    logs = {}
+    _record(m, logs)
+    _stats(m, st)
+    m.set_pde_loss_function(system, False)
+    h, u, init, _ = fx.ddim_inputs("eval", B=n * fx.EVAL_B)
+    h, u = h[:fx.EVAL_B] * st[1] + st[0], u[:fx.EVAL_B] * st[3] + st[2]
+    with torch.no_grad(), mg._Inject([init]) as inj:
+        res = m.test_step((h, None, None, u), 0)
+    assert not inj.like_queue and res["traj"].dtype == torch.float32
+    spo = dorc.DdimParams(timesteps=N, skip_type=skip, eta=eta, n_repeat=R, n_time_h=nth, n_time_u=ntu)
+    with torch.no_grad():
+        o = dorc.eval_test_step(P, cfg, h, u, st, spo, n, system, init)
+    o["log::test_mae_h"], o["log::test_mae_u"] = o["loss_h"], o["loss"]
+    o["log::test_mae_h_un"], o["log::test_mae_u_un"] = o["loss_h_un"], o["loss_u_un"]
+    o["log::test_mae_u_scaled"] = o["test_mae_u_scaled"]
+    _compare("PlDdim.test_step[ddim sampler]", o, res, logs, out, "ddpm_ddim")
+
     system, n, N, R, churn, nth, ntu = fx.EVAL_DDPM_VAL
     sp = mgd.sampler_dict(timesteps=N, n_repeat=R, S_churn=churn, n_time_h=nth, n_time_u=ntu)
     m, P = mgd.build(cfg, 21, sp)

@@ -227,3 +227,43 @@ def test_plddim_sample_edm_device_noise_graph_and_seed(monkeypatch):
     assert torch.equal(a[:, 0, :ntu, :, 1], u[:, :ntu, :, 0].double()), "known rows of u are the clean data"
     monkeypatch.setenv("MCEDM_HIP_GRAPH", "0")
     assert torch.equal(run(5), a), "graph replay and eager launches must agree bit for bit"
+
+
+def test_model_forward_with_self_conditioning_golden(net, golden):
+    """Model.forward(x, t, x_self_cond) (ddim_blocks.py:417-420): the self-conditioning half of conv_in's input."""
+    L, plan, packed, P = net
+    g = golden("ddpm.npz")
+    x = fx.randn("ddpm/x", 3, 2, CFG.resolution, CFG.resolution).cuda()
+    xsc = fx.randn("ddpm/x_self_cond", 3, 2, CFG.resolution, CFG.resolution).cuda()
+    close(plan.forward(packed, x, float(fx.DDPM_T), x_self_cond=xsc), g["F_selfcond"], what="Model.forward x_self_cond")
+    assert not torch.equal(plan.forward(packed, x, float(fx.DDPM_T), x_self_cond=xsc), plan.forward(packed, x, float(fx.DDPM_T)))
+
+
+@pytest.mark.parametrize("tag", list(fx.DDIM_CASES))
+def test_ddim_repaint_sample_golden(net, golden, tag):
+    """mcedm_ddim_repaint_sample = PlDdim.sample_with_repeat (models/ddim.py:808-913): uniform / quad skipping, eta = 0 and
+    eta != 0 (the reference's uniform rand_like draw), x0 prediction fed back as x_self_cond; against the reference's outputs."""
+    L, plan, packed, P = net
+    g = golden("ddpm.npz")
+    N, skip, eta, R, nth, ntu = fx.DDIM_CASES[tag]
+    h, u, init, etas = fx.ddim_inputs(tag)
+    hu = torch.cat([h, u], dim=-1).permute(0, 3, 1, 2).contiguous()
+    sp = dorc.DdimParams(timesteps=N, skip_type=skip, eta=eta, n_repeat=R, n_time_h=nth, n_time_u=ntu)
+    dd, keep = L.ddim_desc(sp, dorc.alphas_ext_of(dorc.betas_of(CFG)), 1, 1, True)
+    nseq = len(dorc.ddim_sequence(CFG.num_timesteps, sp))
+    eta_noise = torch.stack(etas[:nseq]).cuda() if abs(eta) > 1e-10 else None
+    xs, x0 = plan.ddim_repaint_sample(packed, dd, hu.cuda(), init.cuda(), eta_noise, return_last=False)
+    for got, key in ((xs, "xs"), (x0, "x0")):
+        ref = torch.as_tensor(g[f"ddim_{tag}_{key}"])
+        print(f"ddim {tag} {key}: max|d| = {float((got.cpu() - ref).abs().max()):.3e} on max|x| = {float(ref.abs().max()):.1f}")
+        close(got, ref, atol=1e-5 * float(ref.abs().max()), what=f"ddim {tag} {key}")
+    last_xs, last_x0 = plan.ddim_repaint_sample(packed, dd, hu.cuda(), init.cuda(), eta_noise, return_last=True)
+    assert torch.equal(last_xs[:, 0], xs[:, -1]) and torch.equal(last_x0[:, 0], x0[:, -1])
+    # known rows of every x0 prediction are the clean data (ddim.py:878-879)
+    known = torch.ones(fx.REPAINT_B, CFG.resolution, CFG.resolution, 2, dtype=torch.bool)
+    known[:, nth:, :, 0] = False
+    known[:, ntu:, :, 1] = False
+    assert torch.equal(x0[:, -1].cpu()[known], torch.cat([h, u], dim=-1)[known])
+    if abs(eta) > 1e-10:
+        with pytest.raises(RuntimeError, match="eta_noise"):
+            plan.ddim_repaint_sample(packed, dd, hu.cuda(), init.cuda(), None)

@@ -166,3 +166,26 @@ def test_plcondedm_validation_step_golden(golden, monkeypatch):
     _compare(g, "cond_val", res, logs)
     m.current_epoch = 7
     assert m.validation_step(batch, 0) == {"epoch": 7}
+
+
+def test_plddim_test_step_with_the_ddim_sampler_golden(golden, monkeypatch):
+    """sparams.type == 'ddim' (configs/diff_sampler/ddim_sampler.yaml, the reference's default): test_step runs
+    sample_with_repeat (models/ddim.py:393-394) = mcedm_ddim_repaint_sample; states are fp32 there."""
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd.ddim import PlDdim
+    g = golden("eval_steps.npz")
+    system, n, N, skip, eta, R, nth, ntu = fx.EVAL_DDIM
+    sp = wrap(dict(name="ddim", type="ddim", timesteps=N, skip_type=skip, eta=eta, n_samples=n, n_repeat=R, n_time_h=nth, n_time_u=ntu,
+                   return_last=True, select_by_pde=False, use_gt_pde_select=True, guide_dx=False, w=0.0, plot_scaled=False))
+    m = PlDdim(ddpm_hparams(sp)).cuda()
+    st = fx.EVAL_DDPM_STATS
+    logs = _fill(m, dorc.make_params(fx.CFG_D, 21), st, system)
+    m.set_test_sampler_params(sp)
+    h, u, init, _ = fx.ddim_inputs("eval", B=n * fx.EVAL_B)
+    h, u = h[:fx.EVAL_B] * st[1] + st[0], u[:fx.EVAL_B] * st[3] + st[2]
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: init.to(t.device))
+    res = m.test_step((h.cuda(), None, None, u.cuda()), 0)
+    monkeypatch.undo()
+    _compare(g, "ddpm_ddim", res, logs)
+    with pytest.raises(NotImplementedError):
+        m.sample(None, None, sp)

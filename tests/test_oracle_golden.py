@@ -303,3 +303,40 @@ def test_eval_plcondedm_steps(golden, tag):
             system, n, guided, st = fx.EVAL_COND_CASES[tag]
             o = orc.eval_cond_test_step(P, cfg, h, u, st, orc.SamplerParams(), n, system, init, guidance=guided)
     assert _check_eval(g, f"cond_{tag}", o) >= 2
+
+
+# ---- DDIM sampler with RePaint loops (PlDdim.sample_with_repeat, models/ddim.py:808-913) ----------------------------------
+@pytest.mark.parametrize("tag", list(fx.DDIM_CASES))
+def test_ddim_sample_with_repeat(golden, tag):
+    from oracle import ddpm_oracle as dorc
+    g = golden("ddpm.npz")
+    cfg = fx.CFG_D
+    P = dorc.make_params(cfg, int(g["seed"]))
+    N, skip, eta, R, nth, ntu = fx.DDIM_CASES[tag]
+    h, u, init, etas = fx.ddim_inputs(tag)
+    hu = torch.cat([h, u], dim=-1).permute(0, 3, 1, 2)
+    sp = dorc.DdimParams(timesteps=N, skip_type=skip, eta=eta, n_repeat=R, n_time_h=nth, n_time_u=ntu)
+    with torch.no_grad():
+        xs, x0 = dorc.sample_with_repeat(P, cfg, hu, sp, init, etas, return_last=False)
+    close(xs, g[f"ddim_{tag}_xs"], rtol=1e-5, atol=1e-6 * float(np.abs(g[f"ddim_{tag}_xs"]).max()))
+    close(x0, g[f"ddim_{tag}_x0"], rtol=1e-5, atol=1e-6 * float(np.abs(g[f"ddim_{tag}_x0"]).max()))
+    xsc = fx.randn("ddpm/x_self_cond", 3, 2, cfg.resolution, cfg.resolution)
+    with torch.no_grad():
+        y = dorc.model_forward(P, cfg, fx.randn("ddpm/x", 3, 2, cfg.resolution, cfg.resolution), fx.DDPM_T, x_self_cond=xsc)
+    close(y, g["F_selfcond"], rtol=1e-5, atol=1e-6)
+
+
+def test_eval_plddim_test_step_with_the_ddim_sampler(golden):
+    """PlDdim.test_step with sparams.type == 'ddim' (the default diff_sampler: models/ddim.py:393-394)."""
+    from oracle import ddpm_oracle as dorc
+    g = golden("eval_steps.npz")
+    cfg = fx.CFG_D
+    P = dorc.make_params(cfg, 21)
+    system, n, N, skip, eta, R, nth, ntu = fx.EVAL_DDIM
+    st = fx.EVAL_DDPM_STATS
+    h, u, init, _ = fx.ddim_inputs("eval", B=n * fx.EVAL_B)
+    h, u = h[:fx.EVAL_B] * st[1] + st[0], u[:fx.EVAL_B] * st[3] + st[2]
+    with torch.no_grad():
+        o = dorc.eval_test_step(P, cfg, h, u, st, dorc.DdimParams(timesteps=N, skip_type=skip, eta=eta, n_repeat=R, n_time_h=nth,
+                                                                   n_time_u=ntu), n, system, init)
+    assert _check_eval(g, "ddpm_ddim", o) >= 3
