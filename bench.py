@@ -446,7 +446,8 @@ def main():
         train_ms = (time.perf_counter() - t1) / nt * 1e3
         assert torch.isfinite(loss).all()
         train_prof = None
-        if rank == 0:             # one more step, launched eagerly with HIP event pairs around every kernel
+        if world == 1:            # one more step, launched eagerly with HIP event pairs around every kernel (single rank
+                                  # only: a step contains the gradient all-reduce, which every rank must enter)
             ts.use_graph = False
             ts.step(xs, run.cond, run.mask, nz, rn)
             torch.cuda.synchronize()

@@ -504,6 +504,114 @@ __global__ __launch_bounds__(64 * KW) __attribute__((amdgpu_waves_per_eu(3, 3)))
   }
 }
 
+// Long sequences (T >= 512: the 32 x 32 level of the ch = 64 networks, one head over 1024 tokens): the four waves of a
+// workgroup take four DIFFERENT query tiles and stream the SAME key / value tiles, which are staged once per workgroup in
+// LDS (double-buffered, one barrier per 32-key tile) instead of being read from L2 by every wave: a quarter of the L2
+// traffic of the split kernel (512 MB per launch at B = 32) and no dependence on latency-hiding by occupancy.  K tile
+// [64 ch][32 keys]; V tile transposed to [32 keys][64 ch] with pitch 65 so that both MFMA operand reads are lane-linear.
+__global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T) {
+  constexpr int VP = 65;                                   // pitch of the transposed V tile
+  __shared__ float ks[2][64 * 32];
+  __shared__ float vs[2][32 * VP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const size_t bh = blockIdx.y;
+  const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
+  const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
+  const int q = q0 + l31;
+  const int qc = q < T ? q : T - 1;
+  float qreg[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) qreg[s] = Q[(size_t)(2 * s + h) * T + qc] * (0.125f * 1.44269504088896340736f);
+
+  // staging: thread owns float4 number tid and tid + 256 of each 64 x 32 tile: row c = idx / 8, keys 4 (idx % 8) .. + 3
+  const int c0 = tid >> 3, kq = tid & 7;
+  f32x4 rk[2], rv[2];
+  auto fetch = [&](int k0) {                                 // T % 4 == 0 and 16-byte aligned rows (checked by the launcher)
+    const int kk = min(k0 + 4 * kq, T - 4);                  // a ragged last tile re-reads valid keys; they are masked below
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rk[u] = *reinterpret_cast<const f32x4*>(K + (size_t)(c0 + 32 * u) * T + kk);
+      rv[u] = *reinterpret_cast<const f32x4*>(V + (size_t)(c0 + 32 * u) * T + kk);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      *reinterpret_cast<f32x4*>(&ks[buf][(c0 + 32 * u) * 32 + 4 * kq]) = rk[u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vs[buf][(4 * kq + e) * VP + c0 + 32 * u] = rv[u][e];
+    }
+  };
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  const int ntile = (T + 31) / 32;
+  for (int it = 0; it < ntile; ++it) {
+    const int k0 = it * 32, buf = it & 1;
+    if (it + 1 < ntile) fetch(k0 + 32);
+    const bool full = (k0 + 32 <= T);
+    const float* kt = ks[buf] + h * 32 + l31;                // + 64 st: channel 2 st + h, key l31
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 32; ++st) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[64 * st], qreg[st], s, 0, 0, 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (!full && key >= T) s[r] = -INFINITY;
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float p[16];
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+      rs += p[r];
+    }
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // O[c][q] += sum_key V[c][key] P[key][q]: MFMA step r contracts keys (r&3) + 8 (r>>2) + 4 h of the tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* vt = vs[buf] + 32 * i + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[((r & 3) + 8 * (r >> 2) + 4 * h) * VP], p[r], o[i], 0, 0, 0);
+    }
+    if (it + 1 < ntile) commit(buf ^ 1);                     // the other buffer: its last readers passed the previous barrier
+    __syncthreads();
+  }
+  if (q < T) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[(bh * 64 + c) * (size_t)T + q] = o[i][r] * inv;
+      }
+  }
+}
+
 static int attn_split_env() {          // MCEDM_ATTN_SPLIT=0: the one-wave-per-query-tile kernel everywhere (A/B runs)
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_ATTN_SPLIT"); env = e ? atoi(e) : 1; }
@@ -516,7 +624,10 @@ int launch_attention(const float* qkv, float* out, int B, int heads, int T, hipS
   ProfScope ps("attention_kernel", 4.0 * B * heads * (double)T * T * 64, 4.0 * 4 * B * heads * 64.0 * T, stream);
   // the split factor is a function of T only (never of the batch size): results are identical under batch sharding
   const dim3 grid(ceil_div(T, 32), B * heads);
-  if (attn_split_env() && T >= 256) hipLaunchKernelGGL(attention_split_kernel<4>, grid, dim3(256), 0, stream, qkv, out, T);
+  const bool aligned = (T % 4 == 0) && ((reinterpret_cast<size_t>(qkv) & 15) == 0);
+  if (attn_split_env() >= 1 && attn_split_env() != 2 && T >= 512 && aligned)      // MCEDM_ATTN_SPLIT=2: split kernel for every T (A/B)
+    hipLaunchKernelGGL(attention_lds_kernel, dim3(ceil_div(T, 128), B * heads), dim3(256), 0, stream, qkv, out, T);
+  else if (attn_split_env() && T >= 256) hipLaunchKernelGGL(attention_split_kernel<4>, grid, dim3(256), 0, stream, qkv, out, T);
   else if (attn_split_env() && T >= 128) hipLaunchKernelGGL(attention_split_kernel<2>, grid, dim3(128), 0, stream, qkv, out, T);
   else hipLaunchKernelGGL(attention_kernel, grid, dim3(64), 0, stream, qkv, out, T);
   MCEDM_LAUNCH_CHECK("attention_kernel");
