@@ -1,6 +1,7 @@
 // norm_emb_attn.hip -- K1 (GroupNorm statistics -> per-channel transform table), K6 (sigma
 // embedding MLP + every FiLM affine row) and K5 (fused softmax attention on fp32 MFMA).
 #include <cstdlib>
+#include <atomic>
 #include "common.hpp"
 #include "prof.hpp"
 
@@ -504,18 +505,24 @@ __global__ __launch_bounds__(64 * KW) __attribute__((amdgpu_waves_per_eu(3, 3)))
   }
 }
 
-// Long sequences (T >= 512: the 32 x 32 level of the ch = 64 networks, one head over 1024 tokens): the four waves of a
-// workgroup take four DIFFERENT query tiles and stream the SAME key / value tiles, which are staged once per workgroup in
-// LDS (double-buffered, one barrier per 32-key tile) instead of being read from L2 by every wave: a quarter of the L2
-// traffic of the split kernel (512 MB per launch at B = 32) and no dependence on latency-hiding by occupancy.  K tile
-// [64 ch][32 keys]; V tile transposed to [32 keys][64 ch] with pitch 65 so that both MFMA operand reads are lane-linear.
-__global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T) {
-  constexpr int VP = 65;                                   // pitch of the transposed V tile
-  __shared__ float ks[2][64 * 32];
-  __shared__ float vs[2][32 * VP];
+// Long sequences (T >= 512: the 32 x 32 level of the ch = 64 networks, one head over 1024 tokens): the waves of a workgroup
+// take four DIFFERENT query tiles and stream the SAME key / value tiles, which are staged once per workgroup in LDS
+// (double-buffered, one barrier per tile) instead of being read from L2 by every wave: a quarter of the L2 traffic of the
+// split kernel (512 MB per launch at B = 32) and no dependence on latency-hiding by occupancy.  KH = 2: eight waves, waves
+// 4..7 take the odd 32-key tiles of the same four query tiles (two waves per SIMD: one wave's softmax runs under the
+// other's MFMAs) and the halves are merged in LDS at the end, half 0 first (a fixed order: bitwise reproducible).
+// K tile [64 ch][32 KH keys]; V tile transposed to [32 KH keys][64 ch] with pitch 65: both MFMA operand reads lane-linear.
+template <int KH>
+__global__ __launch_bounds__(256 * KH) void attention_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T) {
+  constexpr int VP = 65, NK = 32 * KH;                     // pitch of the transposed V tile; keys per staged tile
+  constexpr int KS_F = 64 * NK, VS_F = NK * VP;
+  extern __shared__ float lds[];                           // ks[2][KS_F] | vs[2][VS_F]; reused for the merge
+  float* ks = lds;
+  float* vs = lds + 2 * KS_F;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = wave & 3, hf = wave >> 2;
   const int l31 = lane & 31, h = lane >> 5;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = (blockIdx.x * 4 + qt) * 32;
   const size_t bh = blockIdx.y;
   const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
   const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
@@ -526,11 +533,11 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restr
 #pragma unroll
   for (int s = 0; s < 32; ++s) qreg[s] = Q[(size_t)(2 * s + h) * T + qc] * (0.125f * 1.44269504088896340736f);
 
-  // staging: thread owns float4 number tid and tid + 256 of each 64 x 32 tile: row c = idx / 8, keys 4 (idx % 8) .. + 3
-  const int c0 = tid >> 3, kq = tid & 7;
+  // staging: 64 rows x 8 KH float4 per tile, two per thread: row c0 (+ 32), keys 4 kq .. 4 kq + 3
+  const int c0 = tid / (8 * KH), kq = tid % (8 * KH);
   f32x4 rk[2], rv[2];
   auto fetch = [&](int k0) {                                 // T % 4 == 0 and 16-byte aligned rows (checked by the launcher)
-    const int kk = min(k0 + 4 * kq, T - 4);                  // a ragged last tile re-reads valid keys; they are masked below
+    const int kk = min(k0 + 4 * kq, T - 4);                  // past the end: re-reads valid keys; they are masked below
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       rk[u] = *reinterpret_cast<const f32x4*>(K + (size_t)(c0 + 32 * u) * T + kk);
@@ -540,9 +547,9 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restr
   auto commit = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      *reinterpret_cast<f32x4*>(&ks[buf][(c0 + 32 * u) * 32 + 4 * kq]) = rk[u];
+      *reinterpret_cast<f32x4*>(&ks[buf * KS_F + (c0 + 32 * u) * NK + 4 * kq]) = rk[u];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vs[buf][(4 * kq + e) * VP + c0 + 32 * u] = rv[u][e];
+      for (int e = 0; e < 4; ++e) vs[buf * VS_F + (4 * kq + e) * VP + c0 + 32 * u] = rv[u][e];
     }
   };
   float m = -INFINITY, l = 0.f;
@@ -554,17 +561,17 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restr
   fetch(0);
   commit(0);
   __syncthreads();
-  const int ntile = (T + 31) / 32;
+  const int ntile = (T + NK - 1) / NK;
   for (int it = 0; it < ntile; ++it) {
-    const int k0 = it * 32, buf = it & 1;
-    if (it + 1 < ntile) fetch(k0 + 32);
+    const int k0 = it * NK + 32 * hf, buf = it & 1;
+    if (it + 1 < ntile) fetch((it + 1) * NK);
     const bool full = (k0 + 32 <= T);
-    const float* kt = ks[buf] + h * 32 + l31;                // + 64 st: channel 2 st + h, key l31
+    const float* kt = ks + buf * KS_F + h * NK + 32 * hf + l31;   // + 2 NK st: channel 2 st + h, key 32 hf + l31
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int st = 0; st < 32; ++st) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[64 * st], qreg[st], s, 0, 0, 0);
+    for (int st = 0; st < 32; ++st) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[2 * NK * st], qreg[st], s, 0, 0, 0);
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -574,33 +581,57 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restr
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    float p[16];
-    float rs = 0.f;
+    if (m_new > -INFINITY) {                                 // a wave whose first tile lies wholly past T has nothing to add yet
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      float p[16];
+      float rs = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      p[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
-      rs += p[r];
-    }
-    rs += __shfl_xor(rs, 32);
-    l = l * alpha + rs;
-    m = m_new;
+      for (int r = 0; r < 16; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+        rs += p[r];
+      }
+      rs += __shfl_xor(rs, 32);
+      l = l * alpha + rs;
+      m = m_new;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    // O[c][q] += sum_key V[c][key] P[key][q]: MFMA step r contracts keys (r&3) + 8 (r>>2) + 4 h of the tile
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      // O[c][q] += sum_key V[c][key] P[key][q]: MFMA step r contracts keys (r&3) + 8 (r>>2) + 4 h of the wave's 32-key tile
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float* vt = vs[buf] + 32 * i + l31;
+      for (int i = 0; i < 2; ++i) {
+        const float* vt = vs + buf * VS_F + 32 * hf * VP + 32 * i + l31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[((r & 3) + 8 * (r >> 2) + 4 * h) * VP], p[r], o[i], 0, 0, 0);
+        for (int r = 0; r < 16; ++r)
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[((r & 3) + 8 * (r >> 2) + 4 * h) * VP], p[r], o[i], 0, 0, 0);
+      }
     }
     if (it + 1 < ntile) commit(buf ^ 1);                     // the other buffer: its last readers passed the previous barrier
     __syncthreads();
   }
-  if (q < T) {
+  if (KH == 2) {                                             // merge the two key halves (all tiles are past their last barrier)
+    float* mg = lds + (size_t)(qt * 64 + lane) * 35;         // pitch 35: conflict-free for lane-linear access
+    if (hf == 1) {
+      mg[0] = m;
+      mg[1] = l;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mg[2 + 16 * i + r] = o[i][r];
+    }
+    __syncthreads();
+    if (hf == 0) {
+      const float m1 = mg[0], l1 = mg[1];
+      const float mm = fmaxf(m, m1);
+      const float a0 = __builtin_amdgcn_exp2f(m - mm), a1 = m1 > -INFINITY ? __builtin_amdgcn_exp2f(m1 - mm) : 0.f;
+      l = l * a0 + l1 * a1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + mg[2 + 16 * i + r] * a1;
+    }
+  }
+  if (hf == 0 && q < T) {
     const float inv = 1.0f / l;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -612,9 +643,30 @@ __global__ __launch_bounds__(256) void attention_lds_kernel(const float* __restr
   }
 }
 
+template <int KH>
+static int launch_attention_lds(const float* qkv, float* out, int B, int heads, int T, hipStream_t stream) {
+  constexpr int lds_bytes = (2 * 64 * 32 * KH + 2 * 32 * KH * 65) * 4;
+  static_assert(KH == 1 || lds_bytes >= 4 * 64 * 35 * 4, "merge scratch");
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  MCEDM_HIP_TRY(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !attr_set[dev].load(std::memory_order_acquire)) {
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)attention_lds_kernel<KH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(attention_lds_kernel<KH>, dim3(ceil_div(T, 128), B * heads), dim3(256 * KH), lds_bytes, stream, qkv, out, T);
+  return MCEDM_OK;
+}
+
 static int attn_split_env() {          // MCEDM_ATTN_SPLIT=0: the one-wave-per-query-tile kernel everywhere (A/B runs)
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_ATTN_SPLIT"); env = e ? atoi(e) : 1; }
+  return env;
+}
+
+static int attn_lds_min_env() {        // MCEDM_ATTN_LDS_MIN: shortest sequence that takes the LDS-staged kernel (A/B runs)
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_ATTN_LDS_MIN"); env = e ? atoi(e) : 512; }
   return env;
 }
 
@@ -624,9 +676,15 @@ int launch_attention(const float* qkv, float* out, int B, int heads, int T, hipS
   ProfScope ps("attention_kernel", 4.0 * B * heads * (double)T * T * 64, 4.0 * 4 * B * heads * 64.0 * T, stream);
   // the split factor is a function of T only (never of the batch size): results are identical under batch sharding
   const dim3 grid(ceil_div(T, 32), B * heads);
+  // LDS-staged kernel for long sequences, chosen by T alone like the split factor (at B * heads < 24 it fills fewer CUs than
+  // the split kernel would: 91 vs 45 us at B = 8 -- accepted for the batch-sharding invariance).  MCEDM_ATTN_SPLIT=2: split
+  // kernel for every T, 3: the four-wave variant of the LDS kernel (A/B switches)
   const bool aligned = (T % 4 == 0) && ((reinterpret_cast<size_t>(qkv) & 15) == 0);
-  if (attn_split_env() >= 1 && attn_split_env() != 2 && T >= 512 && aligned)      // MCEDM_ATTN_SPLIT=2: split kernel for every T (A/B)
-    hipLaunchKernelGGL(attention_lds_kernel, dim3(ceil_div(T, 128), B * heads), dim3(256), 0, stream, qkv, out, T);
+  const int mode = attn_split_env();
+  if (mode >= 1 && mode != 2 && T >= attn_lds_min_env() && aligned) {
+    const int rc = mode == 3 ? launch_attention_lds<1>(qkv, out, B, heads, T, stream) : launch_attention_lds<2>(qkv, out, B, heads, T, stream);
+    if (rc != MCEDM_OK) return rc;
+  }
   else if (attn_split_env() && T >= 256) hipLaunchKernelGGL(attention_split_kernel<4>, grid, dim3(256), 0, stream, qkv, out, T);
   else if (attn_split_env() && T >= 128) hipLaunchKernelGGL(attention_split_kernel<2>, grid, dim3(128), 0, stream, qkv, out, T);
   else hipLaunchKernelGGL(attention_kernel, grid, dim3(64), 0, stream, qkv, out, T);

@@ -352,9 +352,11 @@ def test_attention_golden(lib, golden, T):
 
 
 @pytest.mark.parametrize("B,heads,hw,scale", [(2, 1, (32, 32), 1.0), (1, 2, (4, 4), 1.0), (1, 1, (6, 6), 1.0),
-                                              (1, 1, (2, 2), 1.0), (2, 1, (8, 8), 6.0)])
+                                              (1, 1, (2, 2), 1.0), (2, 1, (8, 8), 6.0), (1, 2, (22, 26), 1.0),
+                                              (1, 1, (32, 20), 2.0), (1, 1, (23, 23), 1.0)])
 def test_attention_vs_oracle(lib, B, heads, hw, scale):
-    # ragged token counts (36, 4), one full 1024-token case, and a peaked-softmax case (scale 6)
+    # ragged token counts (36, 4), one full 1024-token case, and a peaked-softmax case (scale 6); 572 and 640 tokens take the
+    # LDS-staged long-sequence kernel with a ragged last key tile / query block, 529 (not a multiple of 4) must not
     qkv = fx.randn(f"t/attn/{B}{heads}{hw}{scale}", B, heads * 192, *hw) * scale
     a = lib.op_attention(dev(packed_qkv(qkv, heads)), heads)
     close(a, orc.attention(qkv, heads), what="attention")
@@ -367,6 +369,12 @@ def test_attention_online_softmax_rescale(lib):
     k[0, :, 120] = q[0, :, 5] * 4.0
     a = lib.op_attention(dev(packed_qkv(qkv, 1)), 1)
     close(a, orc.attention(qkv, 1), what="attention spike")
+    # the same in the long-sequence kernel: the spike sits in the last of 20 key tiles
+    qkv = fx.randn("t/attn/spike640", 1, 192, 20, 32)
+    q, k, v = qkv.reshape(1, 64, 3, 640).unbind(2)
+    k[0, :, 630] = q[0, :, 133] * 4.0
+    a = lib.op_attention(dev(packed_qkv(qkv, 1)), 1)
+    close(a, orc.attention(qkv, 1), what="attention spike, 640 tokens")
 
 
 # ------------------------------------------------------------------ whole blocks out of the ops
