@@ -155,6 +155,7 @@ static int dgrad(const Ctx& c, const ConvP& cv, const float* dy, int H, int W, f
   a.xa = dy; a.Ca = cv.cout;
   a.Hs = H; a.Ws = W; a.H = H; a.W = W;
   a.wpk = c.pk + cv.wpk_dgrad;
+  a.wino = cv.wino_dgrad != NONE ? c.pk + cv.wino_dgrad : nullptr;
   a.out = out; a.Cout = cv.cin; a.B = c.B;
   return launch_conv(a, cv.taps, c.s);
 }

@@ -105,6 +105,7 @@ struct ConvArgs {
   int Hs, Ws;        // source spatial size
   int H, W;          // conv input == output spatial size
   const float* wpk;  // packed weights (see pack_conv_weights)
+  const float* wino; // optional: the same weights in Winograd F(2x2, 3x3) form (launch_pack_conv_wino), or null
   const float* bias; // [Cout] (packed order) or null
   const float* res;  // residual [B, Cout, Hr, Wr] or null
   int res_mode;      // Resample applied to the residual source
@@ -130,6 +131,12 @@ struct ConvArgs {
 };
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t stream);
+// conv_wino.hip: Winograd F(2x2, 3x3) kernel for un-resampled 3x3 convs with Cout % 128 == 0 on (8, 16)-divisible images
+size_t conv_wino_packed_floats(int Cout, int Cin);
+int launch_pack_conv_wino(const float* w, float* dst, int Cout, int Cin, int transpose_flip, hipStream_t stream);   // w [Cout][Cin][3][3]; transpose_flip: w is [Cin][Cout][3][3], build the data-gradient weights
+bool conv_wino_applicable(const ConvArgs& a, int taps);
+bool conv_wino_preferred(const ConvArgs& a);              // env MCEDM_WINOGRAD (default on), MCEDM_WINO_MIN_HW (default 32 x 32)
+int launch_conv_wino(const ConvArgs& a, hipStream_t stream);
 static inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }     // channel padding of the packed tables
 int conv_resolve_identity(ConvArgs& a);                  // points a missing transform table at the identity row
 unsigned long long* conv_debug_buffer();

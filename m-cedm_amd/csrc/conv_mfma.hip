@@ -898,6 +898,9 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {
   if (taps == 9 && a.Cout <= 4 && a.resample == RS_NONE && !a.res && !a.gsum && !g_force_mt && (long long)a.H * a.W >= 4096)
     return launch_small_cout(a, stream);
   if (a.resample == RS_S2) return dispatch_s2(a, stream);
+  // Winograd F(2x2, 3x3) kernel (conv_wino.hip) where the launch carries its weight table and the shape fits: chosen by shape
+  // alone (never by the batch size), like every other tile choice here
+  if (!g_force_mt && taps == 9 && a.wino && conv_wino_preferred(a) && conv_wino_applicable(a, taps)) return launch_conv_wino(a, stream);
   if (!g_force_mt) {     // small images: the input-resident kernel (conv_resident.hip), bit-identical per tile configuration
     const int rc = try_launch_conv_resident(a, taps, stream);
     if (rc != -1) return rc;

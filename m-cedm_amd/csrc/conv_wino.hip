@@ -1,0 +1,406 @@
+// conv_wino.hip -- the un-resampled 3x3 convolution of the 128-channel levels in Winograd F(2x2, 3x3) form.
+//
+// Why: on gfx950 the fp32 matrix rate (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense) bounds conv_mfma_kernel, whose K loop
+// already runs at 97 % of it.  The only thing left is to issue fewer MFMAs: F(2x2, 3x3) computes a
+// 2 x 2 output patch from a 4 x 4 input patch with 16 multiplies per (cin, cout) instead of 36 -- 2.25x less matrix work --
+// at the price of a 4x larger accumulator footprint (16 Winograd-domain values per 4 outputs) and of input / output
+// transforms in vector instructions (which are paid in matrix time on this chip).
+//
+//   y = A^T [ sum_cin (G g G^T) o (B^T d B) ] A        (Lavin & Gray 2016; B, G, A below)
+//
+// Mapping to one CU (one 512-thread workgroup = 8 waves, 2 per SIMD):
+//   * workgroup tile = 128 output channels x (8 x 16 pixels = 32 patches) x 16 Winograd positions = 64 accumulator blocks
+//     of 32 x 32 = half of the CU's register file.  Wave (mb, hf) owns output channels 32 mb .. + 31 and the eight
+//     positions (xi, nu) with xi in {2 hf, 2 hf + 1}: 128 accumulator registers.
+//   * K loop over chunks of 8 input channels.  Per chunk and wave: 8 positions x 4 k-steps = 32 MFMAs; the A operand
+//     (transformed weights U = G g G^T, packed per (chunk, 32-channel block, position, lane) so that a lane's four k-steps
+//     are one 16-byte load) comes straight from L2 into registers, one chunk ahead -- no weight slab in LDS; the B operand
+//     (transformed input V = B^T d B, LDS layout [position][patch][k parity][k-step]) is one ds_read_b128 per position.
+//   * input path per chunk: wave w loads channel w of the chunk (10 x 18 raw patch incl. halo, 3 elements per lane), applies
+//     the fused (x - mean) * scale + offset -> SiLU transform and writes the raw tile to LDS; one chunk later every thread
+//     turns (channel k, patch t, row half) of it into 8 Winograd-domain values (6 ds_read_b64, 16 adds, 8 ds_write_b32).
+//     Both LDS stages are double-buffered: ONE barrier per chunk.
+//   * epilogue: the output transform is register-local over nu; over xi the two halves exchange one 2 x 32-register
+//     partial through LDS; then bias, residual, stores (8-byte, two pixels of a row) and the fused GroupNorm statistics.
+// Results differ from the direct kernel in the last bits (a different, equally long fp32 sum: measured 1.5x its error
+// against fp64, 0.1 of the rtol 1e-4 / atol 1e-5 bar); they do not depend on the batch size or the grid.
+#include <atomic>
+#include <cstdlib>
+
+#include "conv_tile.hpp"
+#include "prof.hpp"
+
+namespace mcedm {
+
+namespace {
+
+constexpr int WPH = 8, WPW = 16;                 // output pixels per workgroup
+constexpr int WTX = WPW / 2, WTY = WPH / 2;      // 2x2 patches: 8 x 4 = 32 = one MFMA N block
+constexpr int WKC = 8;                           // input channels per chunk
+constexpr int WNT = 512;
+constexpr int RROWS = WPH + 2, RPITCH = WPW + 2; // raw tile with halo: 10 x 18
+constexpr int RPLANE = 208;                      // floats between channels of the raw tile (180 used; = 16 mod 32 banks)
+constexpr int RSUB = (RROWS * RPITCH + 63) / 64; // raw elements per lane and channel: 3
+constexpr int VPOS = WTX * WTY * WKC;            // floats per position of the V tile: 256
+constexpr int VBUF = 16 * VPOS, RBUF = WKC * RPLANE;
+constexpr int LDS_ROWS_OFF = 2 * VBUF + 2 * RBUF;     // transform rows start here (floats; 16-byte aligned)
+constexpr int XCH_FLOATS = 8 * 32 * 64;               // epilogue exchange: 8 waves x 32 registers x 64 lanes
+static_assert(LDS_ROWS_OFF % 4 == 0 && RPLANE >= RROWS * RPITCH && RPLANE % 2 == 0, "LDS layout");
+
+struct WinoStatCfg { static constexpr int MT = 128, NT = WNT; };   // what conv_stats_store needs to know about the tile
+
+// U = G g G^T for one (cout, cin): G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// tflip: the data-gradient weights, w'[co][ci][a][b] = w[ci][co][2 - a][2 - b] (w is then [Cin][Cout][3][3])
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int coutp, int nch,
+                                 int tflip) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= coutp * nch * WKC) return;
+  const int co = idx % coutp, ci = idx / coutp;
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float v = 0.f;
+      if (co < Cout && ci < Cin) v = tflip ? w[((size_t)ci * Cout + co) * 9 + (2 - a) * 3 + (2 - b)] : w[((size_t)co * Cin + ci) * 9 + a * 3 + b];
+      g[a][b] = v;
+    }
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+    t[3][b] = g[2][b];
+  }
+  const int chunk = ci / WKC, k = ci % WKC, mb = co / 32, lane = (co & 31) + 32 * (k & 1), s = k >> 1;
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi) {
+    const float u[4] = {t[xi][0], 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), t[xi][2]};
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+      dst[((((size_t)chunk * (coutp / 32) + mb) * 16 + 4 * xi + nu) * 64 + lane) * 4 + s] = u[nu];
+  }
+}
+
+__global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int tiles_x, int tiles_img, int nch, int mblocks, int mode) {
+  extern __shared__ float lds[];
+  float* const vbuf = lds;
+  float* const rbuf = lds + 2 * VBUF;
+  Coef* const cfl = reinterpret_cast<Coef*>(lds + LDS_ROWS_OFF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mb = wave & 3, hf = wave >> 2;
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
+  const int n = blockIdx.x / tiles_img, tile = blockIdx.x % tiles_img;
+  const int y0 = (tile / tiles_x) * WPH, x0 = (tile % tiles_x) * WPW;
+  const int m0 = blockIdx.y * 128;
+  const int Cin = p.Ca + p.Cb;
+  const size_t HW = (size_t)p.H * p.W;
+
+  // ---- raw staging geometry: wave w stages channel w of every chunk, lane elements lane, lane + 64, lane + 128 of 180
+  unsigned roff[RSUB], rkeep[RSUB];
+#pragma unroll
+  for (int i = 0; i < RSUB; ++i) {
+    const int e = lane + 64 * i;
+    const int r = e / RPITCH, c = e - r * RPITCH;
+    const int y = y0 - 1 + r, x = x0 - 1 + c;
+    const bool inb = e < RROWS * RPITCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    rkeep[i] = inb ? 0xffffffffu : 0u;
+    roff[i] = inb ? 4u * (unsigned)(y * p.W + x) : 0u;
+  }
+  float raw[RSUB];
+  auto raw_load = [&](int ch) {
+    const int ci = ch * WKC + wave;
+    const bool in_a = ci < p.Ca;
+    const float* src = in_a ? p.xa : p.xb;
+    const int cc = in_a ? ci : ci - p.Ca, CC = in_a ? p.Ca : p.Cb;
+    const bool ok = ci < Cin && src != nullptr;
+    const float* plane = ok ? src + ((size_t)n * CC + cc) * HW : (p.xa ? p.xa : p.xb);
+#pragma unroll
+    for (int i = 0; i < RSUB; ++i) raw[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
+  };
+  auto raw_commit = [&](int ch, float* rb) {
+    const int ci = ch * WKC + wave;
+    const bool ok = ci < Cin && (ci < p.Ca ? p.xa : p.xb) != nullptr;
+    const Coef cf = cfl[ci < Cin ? ci : Cin - 1];
+    const unsigned ck = ok ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < RSUB; ++i) {
+      float v = apply_coef(raw[i], cf, p.act);
+      v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeep[i] & ck));
+      if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[wave * RPLANE + lane + 64 * i] = v;
+    }
+  };
+  // ---- input transform: thread = (channel k, patch (ty, tx), row half hf): V[xi][nu] for xi in {2 hf, 2 hf + 1}
+  const int tk = lane & 7, ttx = lane >> 3, tty = mb;
+  const int tr_src = tk * RPLANE + (2 * tty + hf) * RPITCH + 2 * ttx;
+  const int tr_dst = (8 * hf) * VPOS + (tty * WTX + ttx) * 8 + (tk & 1) * 4 + (tk >> 1);
+  auto transform = [&](const float* rb, float* vb) {
+    float d[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float2 lo = *reinterpret_cast<const float2*>(rb + tr_src + a * RPITCH);
+      const float2 hi = *reinterpret_cast<const float2*>(rb + tr_src + a * RPITCH + 2);
+      d[a][0] = lo.x; d[a][1] = lo.y; d[a][2] = hi.x; d[a][3] = hi.y;
+    }
+    // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; rows held: hf = 0: d0 d1 d2, hf = 1: d1 d2 d3
+    float t[2][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (hf == 0) { t[0][b] = d[0][b] - d[2][b]; t[1][b] = d[1][b] + d[2][b]; }
+      else         { t[0][b] = d[1][b] - d[0][b]; t[1][b] = d[0][b] - d[2][b]; }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      float* o = vb + tr_dst + 4 * x * VPOS;
+      o[0 * VPOS] = t[x][0] - t[x][2];
+      o[1 * VPOS] = t[x][1] + t[x][2];
+      o[2 * VPOS] = t[x][2] - t[x][1];
+      o[3 * VPOS] = t[x][1] - t[x][3];
+    }
+  };
+
+  // ---- prologue
+  stage_coef_rows<WNT>(p, n, cfl, tid);
+  raw_load(0);
+  __syncthreads();
+  raw_commit(0, rbuf);
+  if (nch > 1) raw_load(1);
+  // this wave's transformed weights: 8 positions x one 16-byte load per chunk
+  const size_t ustride = (size_t)mblocks * 16 * 64;                  // f32x4 per chunk
+  const f32x4* up = reinterpret_cast<const f32x4*>(p.wino) + ((size_t)(m0 / 32 + mb) * 16 + 8 * hf) * 64 + lane;
+  f32x4 ua[8];                                                       // reloaded position by position right after its last use
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ua[q] = up[q * 64];
+  __syncthreads();
+  transform(rbuf, vbuf);
+  if (nch > 1) raw_commit(1, rbuf + RBUF);
+  f32x16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  __syncthreads();
+
+  // ---- K loop
+  const int vrd = (8 * hf) * VPOS + (lane & 31) * 8 + (lane >> 5) * 4;
+  const bool late = (hf == 1) && (mode & 1);
+  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
+#ifdef MCEDM_WINO_TIMELINE      // per-phase cycle sums of waves 0 and 4 (lane 0) -> dbg[8..12] / dbg[13..15, 7] (diagnostic builds only)
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define WINO_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; }
+#else
+#define WINO_STAMP(i)
+#endif
+#ifdef MCEDM_WINO_TIMELINE      // diagnostic builds: mode bits 1..3 drop the weight reloads / the transform / the raw tile path (wrong results)
+  const bool no_u = mode & 2, no_t = mode & 4, no_r = mode & 8;
+#else
+  constexpr bool no_u = false, no_t = false, no_r = false;
+#endif
+  for (int c = 0; c < nch; ++c) {
+    const int cur = c & 1;
+    if (c + 2 < nch && !no_r) raw_load(c + 2);
+    const f32x4* un = up + (size_t)(c + 1 < nch ? c + 1 : c) * ustride;
+    // the two waves of a SIMD (same mb, hf = 0 / 1) take the transform and the MFMA block in opposite order: one's vector /
+    // LDS work runs beside the other's MFMAs.  Every phase of a trip touches buffers of its own, so any order is legal; the
+    // commit of the raw tile comes last in both (its global loads were issued at the top of the trip).
+    WINO_STAMP(0)
+    if (!late && c + 1 < nch && !no_t) transform(rbuf + (cur ^ 1) * RBUF, vbuf + (cur ^ 1) * VBUF);
+    WINO_STAMP(1)
+    const float* vb = vbuf + cur * VBUF + vrd;
+    f32x4 b4[2][2];                                        // B fragments of two positions, one pair ahead of the MFMAs
+    b4[0][0] = *reinterpret_cast<const f32x4*>(vb);
+    b4[0][1] = *reinterpret_cast<const f32x4*>(vb + VPOS);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int qp = 0; qp < 4; ++qp) {
+      const int cb = qp & 1;
+      if (qp < 3) {
+        b4[cb ^ 1][0] = *reinterpret_cast<const f32x4*>(vb + (2 * qp + 2) * VPOS);
+        b4[cb ^ 1][1] = *reinterpret_cast<const f32x4*>(vb + (2 * qp + 3) * VPOS);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[2 * qp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * qp][s], b4[cb][0][s], acc[2 * qp], 0, 0, 0);
+        acc[2 * qp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * qp + 1][s], b4[cb][1][s], acc[2 * qp + 1], 0, 0, 0);
+      }
+      // the next chunk's weights of these two positions: 2 KB per wave every eight MFMAs.  (All of a chunk's weight loads
+      // issued together right behind the barrier -- 64 KB per CU at once -- back up the vector memory path and every wave
+      // stalls in their issue for 1000-3000 cycles per chunk.)
+      if (!no_u) {
+        ua[2 * qp] = un[(2 * qp) * 64];
+        ua[2 * qp + 1] = un[(2 * qp + 1) * 64];
+      }
+      // pin the order: the next pair's two LDS reads, this pair's eight MFMAs, this pair's two reloads
+      if (qp < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    }
+    WINO_STAMP(2)
+    if (late && c + 1 < nch && !no_t) transform(rbuf + (cur ^ 1) * RBUF, vbuf + (cur ^ 1) * VBUF);
+    if (c + 2 < nch && !no_r) raw_commit(c + 2, rbuf + cur * RBUF);
+    WINO_STAMP(3)
+    __syncthreads();
+    WINO_STAMP(4)
+  }
+
+  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
+#ifdef MCEDM_WINO_TIMELINE
+  if (p.dbg && tid == 0) for (int i = 0; i < 5; ++i) p.dbg[blockIdx.x * 16 + 8 + i] = ph[i];
+  if (p.dbg && tid == 256) { p.dbg[blockIdx.x * 16 + 13] = ph[1]; p.dbg[blockIdx.x * 16 + 14] = ph[2]; p.dbg[blockIdx.x * 16 + 15] = ph[3]; p.dbg[blockIdx.x * 16 + 7] = ph[4]; }
+#endif
+  // ---- output transform.  A^T = [[1,1,1,0],[0,1,-1,-1]].  Over nu (register-local), then over xi across the two halves:
+  // row 0 of the patch = T0 + T1 + T2, row 1 = T1 - T2 - T3 with T_xi the nu-reduced blocks; half 0 holds T0, T1, half 1 T2, T3.
+  const int pt = lane & 31;                             // this wave stores row hf of every patch: pixels
+  const int oy = y0 + 2 * (pt >> 3) + hf, ox = x0 + 2 * (pt & 7);   // (y0 + 2 ty + hf, x0 + 2 tx + {0, 1}), patch = lane & 31
+  const int cbase = m0 + 32 * mb + 4 * (lane >> 5);
+  const size_t obase = ((size_t)n * p.Cout + cbase) * HW + (size_t)oy * p.W + ox;
+  float2 rv[16];                                        // residual and bias: in flight during the transform and the exchange
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int dr = (r & 3) + 8 * (r >> 2);
+    rv[r] = p.res ? *reinterpret_cast<const float2*>(p.res + obase + (size_t)dr * HW) : make_float2(0.f, 0.f);
+    bv[r] = p.bias ? p.bias[cbase + dr] : 0.f;
+  }
+  f32x16 keep[2], send[2];
+  {
+    f32x16 t[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      t[x][0] = acc[4 * x + 0] + acc[4 * x + 1] + acc[4 * x + 2];
+      t[x][1] = acc[4 * x + 1] - acc[4 * x + 2] - acc[4 * x + 3];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (hf == 0) { keep[j] = t[0][j] + t[1][j]; send[j] = t[1][j]; }
+      else         { keep[j] = -t[0][j] - t[1][j]; send[j] = t[0][j]; }
+    }
+  }
+  float* xch = lds;                                     // every LDS reader of the K loop is past the last barrier
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xch[(wave * 32 + j * 16 + r) * 64 + lane] = send[j][r];
+  __syncthreads();
+  const int pw = wave ^ 4;
+  float v0[16], v1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    v0[r] = keep[0][r] + xch[(pw * 32 + r) * 64 + lane] + bv[r] + rv[r].x;
+    v1[r] = keep[1][r] + xch[(pw * 32 + 16 + r) * 64 + lane] + bv[r] + rv[r].y;
+    *reinterpret_cast<float2*>(p.out + obase + (size_t)((r & 3) + 8 * (r >> 2)) * HW) = make_float2(v0[r], v1[r]);
+  }
+  if (p.gsum) {
+    // fused GroupNorm statistics of what was stored (conv_tile.hpp conv_epilogue): one record per 4-channel block =
+    // registers 4 g .. 4 g + 3 of the 32 lanes that share lane >> 5; this wave holds one pixel row of every patch
+    // (256 values per block), its partner wave the other: (count, sum, M2 about the wave's own mean) per wave, merged in
+    // a fixed order by conv_stats_store.
+    float* red = lds + XCH_FLOATS;
+    float sm[4], m2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 4 * g; r < 4 * g + 4; ++r) a += v0[r] + v1[r];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) a += __shfl_xor(a, off);
+      sm[g] = a;
+      const float mean = a * (1.0f / 256.0f);
+      float b = 0.f;
+#pragma unroll
+      for (int r = 4 * g; r < 4 * g + 4; ++r) { const float d0 = v0[r] - mean, d1 = v1[r] - mean; b = fmaf(d0, d0, b); b = fmaf(d1, d1, b); }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) b += __shfl_xor(b, off);
+      m2[g] = b;
+    }
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float* slot = red + (hf * 32 + 8 * mb + 2 * g + (lane >> 5)) * 3;
+        slot[0] = 256.f; slot[1] = sm[g]; slot[2] = m2[g];
+      }
+    }
+    __syncthreads();
+    conv_stats_store<WinoStatCfg, 2>(p, red, n, m0, tile, tiles_img, tid);
+  }
+  if (p.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p.dbg[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+int wino_env() {                                        // MCEDM_WINOGRAD=0: never take this kernel
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_WINOGRAD"); env = e ? atoi(e) : 1; }
+  return env;
+}
+int wino_mode_env() {                                   // MCEDM_WINO_MODE bit 0: opposite phase order in the two waves of a SIMD
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_WINO_MODE"); env = e ? atoi(e) : 1; }
+  return env;
+}
+
+int wino_min_hw_env() {                                 // MCEDM_WINO_MIN_HW: smallest image (pixels) served; below 32 x 32 the grid
+  static int env = -1;                                  // (B * H * W / 128 workgroups) no longer fills the chip
+  if (env < 0) { const char* e = getenv("MCEDM_WINO_MIN_HW"); env = e ? atoi(e) : 1024; }
+  return env;
+}
+
+}  // namespace
+
+size_t conv_wino_packed_floats(int Cout, int Cin) { return (size_t)16 * cout_padded(Cout) * (size_t)ceil_div(Cin, WKC) * WKC; }
+
+int launch_pack_conv_wino(const float* w, float* dst, int Cout, int Cin, int transpose_flip, hipStream_t stream) {
+  MCEDM_REQUIRE(w && dst && Cout > 0 && Cin > 0, "pack_conv_wino: bad arguments");
+  const int coutp = cout_padded(Cout), nch = ceil_div(Cin, WKC);
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(ceil_div(coutp * nch * WKC, 256)), dim3(256), 0, stream, w, dst, Cout, Cin, coutp, nch,
+                     transpose_flip);
+  MCEDM_LAUNCH_CHECK("wino_pack_kernel");
+  return MCEDM_OK;
+}
+
+bool conv_wino_applicable(const ConvArgs& a, int taps) {
+  return taps == 9 && a.wino && a.resample == RS_NONE && a.Cout % 128 == 0 && a.H % WPH == 0 && a.W % WPW == 0 &&
+         (a.Ca + a.Cb) % WKC == 0 && a.Ca % WKC == 0 && !a.sk_wpk && !(a.gsum && a.gsum_rc == 2) &&
+         (!a.res || a.res_mode == RS_NONE) && (a.Ca + a.Cb) <= 1024;
+}
+
+int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
+  ConvArgs a = a_in;
+  a.dbg = conv_debug_buffer();
+  MCEDM_REQUIRE(conv_wino_applicable(a, 9), "conv_wino: shape not served by the Winograd kernel");
+  MCEDM_REQUIRE(a.out && a.B > 0 && a.Hs == a.H && a.Ws == a.W, "conv_wino: bad arguments");
+  MCEDM_REQUIRE((unsigned long long)a.H * a.W * 4ull < (1ull << 32), "conv_wino: plane exceeds the 4 GiB offset range");
+  { const int rc = conv_resolve_identity(a); if (rc != MCEDM_OK) return rc; }
+  const int tiles_x = a.W / WPW, tiles_img = tiles_x * (a.H / WPH);
+  const long long blocks = (long long)a.B * tiles_img;
+  MCEDM_REQUIRE(blocks > 0 && blocks <= 0x7fffffffLL, "conv_wino: grid out of range");
+  const int Cin = a.Ca + a.Cb, nch = Cin / WKC;
+  const int lds_rows = (LDS_ROWS_OFF * 4 + Cin * (int)sizeof(Coef));
+  const int lds_xch = (XCH_FLOATS + 2 * 32 * 3) * 4;             // exchange area + the statistics records of the two halves
+  const int lds_bytes = lds_rows > lds_xch ? lds_rows : lds_xch;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  MCEDM_HIP_TRY(hipGetDevice(&dev));
+  MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  if (!attr_set[dev].load(std::memory_order_acquire)) {
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set[dev].store(true, std::memory_order_release);
+  }
+  const double px = (double)a.B * a.H * a.W;
+  // algorithmic cost = the direct convolution's (2 * MAC); the kernel issues 4 / 9 of these as matrix flops
+  ProfScope ps("conv_wino_kernel", 2.0 * px * a.Cout * (double)Cin * 9,
+               4.0 * ((double)a.B * Cin * a.H * a.W + px * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * Cin * 9), stream);
+  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks, a.Cout / 128), dim3(WNT), lds_bytes, stream, a, tiles_x, tiles_img, nch,
+                     cout_padded(a.Cout) / 32, wino_mode_env());
+  MCEDM_LAUNCH_CHECK("conv_wino_kernel");
+  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_img, tiles_x, WPH, WPW, 4};
+  return MCEDM_OK;
+}
+
+// the dispatcher's choice: enabled, and an image large enough for the grid to fill the chip
+bool conv_wino_preferred(const ConvArgs& a) { return wino_env() != 0 && (long long)a.H * a.W >= wino_min_hw_env(); }
+
+}  // namespace mcedm

@@ -50,6 +50,25 @@ extern "C" int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, c
   return launch_conv(a, k * k, (hipStream_t)stream);
 }
 
+extern "C" size_t mcedm_op_conv_wino_packed_floats(int Cout, int Cin) { return conv_wino_packed_floats(Cout, Cin); }
+
+extern "C" int mcedm_op_pack_conv_wino(const float* w, int Cout, int Cin, float* wino, void* stream) {
+  return launch_pack_conv_wino(w, wino, Cout, Cin, 0, (hipStream_t)stream);
+}
+
+extern "C" int mcedm_op_conv_wino(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch,
+                                  int act, int H, int W, const float* wino, const float* bias, const float* res, float* out,
+                                  int Cout, int B, void* stream) {
+  ConvArgs a{};
+  a.xa = xa; a.xb = xb; a.Ca = Ca; a.Cb = Cb;
+  a.coef = reinterpret_cast<const Coef*>(coef); a.coef_batch = coef_batch; a.act = act;
+  a.resample = RS_NONE; a.Hs = H; a.Ws = W; a.H = H; a.W = W;
+  a.wino = wino; a.bias = bias; a.res = res; a.res_mode = RS_NONE;
+  a.out = out; a.Cout = Cout; a.B = B;
+  MCEDM_REQUIRE(conv_wino_applicable(a, 9), "op_conv_wino: needs Cout %% 128 == 0, H %% 8 == 0, W %% 16 == 0, Cin %% 8 == 0");
+  return launch_conv_wino(a, (hipStream_t)stream);
+}
+
 // freqs[k] = (1/10000)^(k/half) exactly as the plan packs them (adm_blocks.py:193-196, endpoint=False)
 __global__ void op_freqs_kernel(float* f, int half) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;

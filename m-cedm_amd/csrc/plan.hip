@@ -91,6 +91,10 @@ static void place_conv(Taker& t, ConvP& c, bool dgrad) {
   c.wpk = t.take(conv_packed_floats(c.cout, c.cin, c.taps));
   c.bias = t.take((size_t)(c.cout + 31) / 32 * 32);
   if (dgrad) c.wpk_dgrad = t.take(conv_packed_floats(c.cin, c.cout, c.taps));
+  if (c.taps == 9 && c.qkv_heads == 0) {       // Winograd tables where the kernel's channel constraints can be met
+    if (c.cout % 128 == 0 && c.cin % 8 == 0) c.wino = t.take(conv_wino_packed_floats(c.cout, c.cin));
+    if (dgrad && c.cin % 128 == 0 && c.cout % 8 == 0) c.wino_dgrad = t.take(conv_wino_packed_floats(c.cin, c.cout));
+  }
 }
 static void place_norm(Taker& t, NormP& n) { n.gamma = t.take(n.C); n.beta = t.take(n.C); }
 
@@ -278,6 +282,8 @@ static int pack_conv(const ConvP& c, const float* const* params, float* pk, Copi
     // (head, which, c) order of the incoming gradient rows
     rc = launch_pack_conv(params[c.w], pk + c.wpk_dgrad, c.cin, c.cout, c.taps, c.qkv_heads, 1, s);
   }
+  if (!rc && c.wino != NONE) rc = launch_pack_conv_wino(params[c.w], pk + c.wino, c.cout, c.cin, 0, s);
+  if (!rc && c.wino_dgrad != NONE) rc = launch_pack_conv_wino(params[c.w], pk + c.wino_dgrad, c.cin, c.cout, 1, s);
   return rc;
 }
 
@@ -511,6 +517,7 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   c0.resample = rs;
   c0.Hs = bl.Hin; c0.Ws = bl.Win; c0.H = bl.H; c0.W = bl.W;
   c0.wpk = pk + b.conv0.wpk; c0.bias = pk + b.conv0.bias;
+  c0.wino = b.conv0.wino != NONE ? pk + b.conv0.wino : nullptr;
   c0.out = T(bl.h); c0.Cout = b.cout; c0.B = B; c0.gsum = SUMS(bl.h); c0.gsum_tiles = &st[bl.h];
   if ((rc = gn_for_conv(g0, c0, /*need_table=*/bl.xd >= 0, s))) return rc;
   if (bl.xd >= 0) {
@@ -547,6 +554,7 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   c1.coef = CF(bl.coef1); c1.coef_batch = 1; c1.act = 1;
   c1.Hs = bl.H; c1.Ws = bl.W; c1.H = bl.H; c1.W = bl.W;
   c1.wpk = pk + b.conv1.wpk; c1.bias = pk + b.conv1.bias;
+  c1.wino = b.conv1.wino != NONE ? pk + b.conv1.wino : nullptr;
   c1.res = res; c1.res_mode = res_mode;
   if (fold_skip) {            // y = conv1(...) + skip(orig): the projection rides on conv1 as extra K chunks
     c1.res = nullptr; c1.res_mode = RS_NONE;

@@ -55,6 +55,7 @@ struct ConvP {   // one Conv2d with weights
   int qkv_heads = 0;           // > 0: output rows re-ordered to (head, {q,k,v}, c)
   size_t wpk = NONE, bias = NONE;      // float offsets into the packed buffer
   size_t wpk_dgrad = NONE;             // transposed + mirrored weights for the data gradient
+  size_t wino = NONE, wino_dgrad = NONE;   // both again in Winograd F(2x2, 3x3) form (conv_wino.hip) where that kernel can serve
 };
 
 struct NormP {

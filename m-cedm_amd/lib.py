@@ -758,8 +758,12 @@ def _bind_ops():
     lib.mcedm_op_gn_bwd.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp,
                                     i32, vp, i32, vp, vp, vp, vp, i32, vp]
     lib.mcedm_op_attention_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.mcedm_op_conv_wino_packed_floats.argtypes = [i32, i32]
+    lib.mcedm_op_conv_wino_packed_floats.restype = sz
+    lib.mcedm_op_pack_conv_wino.argtypes = [vp, i32, i32, vp, vp]
+    lib.mcedm_op_conv_wino.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]
     for n in ("mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv", "mcedm_op_attention", "mcedm_op_embedding", "mcedm_op_conv_wgrad",
-              "mcedm_op_gn_bwd", "mcedm_op_attention_bwd"):
+              "mcedm_op_gn_bwd", "mcedm_op_attention_bwd", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino"):
         getattr(lib, n).restype = C.c_int
     _OPS_BOUND = True
     return lib
@@ -768,7 +772,8 @@ def _bind_ops():
 OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv",
               "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report",
               "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd",
-              "mcedm_op_set_conv_debug", "mcedm_op_set_conv8", "mcedm_op_set_conv_resident", "mcedm_op_set_attn_fused", "mcedm_op_embedding"]
+              "mcedm_op_set_conv_debug", "mcedm_op_set_conv8", "mcedm_op_set_conv_resident", "mcedm_op_set_attn_fused", "mcedm_op_embedding",
+              "mcedm_op_conv_wino_packed_floats", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino"]
 
 
 def prof_enable(on: bool) -> None:
@@ -851,6 +856,26 @@ def op_conv(xa, xb, wpk, bias_pk, Cout, k, coef=None, coef_batch=1, act=0, resam
         out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xa.device)
     check(lib.mcedm_op_conv(_ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, resample, Hs, Ws, H, W, _ptr(wpk),
                             _ptr(bias_pk), _ptr(res), res_mode, _ptr(out), Cout, B, k, _stream()), "op_conv")
+    return out
+
+
+def op_pack_conv_wino(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> the Winograd F(2x2, 3x3) weight table of mcedm_op_conv_wino."""
+    lib = _bind_ops()
+    Cout, Cin = w.shape[:2]
+    wino = torch.empty(lib.mcedm_op_conv_wino_packed_floats(Cout, Cin), dtype=torch.float32, device=w.device)
+    check(lib.mcedm_op_pack_conv_wino(_ptr(w), Cout, Cin, _ptr(wino), _stream()), "op_pack_conv_wino")
+    return wino
+
+
+def op_conv_wino(xa, xb, wino, bias, Cout, coef=None, coef_batch=1, act=0, res=None, out=None):
+    lib = _bind_ops()
+    B, Ca, H, W = xa.shape
+    Cb = xb.shape[1] if xb is not None else 0
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xa.device)
+    check(lib.mcedm_op_conv_wino(_ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, H, W, _ptr(wino), _ptr(bias),
+                                 _ptr(res), _ptr(out), Cout, B, _stream()), "op_conv_wino")
     return out
 
 

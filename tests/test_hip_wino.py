@@ -1,0 +1,95 @@
+"""Winograd F(2x2, 3x3) form of the 3x3 convolution (csrc/conv_wino.hip) against the oracle's direct convolution and the
+device's direct kernel: same inputs, fused input transform, bias, residual, channel concat.  rtol 1e-4 / atol 1e-5 (the
+north_star bar); the two device kernels sum in different orders, so they agree to rounding, not bit for bit."""
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import mcedm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import importlib
+    L = importlib.import_module("m-cedm_amd.lib")
+    L.load()
+    return L
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def close(got, ref, what, rtol=1e-4, atol=1e-5):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {err.max():.3e} (max ref {ref.abs().max():.3e})"
+
+
+def coef_table(tag, B, C):
+    return torch.stack([fx.randn(tag + "/m", B, C) * 0.1, 1 + 0.1 * fx.randn(tag + "/s", B, C), 0.1 * fx.randn(tag + "/o", B, C),
+                        torch.zeros(B, C)], -1)
+
+
+@pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,act,use_coef,use_res", [
+    (2, 128, 0, 128, 16, 16, 1, True, True),      # one workgroup row of tiles, every border
+    (1, 128, 0, 128, 32, 48, 1, True, False),     # interior tiles, non-square
+    (2, 64, 64, 128, 16, 32, 1, True, True),      # channel concat
+    (1, 8, 0, 128, 8, 16, 0, False, False),       # a single chunk, a single tile, no transform
+    (1, 128, 128, 256, 16, 16, 1, True, True),    # two 128-channel output blocks, 32 chunks
+    (3, 24, 0, 128, 24, 16, 0, True, False),      # odd chunk count
+])
+def test_conv_wino_vs_oracle_and_direct(lib, B, Ca, Cb, Cout, H, W, act, use_coef, use_res):
+    tag = f"wino/{B}{Ca}{Cb}{Cout}{H}{W}"
+    Cin = Ca + Cb
+    xa = fx.randn(tag + "/xa", B, Ca, H, W)
+    xb = fx.randn(tag + "/xb", B, Cb, H, W) if Cb else None
+    w = fx.randn(tag + "/w", Cout, Cin, 3, 3) / (Cin * 9) ** 0.5
+    b = fx.randn(tag + "/b", Cout) * 0.1
+    res = fx.randn(tag + "/res", B, Cout, H, W) if use_res else None
+    coef = coef_table(tag, B, Cin) if use_coef else None
+    x = torch.cat([xa, xb], 1) if Cb else xa
+    if coef is not None:
+        x = (x - coef[..., 0, None, None]) * coef[..., 1, None, None] + coef[..., 2, None, None]
+    if act:
+        x = torch.nn.functional.silu(x)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res is not None:
+        ref = ref + res.double()
+    wino = lib.op_pack_conv_wino(dev(w))
+    got = lib.op_conv_wino(dev(xa), dev(xb) if Cb else None, wino, dev(b), Cout, coef=dev(coef) if use_coef else None, act=act,
+                           res=dev(res) if use_res else None)
+    close(got, ref, "winograd vs fp64 direct convolution")
+    wpk, bpk = lib.op_pack_conv(dev(w), dev(b))
+    direct = lib.op_conv(dev(xa), dev(xb) if Cb else None, wpk, bpk, Cout, 3, coef=dev(coef) if use_coef else None, act=act,
+                         res=dev(res) if use_res else None)
+    close(got, direct, "winograd vs direct kernel")
+    # zero padding and tile seams: unit centre weights must reproduce the input (to rounding: G has halves in it)
+    if not use_coef and not act:
+        wi = torch.zeros(Cout, Cin, 3, 3)
+        for c in range(min(Cout, Cin)):
+            wi[c, c, 1, 1] = 1.0
+        y = lib.op_conv_wino(dev(xa), None, lib.op_pack_conv_wino(dev(wi)), None, Cout)
+        close(y[:, :Cin], xa, "identity kernel through the Winograd transforms", rtol=1e-6, atol=2e-6)
+        assert float(y[:, Cin:].abs().max()) == 0.0
+
+
+def test_conv_wino_is_batch_invariant(lib):
+    """A sample's output bits do not depend on the batch it is computed in (sharding invariance, tests/test_hip_fullsize.py)."""
+    xa = fx.randn("wino/inv/x", 4, 128, 16, 32)
+    w = fx.randn("wino/inv/w", 128, 128, 3, 3) / 34.0
+    wino = lib.op_pack_conv_wino(dev(w))
+    coef = coef_table("wino/inv", 4, 128)
+    full = lib.op_conv_wino(dev(xa), None, wino, None, 128, coef=dev(coef), act=1)
+    part = lib.op_conv_wino(dev(xa[2:3]), None, wino, None, 128, coef=dev(coef[2:3]), act=1)
+    assert torch.equal(full[2:3], part)
+
+
+def test_conv_wino_rejects_unserved_shapes(lib):
+    w = lib.op_pack_conv_wino(dev(fx.randn("wino/rej/w", 128, 8, 3, 3)))
+    with pytest.raises(RuntimeError):
+        lib.op_conv_wino(dev(torch.zeros(1, 8, 12, 16)), None, w, None, 128)

@@ -1,0 +1,47 @@
+"""In-kernel timeline of the Winograd conv: per-workgroup stamps (start, prologue end, K loop end, end).
+    MCEDM_WINO_MODE=1 python tools/wino_timeline.py [B cin hw]"""
+import ctypes as C, importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+lib = importlib.import_module("m-cedm_amd.lib")
+B, cin, hw = (int(v) for v in (sys.argv[1:4] + ["32", "128", "128"][len(sys.argv) - 1:]))
+cout = 128
+x = torch.randn(B, cin, hw, hw, device="cuda")
+w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+b = torch.randn(cout, device="cuda")
+res = torch.randn(B, cout, hw, hw, device="cuda")
+coef = torch.stack([torch.zeros(B, cin), torch.ones(B, cin), torch.zeros(B, cin), torch.zeros(B, cin)], -1).cuda()
+wino = lib.op_pack_conv_wino(w)
+out = torch.empty(B, cout, hw, hw, device="cuda")
+run = lambda: lib.op_conv_wino(x, None, wino, b, cout, coef=coef, act=1, res=res, out=out)
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    run()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 10 * 1e3
+nb = B * (hw // 8) * (hw // 16)
+dbg = torch.zeros(nb * 16, dtype=torch.int64, device="cuda")
+l = lib._bind_ops()
+l.mcedm_op_set_conv_debug.argtypes = [C.c_void_p]
+l.mcedm_op_set_conv_debug(dbg.data_ptr())
+run()
+torch.cuda.synchronize()
+l.mcedm_op_set_conv_debug(None)
+d = dbg.cpu().numpy().reshape(nb, 16)
+t0 = d[:, 0].min()
+st, pro, loop, end = [(d[:, i] - t0) / 100.0 for i in range(4)]
+flops = 2.0 * B * hw * hw * cout * cin * 9
+cyc = np.median(d[:, 6] - d[:, 5])
+clk = np.median((d[:, 6] - d[:, 5]) / ((d[:, 2] - d[:, 1]) * 10e-9) / 1e9)
+nch = cin // 8
+print(f"mode {os.environ.get('MCEDM_WINO_MODE', 'default')} B={B} {cin}->{cout} {hw}x{hw}: {us:.1f} us/launch ({flops / us / 1e6:.1f} algorithmic TFLOP/s), {nb} workgroups, "
+      f"span {end.max():.1f} us | prologue {np.mean(pro - st):.2f} | K loop {np.mean(loop - pro):.2f} | epilogue {np.mean(end - loop):.2f} us per workgroup")
+print(f"   K loop {cyc:.0f} cycles = {cyc / nch:.0f} per chunk (matrix floor 4096 per chunk and SIMD), clock {clk:.2f} GHz")
+if d[:, 8:13].max() > 0:
+    print("   wave 0 cycles per chunk: " + "  ".join(f"{nm} {np.mean(d[:, 8 + j]) / nch:.0f}" for j, nm in enumerate(["load-issue", "transform(early)", "mfma-issue", "transform(late)+commit", "barrier"])))
+    print("   wave 4 cycles per chunk: " + "  ".join(f"{nm} {np.mean(d[:, j]) / nch:.0f}" for nm, j in [("transform(early)", 13), ("mfma-issue", 14), ("transform(late)+commit", 15), ("barrier", 7)]))
