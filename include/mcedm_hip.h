@@ -226,15 +226,16 @@ int mcedm_op_gn_coef(const float* xa, const float* xb, int Ca, int Cb, int B, in
 int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch, int act,
                   int resample, int Hs, int Ws, int H, int W, const float* wpk, const float* bias_pk,
                   const float* res, int res_mode, float* out, int Cout, int B, int k, void* stream);
-/* The same convolution (3x3, pad 1, no resampling) in Winograd F(2x2, 3x3) form: 4/9 of the matrix instructions of
- * mcedm_op_conv.  Serves Cout % 128 == 0, H % 8 == 0, W % 16 == 0, (Ca + Cb) % 8 == 0; results agree with mcedm_op_conv to
- * fp32 rounding (a different summation), not bit for bit.  w [Cout][Cin][3][3] -> wino (mcedm_op_conv_wino_packed_floats
- * floats); bias [Cout] in natural order or NULL; res [B, Cout, H, W] or NULL. */
+/* The same convolution (3x3, pad 1) in Winograd F(2x2, 3x3) form: 4/9 of the matrix instructions of mcedm_op_conv.
+ * Serves Cout % 128 == 0, H % 8 == 0, W % 16 == 0, Ca % 8 == 0, Cb % 8 == 0, resample / res_mode 0 (none) or 1 (nearest-2x
+ * up: the source / residual is [.., H/2, W/2]); results agree with mcedm_op_conv to fp32 rounding (a different
+ * summation), not bit for bit.  w [Cout][Cin][3][3] -> wino (mcedm_op_conv_wino_packed_floats floats); bias [Cout] in
+ * natural order or NULL; (H, W) is the conv (= output) size. */
 size_t mcedm_op_conv_wino_packed_floats(int Cout, int Cin);
 int mcedm_op_pack_conv_wino(const float* w, int Cout, int Cin, float* wino, void* stream);
 int mcedm_op_conv_wino(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch, int act,
-                       int H, int W, const float* wino, const float* bias, const float* res, float* out, int Cout, int B,
-                       void* stream);
+                       int resample, int H, int W, const float* wino, const float* bias, const float* res, int res_mode,
+                       float* out, int Cout, int B, void* stream);
 /* sigma-embedding MLP + every block's FiLM rows in one launch (models/adm_blocks.py:192-199 PositionalEmbedding,
  * :367-379 mapping MLP with SiLU, :143,163-165 per-block affine):  emb = silu(W1 silu(W0 pe(labels) + b0) + b1),
  * film[n] = Waff emb[n] + baff.  labels [n]; w0, w1 [ch][ch] (out, in); waff [rows][ch] = the blocks' affine weights

@@ -107,8 +107,10 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
     const int y = y0 - 1 + r, x = x0 - 1 + c;
     const bool inb = e < RROWS * RPITCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
     rkeep[i] = inb ? 0xffffffffu : 0u;
-    roff[i] = inb ? 4u * (unsigned)(y * p.W + x) : 0u;
+    // RS_UP: the conv input is the nearest-neighbour 2x up-sampling of the (activated) source (adm_blocks.py:69-73)
+    roff[i] = !inb ? 0u : p.resample == RS_UP ? 4u * (unsigned)((y >> 1) * p.Ws + (x >> 1)) : 4u * (unsigned)(y * p.W + x);
   }
+  const size_t HWs = (size_t)p.Hs * p.Ws;
   float raw[RSUB];
   auto raw_load = [&](int ch) {
     const int ci = ch * WKC + wave;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
     const float* src = in_a ? p.xa : p.xb;
     const int cc = in_a ? ci : ci - p.Ca, CC = in_a ? p.Ca : p.Cb;
     const bool ok = ci < Cin && src != nullptr;
-    const float* plane = ok ? src + ((size_t)n * CC + cc) * HW : (p.xa ? p.xa : p.xb);
+    const float* plane = ok ? src + ((size_t)n * CC + cc) * HWs : (p.xa ? p.xa : p.xb);
 #pragma unroll
     for (int i = 0; i < RSUB; ++i) raw[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
   };
@@ -261,7 +263,12 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int dr = (r & 3) + 8 * (r >> 2);
-    rv[r] = p.res ? *reinterpret_cast<const float2*>(p.res + obase + (size_t)dr * HW) : make_float2(0.f, 0.f);
+    if (p.res && p.res_mode == RS_UP) {                  // residual at half resolution: both pixels of the pair share a source
+      const float q = p.res[((size_t)n * p.Cout + cbase + dr) * (HW >> 2) + (size_t)(oy >> 1) * (p.W >> 1) + (ox >> 1)];
+      rv[r] = make_float2(q, q);
+    } else {
+      rv[r] = p.res ? *reinterpret_cast<const float2*>(p.res + obase + (size_t)dr * HW) : make_float2(0.f, 0.f);
+    }
     bv[r] = p.bias ? p.bias[cbase + dr] : 0.f;
   }
   f32x16 keep[2], send[2];
@@ -362,16 +369,17 @@ int launch_pack_conv_wino(const float* w, float* dst, int Cout, int Cin, int tra
 }
 
 bool conv_wino_applicable(const ConvArgs& a, int taps) {
-  return taps == 9 && a.wino && a.resample == RS_NONE && a.Cout % 128 == 0 && a.H % WPH == 0 && a.W % WPW == 0 &&
-         (a.Ca + a.Cb) % WKC == 0 && a.Ca % WKC == 0 && !a.sk_wpk && !(a.gsum && a.gsum_rc == 2) &&
-         (!a.res || a.res_mode == RS_NONE) && (a.Ca + a.Cb) <= 1024;
+  return taps == 9 && a.wino && (a.resample == RS_NONE || a.resample == RS_UP) && a.Cout % 128 == 0 && a.H % WPH == 0 &&
+         a.W % WPW == 0 && (a.Ca + a.Cb) % WKC == 0 && a.Ca % WKC == 0 && !a.sk_wpk && !(a.gsum && a.gsum_rc == 2) &&
+         (!a.res || a.res_mode == RS_NONE || a.res_mode == RS_UP) && (a.Ca + a.Cb) <= 1024;
 }
 
 int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
   ConvArgs a = a_in;
   a.dbg = conv_debug_buffer();
   MCEDM_REQUIRE(conv_wino_applicable(a, 9), "conv_wino: shape not served by the Winograd kernel");
-  MCEDM_REQUIRE(a.out && a.B > 0 && a.Hs == a.H && a.Ws == a.W, "conv_wino: bad arguments");
+  MCEDM_REQUIRE(a.out && a.B > 0 && (a.resample == RS_UP ? (a.Hs * 2 == a.H && a.Ws * 2 == a.W) : (a.Hs == a.H && a.Ws == a.W)),
+                "conv_wino: bad arguments");
   MCEDM_REQUIRE((unsigned long long)a.H * a.W * 4ull < (1ull << 32), "conv_wino: plane exceeds the 4 GiB offset range");
   { const int rc = conv_resolve_identity(a); if (rc != MCEDM_OK) return rc; }
   const int tiles_x = a.W / WPW, tiles_img = tiles_x * (a.H / WPH);
@@ -392,7 +400,7 @@ int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
   const double px = (double)a.B * a.H * a.W;
   // algorithmic cost = the direct convolution's (2 * MAC); the kernel issues 4 / 9 of these as matrix flops
   ProfScope ps("conv_wino_kernel", 2.0 * px * a.Cout * (double)Cin * 9,
-               4.0 * ((double)a.B * Cin * a.H * a.W + px * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * Cin * 9), stream);
+               4.0 * ((double)a.B * Cin * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * Cin * 9), stream);
   hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks, a.Cout / 128), dim3(WNT), lds_bytes, stream, a, tiles_x, tiles_img, nch,
                      cout_padded(a.Cout) / 32, wino_mode_env());
   MCEDM_LAUNCH_CHECK("conv_wino_kernel");
@@ -400,6 +408,10 @@ int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
   return MCEDM_OK;
 }
 
+// plan-time question (build_layout): will an un-resampled Cin -> Cout conv on H x W images be served here?
+bool conv_wino_shape_ok(int Cout, int Cin, int H, int W) {
+  return wino_env() != 0 && Cout % 128 == 0 && Cin % WKC == 0 && H % WPH == 0 && W % WPW == 0 && (long long)H * W >= wino_min_hw_env();
+}
 // the dispatcher's choice: enabled, and an image large enough for the grid to fill the chip
 bool conv_wino_preferred(const ConvArgs& a) { return wino_env() != 0 && (long long)a.H * a.W >= wino_min_hw_env(); }
 

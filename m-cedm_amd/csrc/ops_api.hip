@@ -57,13 +57,16 @@ extern "C" int mcedm_op_pack_conv_wino(const float* w, int Cout, int Cin, float*
 }
 
 extern "C" int mcedm_op_conv_wino(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch,
-                                  int act, int H, int W, const float* wino, const float* bias, const float* res, float* out,
-                                  int Cout, int B, void* stream) {
+                                  int act, int resample, int H, int W, const float* wino, const float* bias, const float* res,
+                                  int res_mode, float* out, int Cout, int B, void* stream) {
+  MCEDM_REQUIRE((resample == RS_NONE || resample == RS_UP) && (res_mode == RS_NONE || res_mode == RS_UP),
+                "op_conv_wino: resample / res_mode must be 0 (none) or 1 (nearest-2x up)");
   ConvArgs a{};
   a.xa = xa; a.xb = xb; a.Ca = Ca; a.Cb = Cb;
   a.coef = reinterpret_cast<const Coef*>(coef); a.coef_batch = coef_batch; a.act = act;
-  a.resample = RS_NONE; a.Hs = H; a.Ws = W; a.H = H; a.W = W;
-  a.wino = wino; a.bias = bias; a.res = res; a.res_mode = RS_NONE;
+  a.resample = resample; a.H = H; a.W = W;
+  a.Hs = resample == RS_UP ? H / 2 : H; a.Ws = resample == RS_UP ? W / 2 : W;
+  a.wino = wino; a.bias = bias; a.res = res; a.res_mode = res_mode;
   a.out = out; a.Cout = Cout; a.B = B;
   MCEDM_REQUIRE(conv_wino_applicable(a, 9), "op_conv_wino: needs Cout %% 128 == 0, H %% 8 == 0, W %% 16 == 0, Cin %% 8 == 0");
   return launch_conv_wino(a, (hipStream_t)stream);

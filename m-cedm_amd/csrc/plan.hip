@@ -414,8 +414,12 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
     // the 1x1 skip projection is folded into conv1 (ConvArgs::sk_*) in inference AND in training: the backward never reads
     // the projected tensor (its weight gradient takes dy and the block input, its data gradient dy alone), so it only
     // exists for the resampling blocks, which the fold does not serve
+    // ... and for blocks whose conv1 the Winograd kernel serves (conv_wino.hip): a 1x1 projection has nothing to gain
+    // from that transform (it would cost 16 multiplies per output instead of 1), so it runs as its own launch there
+    // and enters conv1 as a residual
     (void)training;
-    if (b.skip_kernel == 1 && (b.up || b.down)) bl.sk = lb.act(b.cout, bl.H, bl.W);
+    const bool wino1 = b.conv1.wino != NONE && conv_wino_shape_ok(b.cout, b.cout, bl.H, bl.W);
+    if (b.skip_kernel == 1 && (b.up || b.down || wino1)) bl.sk = lb.act(b.cout, bl.H, bl.W);
     bl.y = lb.act(b.cout, bl.H, bl.W);
     give_sums(bl.y);
     lb.drop(bl.h); lb.drop(bl.coef1); lb.drop(bl.sk);

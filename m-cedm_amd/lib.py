@@ -761,7 +761,7 @@ def _bind_ops():
     lib.mcedm_op_conv_wino_packed_floats.argtypes = [i32, i32]
     lib.mcedm_op_conv_wino_packed_floats.restype = sz
     lib.mcedm_op_pack_conv_wino.argtypes = [vp, i32, i32, vp, vp]
-    lib.mcedm_op_conv_wino.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]
+    lib.mcedm_op_conv_wino.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp]
     for n in ("mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv", "mcedm_op_attention", "mcedm_op_embedding", "mcedm_op_conv_wgrad",
               "mcedm_op_gn_bwd", "mcedm_op_attention_bwd", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino"):
         getattr(lib, n).restype = C.c_int
@@ -868,14 +868,16 @@ def op_pack_conv_wino(w: torch.Tensor) -> torch.Tensor:
     return wino
 
 
-def op_conv_wino(xa, xb, wino, bias, Cout, coef=None, coef_batch=1, act=0, res=None, out=None):
+def op_conv_wino(xa, xb, wino, bias, Cout, coef=None, coef_batch=1, act=0, resample=RS_NONE, res=None, res_mode=RS_NONE,
+                 out=None):
     lib = _bind_ops()
-    B, Ca, H, W = xa.shape
+    B, Ca, Hs, Ws = xa.shape
     Cb = xb.shape[1] if xb is not None else 0
+    H, W = (Hs * 2, Ws * 2) if resample == RS_UP else (Hs, Ws)
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=xa.device)
-    check(lib.mcedm_op_conv_wino(_ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, H, W, _ptr(wino), _ptr(bias),
-                                 _ptr(res), _ptr(out), Cout, B, _stream()), "op_conv_wino")
+    check(lib.mcedm_op_conv_wino(_ptr(xa), _ptr(xb), Ca, Cb, _ptr(coef), coef_batch, act, resample, H, W, _ptr(wino),
+                                 _ptr(bias), _ptr(res), res_mode, _ptr(out), Cout, B, _stream()), "op_conv_wino")
     return out
 
 

@@ -78,6 +78,29 @@ def test_conv_wino_vs_oracle_and_direct(lib, B, Ca, Cb, Cout, H, W, act, use_coe
         assert float(y[:, Cin:].abs().max()) == 0.0
 
 
+def test_conv_wino_upsampled_input_and_residual(lib):
+    """The up block's two convs (adm_blocks.py:69-73, 161, 171): conv0 reads the nearest-2x up-sampled activated source,
+    conv1 adds the up-sampled block input as the residual."""
+    B, C, Hs, Ws = 2, 128, 8, 16
+    x = fx.randn("wino/up/x", B, C, Hs, Ws)
+    w = fx.randn("wino/up/w", 128, C, 3, 3) / (C * 9) ** 0.5
+    b = fx.randn("wino/up/b", 128) * 0.1
+    coef = coef_table("wino/up", B, C)
+    wino = lib.op_pack_conv_wino(dev(w))
+    wpk, bpk = lib.op_pack_conv(dev(w), dev(b))
+    xt = torch.nn.functional.silu((x - coef[..., 0, None, None]) * coef[..., 1, None, None] + coef[..., 2, None, None])
+    up = torch.nn.functional.interpolate(xt, scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(up.double(), w.double(), b.double(), padding=1)
+    got = lib.op_conv_wino(dev(x), None, wino, dev(b), 128, coef=dev(coef), act=1, resample=lib.RS_UP)
+    close(got, ref, "winograd on the up-sampled input vs fp64")
+    close(got, lib.op_conv(dev(x), None, wpk, bpk, 128, 3, coef=dev(coef), act=1, resample=lib.RS_UP), "vs the direct kernel")
+    h = fx.randn("wino/up/h", B, C, 2 * Hs, 2 * Ws)
+    ref = torch.nn.functional.conv2d(h.double(), w.double(), b.double(), padding=1) + \
+        torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest").double()
+    got = lib.op_conv_wino(dev(h), None, wino, dev(b), 128, res=dev(x), res_mode=lib.RS_UP)
+    close(got, ref, "winograd with an up-sampled residual vs fp64")
+
+
 def test_conv_wino_is_batch_invariant(lib):
     """A sample's output bits do not depend on the batch it is computed in (sharding invariance, tests/test_hip_fullsize.py)."""
     xa = fx.randn("wino/inv/x", 4, 128, 16, 32)
