@@ -367,8 +367,15 @@ def roofline_of(prof):
     avg_ms = dom["total_ms"] / dom["launches"]
     achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
     traffic, note = committed_traffic(dom["name"])
+    extra = {}
+    if dom["name"].startswith("conv_wino"):
+        # Winograd F(2x2, 3x3): `achieved` keeps the contract's meaning -- the ALGORITHMIC flops of the convolution (2 x MAC of
+        # the direct form) over the launch time -- so it can exceed the matrix peak; the kernel issues 4/9 of them
+        # as MFMA flops, and that executed rate against the peak is the fraction of the matrix pipe it keeps busy
+        extra = {"algorithm": "Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs and (cin, cout) instead of 36",
+                 "executed_tflops": achieved * 4.0 / 9.0, "executed_frac": achieved * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS}
     return {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": note,
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, **extra, "traffic": traffic, "traffic_note": note,
             "kernel": dom["name"], "launches": dom["launches"], "avg_launch_ms": avg_ms,
             "flops_per_launch": dom["flops"] / dom["launches"], "bytes_per_launch": dom["bytes"] / dom["launches"],
             "share_of_kernel_time": dom["total_ms"] / total_ms,

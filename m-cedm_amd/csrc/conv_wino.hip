@@ -17,9 +17,10 @@
 //     are one 16-byte load) comes straight from L2 into registers, one chunk ahead -- no weight slab in LDS; the B operand
 //     (transformed input V = B^T d B, LDS layout [position][patch][k parity][k-step]) is one ds_read_b128 per position.
 //   * input path per chunk: wave w loads channel w of the chunk (10 x 18 raw patch incl. halo, 3 elements per lane), applies
-//     the fused (x - mean) * scale + offset -> SiLU transform and writes the raw tile to LDS; one chunk later every thread
+//     the fused (x - mean) * scale + offset -> SiLU transform and writes the raw tile to LDS; one stage later every thread
 //     turns (channel k, patch t, row half) of it into 8 Winograd-domain values (6 ds_read_b64, 16 adds, 8 ds_write_b32).
-//     Both LDS stages are double-buffered: ONE barrier per chunk.
+//     Both LDS stages are double-buffered, a stage is two chunks, ONE barrier per stage, and all of this side work is
+//     issued in slices between the MFMAs of the same wave (see the K loop).
 //   * epilogue: the output transform is register-local over nu; over xi the two halves exchange one 2 x 32-register
 //     partial through LDS; then bias, residual, stores (8-byte, two pixels of a row) and the fused GroupNorm statistics.
 // Results differ from the direct kernel in the last bits (a different, equally long fp32 sum: measured 1.5x its error
@@ -32,20 +33,23 @@
 
 namespace mcedm {
 
-namespace {
-
 constexpr int WPH = 8, WPW = 16;                 // output pixels per workgroup
 constexpr int WTX = WPW / 2, WTY = WPH / 2;      // 2x2 patches: 8 x 4 = 32 = one MFMA N block
 constexpr int WKC = 8;                           // input channels per chunk
+static_assert(WTX * WTY == 32, "one MFMA N block of patches per workgroup");
 constexpr int WNT = 512;
 constexpr int RROWS = WPH + 2, RPITCH = WPW + 2; // raw tile with halo: 10 x 18
 constexpr int RPLANE = 208;                      // floats between channels of the raw tile (180 used; = 16 mod 32 banks)
 constexpr int RSUB = (RROWS * RPITCH + 63) / 64; // raw elements per lane and channel: 3
-constexpr int VPOS = WTX * WTY * WKC;            // floats per position of the V tile: 256
-constexpr int VBUF = 16 * VPOS, RBUF = WKC * RPLANE;
+constexpr int WSC = 2;                           // chunks per stage of the K loop (one barrier per stage)
+// V tile of one (chunk, position): [k parity h][patch 32][k-step 4]; the h = 1 block starts at float 160 so that the
+// 16-byte B-fragment reads of a wave (lane = patch + 32 h) and the transform's dword writes are bank-conflict free
+constexpr int VH1 = 160, VPOS = 288;
+constexpr int VBUF = WSC * 16 * VPOS, RBUF = WSC * WKC * RPLANE;      // floats per stage
 constexpr int LDS_ROWS_OFF = 2 * VBUF + 2 * RBUF;     // transform rows start here (floats; 16-byte aligned)
 constexpr int XCH_FLOATS = 8 * 32 * 64;               // epilogue exchange: 8 waves x 32 registers x 64 lanes
-static_assert(LDS_ROWS_OFF % 4 == 0 && RPLANE >= RROWS * RPITCH && RPLANE % 2 == 0, "LDS layout");
+static_assert(LDS_ROWS_OFF % 4 == 0 && RPLANE >= RROWS * RPITCH && RPLANE % 2 == 0 && VPOS % 4 == 0 && VH1 % 4 == 0, "LDS layout");
+static_assert(2 * VBUF >= XCH_FLOATS + 2 * 32 * 3, "the epilogue's exchange area lives in the V buffers");
 
 struct WinoStatCfg { static constexpr int MT = 128, NT = WNT; };   // what conv_stats_store needs to know about the tile
 
@@ -111,41 +115,48 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
     roff[i] = !inb ? 0u : p.resample == RS_UP ? 4u * (unsigned)((y >> 1) * p.Ws + (x >> 1)) : 4u * (unsigned)(y * p.W + x);
   }
   const size_t HWs = (size_t)p.Hs * p.Ws;
-  float raw[RSUB];
-  auto raw_load = [&](int ch) {
-    const int ci = ch * WKC + wave;
+  float raw[WSC][RSUB];
+  auto raw_load1 = [&](int st, int sc) {
+    const int ci = (st * WSC + sc) * WKC + wave;
     const bool in_a = ci < p.Ca;
     const float* src = in_a ? p.xa : p.xb;
     const int cc = in_a ? ci : ci - p.Ca, CC = in_a ? p.Ca : p.Cb;
     const bool ok = ci < Cin && src != nullptr;
     const float* plane = ok ? src + ((size_t)n * CC + cc) * HWs : (p.xa ? p.xa : p.xb);
 #pragma unroll
-    for (int i = 0; i < RSUB; ++i) raw[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
+    for (int i = 0; i < RSUB; ++i) raw[sc][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
   };
-  auto raw_commit = [&](int ch, float* rb) {
-    const int ci = ch * WKC + wave;
+  auto raw_commit1 = [&](int st, int sc, float* rb) {
+    const int ci = (st * WSC + sc) * WKC + wave;
     const bool ok = ci < Cin && (ci < p.Ca ? p.xa : p.xb) != nullptr;
     const Coef cf = cfl[ci < Cin ? ci : Cin - 1];
     const unsigned ck = ok ? 0xffffffffu : 0u;
 #pragma unroll
     for (int i = 0; i < RSUB; ++i) {
-      float v = apply_coef(raw[i], cf, p.act);
+      float v = apply_coef(raw[sc][i], cf, p.act);
       v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeep[i] & ck));
-      if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[wave * RPLANE + lane + 64 * i] = v;
+      if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + wave) * RPLANE + lane + 64 * i] = v;
     }
   };
-  // ---- input transform: thread = (channel k, patch (ty, tx), row half hf): V[xi][nu] for xi in {2 hf, 2 hf + 1}
+  auto raw_load = [&](int st) { for (int sc = 0; sc < WSC; ++sc) raw_load1(st, sc); };
+  auto raw_commit = [&](int st, float* rb) { for (int sc = 0; sc < WSC; ++sc) raw_commit1(st, sc, rb); };
+  // ---- input transform: thread = (channel k, patch (ty, tx), row half hf): V[xi][nu] for xi in {2 hf, 2 hf + 1}.
+  // In two halves (LDS reads / arithmetic + LDS writes) per chunk of the stage, so that the K loop can spread them out.
   const int tk = lane & 7, ttx = lane >> 3, tty = mb;
   const int tr_src = tk * RPLANE + (2 * tty + hf) * RPITCH + 2 * ttx;
-  const int tr_dst = (8 * hf) * VPOS + (tty * WTX + ttx) * 8 + (tk & 1) * 4 + (tk >> 1);
-  auto transform = [&](const float* rb, float* vb) {
-    float d[3][4];
+  const int tr_dst = (8 * hf) * VPOS + (tk & 1) * VH1 + (tty * WTX + ttx) * 4 + (tk >> 1);
+  float2 td[WSC][3][2];
+  auto transform_read1 = [&](int sc, const float* rb) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float2 lo = *reinterpret_cast<const float2*>(rb + tr_src + a * RPITCH);
-      const float2 hi = *reinterpret_cast<const float2*>(rb + tr_src + a * RPITCH + 2);
-      d[a][0] = lo.x; d[a][1] = lo.y; d[a][2] = hi.x; d[a][3] = hi.y;
+      td[sc][a][0] = *reinterpret_cast<const float2*>(rb + sc * WKC * RPLANE + tr_src + a * RPITCH);
+      td[sc][a][1] = *reinterpret_cast<const float2*>(rb + sc * WKC * RPLANE + tr_src + a * RPITCH + 2);
     }
+  };
+  auto transform_finish1 = [&](int sc, float* vb) {
+    float d[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { d[a][0] = td[sc][a][0].x; d[a][1] = td[sc][a][0].y; d[a][2] = td[sc][a][1].x; d[a][3] = td[sc][a][1].y; }
     // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; rows held: hf = 0: d0 d1 d2, hf = 1: d1 d2 d3
     float t[2][4];
 #pragma unroll
@@ -155,20 +166,25 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-      float* o = vb + tr_dst + 4 * x * VPOS;
+      float* o = vb + sc * 16 * VPOS + tr_dst + 4 * x * VPOS;
       o[0 * VPOS] = t[x][0] - t[x][2];
       o[1 * VPOS] = t[x][1] + t[x][2];
       o[2 * VPOS] = t[x][2] - t[x][1];
       o[3 * VPOS] = t[x][1] - t[x][3];
     }
   };
+  auto transform_read = [&](const float* rb) { for (int sc = 0; sc < WSC; ++sc) transform_read1(sc, rb); };
+  auto transform_finish = [&](float* vb) { for (int sc = 0; sc < WSC; ++sc) transform_finish1(sc, vb); };
 
   // ---- prologue
+  const int nst = (nch + WSC - 1) / WSC;
   stage_coef_rows<WNT>(p, n, cfl, tid);
   raw_load(0);
   __syncthreads();
   raw_commit(0, rbuf);
-  if (nch > 1) raw_load(1);
+  if (nst > 1) raw_load(1);
+  if (nst > 1) raw_commit(1, rbuf + RBUF);
+  if (nst > 2) raw_load(2);                                          // stays in registers until trip 0 commits it
   // this wave's transformed weights: 8 positions x one 16-byte load per chunk
   const size_t ustride = (size_t)mblocks * 16 * 64;                  // f32x4 per chunk
   const f32x4* up = reinterpret_cast<const f32x4*>(p.wino) + ((size_t)(m0 / 32 + mb) * 16 + 8 * hf) * 64 + lane;
@@ -176,8 +192,8 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
 #pragma unroll
   for (int q = 0; q < 8; ++q) ua[q] = up[q * 64];
   __syncthreads();
-  transform(rbuf, vbuf);
-  if (nch > 1) raw_commit(1, rbuf + RBUF);
+  transform_read(rbuf);
+  transform_finish(vbuf);
   f32x16 acc[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q)
@@ -185,64 +201,75 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   __syncthreads();
 
-  // ---- K loop
-  const int vrd = (8 * hf) * VPOS + (lane & 31) * 8 + (lane >> 5) * 4;
-  const bool late = (hf == 1) && (mode & 1);
+  // ---- K loop: one trip = one stage of WSC chunks
+  const int vrd = (8 * hf) * VPOS + (lane >> 5) * VH1 + (lane & 31) * 4;
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
-#ifdef MCEDM_WINO_TIMELINE      // per-phase cycle sums of waves 0 and 4 (lane 0) -> dbg[8..12] / dbg[13..15, 7] (diagnostic builds only)
+#ifdef MCEDM_WINO_TIMELINE      // cycle sums of waves 0 and 4 (lane 0): trip top, MFMA stream, barrier -> dbg[8..12] / dbg[13..15, 7] (diagnostic builds only)
   unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #define WINO_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; }
+  const bool no_u = mode & 2, no_t = mode & 4, no_r = mode & 8;   // drop the weight reloads / the transform / the raw tile path (wrong results)
 #else
 #define WINO_STAMP(i)
-#endif
-#ifdef MCEDM_WINO_TIMELINE      // diagnostic builds: mode bits 1..3 drop the weight reloads / the transform / the raw tile path (wrong results)
-  const bool no_u = mode & 2, no_t = mode & 4, no_r = mode & 8;
-#else
   constexpr bool no_u = false, no_t = false, no_r = false;
 #endif
-  for (int c = 0; c < nch; ++c) {
-    const int cur = c & 1;
-    if (c + 2 < nch && !no_r) raw_load(c + 2);
-    const f32x4* un = up + (size_t)(c + 1 < nch ? c + 1 : c) * ustride;
-    // the two waves of a SIMD (same mb, hf = 0 / 1) take the transform and the MFMA block in opposite order: one's vector /
-    // LDS work runs beside the other's MFMAs.  Every phase of a trip touches buffers of its own, so any order is legal; the
-    // commit of the raw tile comes last in both (its global loads were issued at the top of the trip).
+  // One trip = one stage: 2 x 4 slots of [two B-fragment reads for the next slot | eight MFMAs | two weight reloads] and,
+  // behind each slot's MFMAs, one slice of the side work that prepares later stages -- the transform of stage st + 1 (LDS
+  // reads in slot 0, arithmetic + LDS writes in slots 4 / 5), the commit of the raw tile of stage st + 2 (slots 1 / 2; its
+  // global loads were issued a trip ago) and the loads of stage st + 3 (slot 3).  Sliced like this the side work costs its
+  // issue cycles; as a phase of its own (before or after the MFMAs, or ping-ponged between the two waves of a SIMD) it
+  // cost its latencies: 2400 cycles per chunk and wave against 2048 of MFMAs.  Every slice touches buffers no MFMA of this
+  // trip reads, so one barrier per trip is enough.
+  auto side_slice = [&](int slot, int st, int cur) {
+    const bool more = st + 1 < nst && !no_t, c2 = st + 2 < nst && !no_r, l3 = st + 3 < nst && !no_r;
+    if (slot == 0 && more) transform_read(rbuf + (cur ^ 1) * RBUF);
+    if (slot == 1 && c2) raw_commit1(st + 2, 0, rbuf + cur * RBUF);
+    if (slot == 2 && c2) raw_commit1(st + 2, 1, rbuf + cur * RBUF);
+    if (slot == 3 && l3) raw_load(st + 3);
+    if (slot == 4 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
+    if (slot == 5 && more) transform_finish1(1, vbuf + (cur ^ 1) * VBUF);
+  };
+  (void)mode;
+  for (int st = 0; st < nst; ++st) {
+    const int cur = st & 1;
     WINO_STAMP(0)
-    if (!late && c + 1 < nch && !no_t) transform(rbuf + (cur ^ 1) * RBUF, vbuf + (cur ^ 1) * VBUF);
-    WINO_STAMP(1)
-    const float* vb = vbuf + cur * VBUF + vrd;
-    f32x4 b4[2][2];                                        // B fragments of two positions, one pair ahead of the MFMAs
-    b4[0][0] = *reinterpret_cast<const f32x4*>(vb);
-    b4[0][1] = *reinterpret_cast<const f32x4*>(vb + VPOS);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-    for (int qp = 0; qp < 4; ++qp) {
-      const int cb = qp & 1;
-      if (qp < 3) {
-        b4[cb ^ 1][0] = *reinterpret_cast<const f32x4*>(vb + (2 * qp + 2) * VPOS);
-        b4[cb ^ 1][1] = *reinterpret_cast<const f32x4*>(vb + (2 * qp + 3) * VPOS);
-      }
+    for (int sc = 0; sc < WSC; ++sc) {
+      const int c = st * WSC + sc;
+      const f32x4* un = up + (size_t)(c + 1 < nch ? c + 1 : nch - 1) * ustride;
+      const float* vb = vbuf + cur * VBUF + sc * 16 * VPOS + vrd;
+      f32x4 b4[2][2];                                      // B fragments of two positions, one pair ahead of the MFMAs
+      b4[0][0] = *reinterpret_cast<const f32x4*>(vb);
+      b4[0][1] = *reinterpret_cast<const f32x4*>(vb + VPOS);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[2 * qp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * qp][s], b4[cb][0][s], acc[2 * qp], 0, 0, 0);
-        acc[2 * qp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * qp + 1][s], b4[cb][1][s], acc[2 * qp + 1], 0, 0, 0);
+      for (int qp = 0; qp < 4; ++qp) {
+        const int cb = qp & 1;
+        if (qp < 3) {
+          b4[cb ^ 1][0] = *reinterpret_cast<const f32x4*>(vb + (2 * qp + 2) * VPOS);
+          b4[cb ^ 1][1] = *reinterpret_cast<const f32x4*>(vb + (2 * qp + 3) * VPOS);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[2 * qp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * qp][s], b4[cb][0][s], acc[2 * qp], 0, 0, 0);
+          acc[2 * qp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[2 * qp + 1][s], b4[cb][1][s], acc[2 * qp + 1], 0, 0, 0);
+        }
+        // the next chunk's weights of these two positions: 2 KB per wave every eight MFMAs.  (All of a chunk's weight loads
+        // issued together right behind the barrier -- 64 KB per CU at once -- back up the vector memory path and every
+        // wave stalls in their issue for 1000-3000 cycles per chunk.)
+        if (!no_u) {
+          ua[2 * qp] = un[(2 * qp) * 64];
+          ua[2 * qp + 1] = un[(2 * qp + 1) * 64];
+        }
+        // pin the order: the next pair's two LDS reads, this pair's eight MFMAs, this pair's two reloads, the slice
+        if (qp < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        side_slice(sc * 4 + qp, st, cur);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      // the next chunk's weights of these two positions: 2 KB per wave every eight MFMAs.  (All of a chunk's weight loads
-      // issued together right behind the barrier -- 64 KB per CU at once -- back up the vector memory path and every wave
-      // stalls in their issue for 1000-3000 cycles per chunk.)
-      if (!no_u) {
-        ua[2 * qp] = un[(2 * qp) * 64];
-        ua[2 * qp + 1] = un[(2 * qp + 1) * 64];
-      }
-      // pin the order: the next pair's two LDS reads, this pair's eight MFMAs, this pair's two reloads
-      if (qp < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
     }
     WINO_STAMP(2)
-    if (late && c + 1 < nch && !no_t) transform(rbuf + (cur ^ 1) * RBUF, vbuf + (cur ^ 1) * VBUF);
-    if (c + 2 < nch && !no_r) raw_commit(c + 2, rbuf + cur * RBUF);
-    WINO_STAMP(3)
     __syncthreads();
     WINO_STAMP(4)
   }
@@ -338,24 +365,22 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
   }
 }
 
-int wino_env() {                                        // MCEDM_WINOGRAD=0: never take this kernel
+static int wino_env() {                                        // MCEDM_WINOGRAD=0: never take this kernel
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_WINOGRAD"); env = e ? atoi(e) : 1; }
   return env;
 }
-int wino_mode_env() {                                   // MCEDM_WINO_MODE bit 0: opposite phase order in the two waves of a SIMD
+static int wino_mode_env() {                                   // MCEDM_WINO_MODE: ablation bits of the -DMCEDM_WINO_TIMELINE build (else unused)
   static int env = -1;
-  if (env < 0) { const char* e = getenv("MCEDM_WINO_MODE"); env = e ? atoi(e) : 1; }
+  if (env < 0) { const char* e = getenv("MCEDM_WINO_MODE"); env = e ? atoi(e) : 0; }
   return env;
 }
 
-int wino_min_hw_env() {                                 // MCEDM_WINO_MIN_HW: smallest image (pixels) served; below 32 x 32 the grid
+static int wino_min_hw_env() {                                 // MCEDM_WINO_MIN_HW: smallest image (pixels) served; below 32 x 32 the grid
   static int env = -1;                                  // (B * H * W / 128 workgroups) no longer fills the chip
   if (env < 0) { const char* e = getenv("MCEDM_WINO_MIN_HW"); env = e ? atoi(e) : 1024; }
   return env;
 }
-
-}  // namespace
 
 size_t conv_wino_packed_floats(int Cout, int Cin) { return (size_t)16 * cout_padded(Cout) * (size_t)ceil_div(Cin, WKC) * WKC; }
 
@@ -394,7 +419,7 @@ int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
   MCEDM_HIP_TRY(hipGetDevice(&dev));
   MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
   if (!attr_set[dev].load(std::memory_order_acquire)) {
-    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[dev].store(true, std::memory_order_release);
   }
   const double px = (double)a.B * a.H * a.W;
