@@ -37,21 +37,29 @@ constexpr int WPH = 8, WPW = 16;                 // output pixels per workgroup
 constexpr int WTX = WPW / 2, WTY = WPH / 2;      // 2x2 patches: 8 x 4 = 32 = one MFMA N block
 constexpr int WKC = 8;                           // input channels per chunk
 static_assert(WTX * WTY == 32, "one MFMA N block of patches per workgroup");
-constexpr int WNT = 512;
+// MB = 32-channel output blocks per workgroup: 4 (128 channels, 512 threads, one workgroup per CU, two chunks per stage) or
+// 2 (64 channels -- the ch = 64 networks --, 256 threads, two workgroups per CU, one chunk per stage so that both fit the LDS)
+template <int MB_>
+struct WinoCfg {
+  static constexpr int MB = MB_, NT = 128 * MB_, NW = 2 * MB_, MT = 32 * MB_;
+  static constexpr int SC = MB_ == 4 ? 2 : 1;          // chunks per stage of the K loop (one barrier per stage)
+  static constexpr int CPW = WKC / NW;                  // channels of a chunk that one wave stages: 1 or 2
+  static constexpr int TI = 4 / MB_;                    // patch rows (of the four) per thread in the input transform
+  static constexpr int VBUF = SC * 16 * 288, RBUF = SC * WKC * 208;      // floats per stage (VPOS, RPLANE below)
+  static constexpr int LDS_ROWS_OFF = 2 * VBUF + 2 * RBUF;              // transform rows start here (floats; 16-byte aligned)
+  static constexpr int XCH_FLOATS = NW * 32 * 64;                       // epilogue exchange: 32 registers x 64 lanes per wave
+  static constexpr int RED_FLOATS = 2 * (MT / 2) * 3;                   // statistics records of the two halves (pairs at most)
+  static_assert(MB_ == 4 || MB_ == 2, "128 or 64 output channels per workgroup");
+  static_assert(LDS_ROWS_OFF % 4 == 0, "LDS layout");
+};
 constexpr int RROWS = WPH + 2, RPITCH = WPW + 2; // raw tile with halo: 10 x 18
 constexpr int RPLANE = 208;                      // floats between channels of the raw tile (180 used; = 16 mod 32 banks)
 constexpr int RSUB = (RROWS * RPITCH + 63) / 64; // raw elements per lane and channel: 3
-constexpr int WSC = 2;                           // chunks per stage of the K loop (one barrier per stage)
 // V tile of one (chunk, position): [k parity h][patch 32][k-step 4]; the h = 1 block starts at float 160 so that the
 // 16-byte B-fragment reads of a wave (lane = patch + 32 h) and the transform's dword writes are bank-conflict free
 constexpr int VH1 = 160, VPOS = 288;
-constexpr int VBUF = WSC * 16 * VPOS, RBUF = WSC * WKC * RPLANE;      // floats per stage
-constexpr int LDS_ROWS_OFF = 2 * VBUF + 2 * RBUF;     // transform rows start here (floats; 16-byte aligned)
-constexpr int XCH_FLOATS = 8 * 32 * 64;               // epilogue exchange: 8 waves x 32 registers x 64 lanes
-static_assert(LDS_ROWS_OFF % 4 == 0 && RPLANE >= RROWS * RPITCH && RPLANE % 2 == 0 && VPOS % 4 == 0 && VH1 % 4 == 0, "LDS layout");
-static_assert(2 * VBUF >= XCH_FLOATS + 2 * 32 * 3, "the epilogue's exchange area lives in the V buffers");
+static_assert(RPLANE == 208 && VPOS == 288 && RPLANE >= RROWS * RPITCH && RPLANE % 2 == 0 && VPOS % 4 == 0 && VH1 % 4 == 0, "LDS layout");
 
-struct WinoStatCfg { static constexpr int MT = 128, NT = WNT; };   // what conv_stats_store needs to know about the tile
 
 // U = G g G^T for one (cout, cin): G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 // tflip: the data-gradient weights, w'[co][ci][a][b] = w[ci][co][2 - a][2 - b] (w is then [Cin][Cout][3][3])
@@ -87,18 +95,20 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int tiles_x, int tiles_img, int nch, int mblocks, int mode) {
+template <class C>
+__global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(const ConvArgs p, int tiles_x, int tiles_img, int nch, int mblocks, int mode) {
+  constexpr int WSC = C::SC, VBUF = C::VBUF, RBUF = C::RBUF, MB = C::MB;
   extern __shared__ float lds[];
   float* const vbuf = lds;
   float* const rbuf = lds + 2 * VBUF;
-  Coef* const cfl = reinterpret_cast<Coef*>(lds + LDS_ROWS_OFF);
+  Coef* const cfl = reinterpret_cast<Coef*>(lds + C::LDS_ROWS_OFF);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mb = wave & 3, hf = wave >> 2;
+  const int mb = wave % MB, hf = wave / MB;
   if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
   const int n = blockIdx.x / tiles_img, tile = blockIdx.x % tiles_img;
   const int y0 = (tile / tiles_x) * WPH, x0 = (tile % tiles_x) * WPW;
-  const int m0 = blockIdx.y * 128;
+  const int m0 = blockIdx.y * C::MT;
   const int Cin = p.Ca + p.Cb;
   const size_t HW = (size_t)p.H * p.W;
 
@@ -115,62 +125,74 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
     roff[i] = !inb ? 0u : p.resample == RS_UP ? 4u * (unsigned)((y >> 1) * p.Ws + (x >> 1)) : 4u * (unsigned)(y * p.W + x);
   }
   const size_t HWs = (size_t)p.Hs * p.Ws;
-  float raw[WSC][RSUB];
+  float raw[WSC][C::CPW][RSUB];
   auto raw_load1 = [&](int st, int sc) {
-    const int ci = (st * WSC + sc) * WKC + wave;
-    const bool in_a = ci < p.Ca;
-    const float* src = in_a ? p.xa : p.xb;
-    const int cc = in_a ? ci : ci - p.Ca, CC = in_a ? p.Ca : p.Cb;
-    const bool ok = ci < Cin && src != nullptr;
-    const float* plane = ok ? src + ((size_t)n * CC + cc) * HWs : (p.xa ? p.xa : p.xb);
 #pragma unroll
-    for (int i = 0; i < RSUB; ++i) raw[sc][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
+    for (int cw = 0; cw < C::CPW; ++cw) {
+      const int ci = (st * WSC + sc) * WKC + wave * C::CPW + cw;
+      const bool in_a = ci < p.Ca;
+      const float* src = in_a ? p.xa : p.xb;
+      const int cc = in_a ? ci : ci - p.Ca, CC = in_a ? p.Ca : p.Cb;
+      const bool ok = ci < Cin && src != nullptr;
+      const float* plane = ok ? src + ((size_t)n * CC + cc) * HWs : (p.xa ? p.xa : p.xb);
+#pragma unroll
+      for (int i = 0; i < RSUB; ++i) raw[sc][cw][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
+    }
   };
   auto raw_commit1 = [&](int st, int sc, float* rb) {
-    const int ci = (st * WSC + sc) * WKC + wave;
-    const bool ok = ci < Cin && (ci < p.Ca ? p.xa : p.xb) != nullptr;
-    const Coef cf = cfl[ci < Cin ? ci : Cin - 1];
-    const unsigned ck = ok ? 0xffffffffu : 0u;
 #pragma unroll
-    for (int i = 0; i < RSUB; ++i) {
-      float v = apply_coef(raw[sc][i], cf, p.act);
-      v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeep[i] & ck));
-      if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + wave) * RPLANE + lane + 64 * i] = v;
+    for (int cw = 0; cw < C::CPW; ++cw) {
+      const int kl = wave * C::CPW + cw, ci = (st * WSC + sc) * WKC + kl;
+      const bool ok = ci < Cin && (ci < p.Ca ? p.xa : p.xb) != nullptr;
+      const Coef cf = cfl[ci < Cin ? ci : Cin - 1];
+      const unsigned ck = ok ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int i = 0; i < RSUB; ++i) {
+        float v = apply_coef(raw[sc][cw][i], cf, p.act);
+        v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeep[i] & ck));
+        if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + kl) * RPLANE + lane + 64 * i] = v;
+      }
     }
   };
   auto raw_load = [&](int st) { for (int sc = 0; sc < WSC; ++sc) raw_load1(st, sc); };
   auto raw_commit = [&](int st, float* rb) { for (int sc = 0; sc < WSC; ++sc) raw_commit1(st, sc, rb); };
   // ---- input transform: thread = (channel k, patch (ty, tx), row half hf): V[xi][nu] for xi in {2 hf, 2 hf + 1}.
   // In two halves (LDS reads / arithmetic + LDS writes) per chunk of the stage, so that the K loop can spread them out.
+  // patch rows ty = mb + MB ti, ti < TI
   const int tk = lane & 7, ttx = lane >> 3, tty = mb;
   const int tr_src = tk * RPLANE + (2 * tty + hf) * RPITCH + 2 * ttx;
   const int tr_dst = (8 * hf) * VPOS + (tk & 1) * VH1 + (tty * WTX + ttx) * 4 + (tk >> 1);
-  float2 td[WSC][3][2];
+  float2 td[WSC][C::TI][3][2];
   auto transform_read1 = [&](int sc, const float* rb) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      td[sc][a][0] = *reinterpret_cast<const float2*>(rb + sc * WKC * RPLANE + tr_src + a * RPITCH);
-      td[sc][a][1] = *reinterpret_cast<const float2*>(rb + sc * WKC * RPLANE + tr_src + a * RPITCH + 2);
-    }
+    for (int ti = 0; ti < C::TI; ++ti)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        td[sc][ti][a][0] = *reinterpret_cast<const float2*>(rb + sc * WKC * RPLANE + tr_src + (2 * MB * ti + a) * RPITCH);
+        td[sc][ti][a][1] = *reinterpret_cast<const float2*>(rb + sc * WKC * RPLANE + tr_src + (2 * MB * ti + a) * RPITCH + 2);
+      }
   };
   auto transform_finish1 = [&](int sc, float* vb) {
-    float d[3][4];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { d[a][0] = td[sc][a][0].x; d[a][1] = td[sc][a][0].y; d[a][2] = td[sc][a][1].x; d[a][3] = td[sc][a][1].y; }
-    // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; rows held: hf = 0: d0 d1 d2, hf = 1: d1 d2 d3
-    float t[2][4];
+    for (int ti = 0; ti < C::TI; ++ti) {
+      float d[3][4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (hf == 0) { t[0][b] = d[0][b] - d[2][b]; t[1][b] = d[1][b] + d[2][b]; }
-      else         { t[0][b] = d[1][b] - d[0][b]; t[1][b] = d[0][b] - d[2][b]; }
-    }
+      for (int a = 0; a < 3; ++a) { d[a][0] = td[sc][ti][a][0].x; d[a][1] = td[sc][ti][a][0].y; d[a][2] = td[sc][ti][a][1].x; d[a][3] = td[sc][ti][a][1].y; }
+      // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; rows held: hf = 0: d0 d1 d2, hf = 1: d1 d2 d3
+      float t[2][4];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      float* o = vb + sc * 16 * VPOS + tr_dst + 4 * x * VPOS;
-      o[0 * VPOS] = t[x][0] - t[x][2];
-      o[1 * VPOS] = t[x][1] + t[x][2];
-      o[2 * VPOS] = t[x][2] - t[x][1];
-      o[3 * VPOS] = t[x][1] - t[x][3];
+      for (int b = 0; b < 4; ++b) {
+        if (hf == 0) { t[0][b] = d[0][b] - d[2][b]; t[1][b] = d[1][b] + d[2][b]; }
+        else         { t[0][b] = d[1][b] - d[0][b]; t[1][b] = d[0][b] - d[2][b]; }
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        float* o = vb + sc * 16 * VPOS + tr_dst + MB * ti * WTX * 4 + 4 * x * VPOS;
+        o[0 * VPOS] = t[x][0] - t[x][2];
+        o[1 * VPOS] = t[x][1] + t[x][2];
+        o[2 * VPOS] = t[x][2] - t[x][1];
+        o[3 * VPOS] = t[x][1] - t[x][3];
+      }
     }
   };
   auto transform_read = [&](const float* rb) { for (int sc = 0; sc < WSC; ++sc) transform_read1(sc, rb); };
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
 
   // ---- prologue
   const int nst = (nch + WSC - 1) / WSC;
-  stage_coef_rows<WNT>(p, n, cfl, tid);
+  stage_coef_rows<C::NT>(p, n, cfl, tid);
   raw_load(0);
   __syncthreads();
   raw_commit(0, rbuf);
@@ -221,12 +243,19 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
   // trip reads, so one barrier per trip is enough.
   auto side_slice = [&](int slot, int st, int cur) {
     const bool more = st + 1 < nst && !no_t, c2 = st + 2 < nst && !no_r, l3 = st + 3 < nst && !no_r;
-    if (slot == 0 && more) transform_read(rbuf + (cur ^ 1) * RBUF);
-    if (slot == 1 && c2) raw_commit1(st + 2, 0, rbuf + cur * RBUF);
-    if (slot == 2 && c2) raw_commit1(st + 2, 1, rbuf + cur * RBUF);
-    if (slot == 3 && l3) raw_load(st + 3);
-    if (slot == 4 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
-    if (slot == 5 && more) transform_finish1(1, vbuf + (cur ^ 1) * VBUF);
+    if (WSC == 2) {
+      if (slot == 0 && more) transform_read(rbuf + (cur ^ 1) * RBUF);
+      if (slot == 1 && c2) raw_commit1(st + 2, 0, rbuf + cur * RBUF);
+      if (slot == 2 && c2) raw_commit1(st + 2, 1, rbuf + cur * RBUF);
+      if (slot == 3 && l3) raw_load(st + 3);
+      if (slot == 4 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
+      if (slot == 5 && more) transform_finish1(WSC - 1, vbuf + (cur ^ 1) * VBUF);
+    } else {
+      if (slot == 0 && more) transform_read(rbuf + (cur ^ 1) * RBUF);
+      if (slot == 1 && c2) raw_commit1(st + 2, 0, rbuf + cur * RBUF);
+      if (slot == 2 && l3) raw_load(st + 3);
+      if (slot == 3 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
+    }
   };
   (void)mode;
   for (int st = 0; st < nst; ++st) {
@@ -318,7 +347,7 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
 #pragma unroll
     for (int r = 0; r < 16; ++r) xch[(wave * 32 + j * 16 + r) * 64 + lane] = send[j][r];
   __syncthreads();
-  const int pw = wave ^ 4;
+  const int pw = wave ^ MB;
   float v0[16], v1[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -328,36 +357,49 @@ __global__ __launch_bounds__(WNT) void conv_wino_kernel(const ConvArgs p, int ti
   }
   if (p.gsum) {
     // fused GroupNorm statistics of what was stored (conv_tile.hpp conv_epilogue): one record per 4-channel block =
-    // registers 4 g .. 4 g + 3 of the 32 lanes that share lane >> 5; this wave holds one pixel row of every patch
-    // (256 values per block), its partner wave the other: (count, sum, M2 about the wave's own mean) per wave, merged in
-    // a fixed order by conv_stats_store.
-    float* red = lds + XCH_FLOATS;
-    float sm[4], m2[4];
+    // registers 4 g .. 4 g + 3 of the 32 lanes that share lane >> 5 (or per 2-channel block, gsum_rc == 2: their two
+    // halves); this wave holds one pixel row of every patch, its partner wave the other: (count, sum, M2 about the wave's
+    // own mean) per wave, merged in a fixed order by conv_stats_store.
+    float* red = lds + C::XCH_FLOATS;
+    const bool pairs = p.gsum_rc == 2;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float a = 0.f;
+      float a[2], b[2];
 #pragma unroll
-      for (int r = 4 * g; r < 4 * g + 4; ++r) a += v0[r] + v1[r];
+      for (int e = 0; e < 2; ++e) {
+        a[e] = (v0[4 * g + 2 * e] + v1[4 * g + 2 * e]) + (v0[4 * g + 2 * e + 1] + v1[4 * g + 2 * e + 1]);
 #pragma unroll
-      for (int off = 16; off > 0; off >>= 1) a += __shfl_xor(a, off);
-      sm[g] = a;
-      const float mean = a * (1.0f / 256.0f);
-      float b = 0.f;
+        for (int off = 16; off > 0; off >>= 1) a[e] += __shfl_xor(a[e], off);
+      }
+      const float cnt = pairs ? 128.f : 256.f;
+      const float mean0 = pairs ? a[0] * (1.0f / 128.0f) : (a[0] + a[1]) * (1.0f / 256.0f);
+      const float mean1 = pairs ? a[1] * (1.0f / 128.0f) : mean0;
 #pragma unroll
-      for (int r = 4 * g; r < 4 * g + 4; ++r) { const float d0 = v0[r] - mean, d1 = v1[r] - mean; b = fmaf(d0, d0, b); b = fmaf(d1, d1, b); }
+      for (int e = 0; e < 2; ++e) {
+        const float mean = e ? mean1 : mean0;
+        float q = 0.f;
 #pragma unroll
-      for (int off = 16; off > 0; off >>= 1) b += __shfl_xor(b, off);
-      m2[g] = b;
-    }
-    if ((lane & 31) == 0) {
+        for (int r = 4 * g + 2 * e; r < 4 * g + 2 * e + 2; ++r) { const float d0 = v0[r] - mean, d1 = v1[r] - mean; q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float* slot = red + (hf * 32 + 8 * mb + 2 * g + (lane >> 5)) * 3;
-        slot[0] = 256.f; slot[1] = sm[g]; slot[2] = m2[g];
+        for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off);
+        b[e] = q;
+      }
+      if ((lane & 31) == 0) {
+        const int quad = 8 * mb + 2 * g + (lane >> 5);
+        if (pairs) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float* slot = red + (hf * (C::MT / 2) + 2 * quad + e) * 3;
+            slot[0] = cnt; slot[1] = a[e]; slot[2] = b[e];
+          }
+        } else {
+          float* slot = red + (hf * (C::MT / 4) + quad) * 3;
+          slot[0] = cnt; slot[1] = a[0] + a[1]; slot[2] = b[0] + b[1];
+        }
       }
     }
     __syncthreads();
-    conv_stats_store<WinoStatCfg, 2>(p, red, n, m0, tile, tiles_img, tid);
+    conv_stats_store<C, 2>(p, red, n, m0, tile, tiles_img, tid);
   }
   if (p.dbg && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -394,9 +436,40 @@ int launch_pack_conv_wino(const float* w, float* dst, int Cout, int Cin, int tra
 }
 
 bool conv_wino_applicable(const ConvArgs& a, int taps) {
-  return taps == 9 && a.wino && (a.resample == RS_NONE || a.resample == RS_UP) && a.Cout % 128 == 0 && a.H % WPH == 0 &&
-         a.W % WPW == 0 && (a.Ca + a.Cb) % WKC == 0 && a.Ca % WKC == 0 && !a.sk_wpk && !(a.gsum && a.gsum_rc == 2) &&
+  return taps == 9 && a.wino && (a.resample == RS_NONE || a.resample == RS_UP) && a.Cout % 64 == 0 && a.H % WPH == 0 &&
+         a.W % WPW == 0 && (a.Ca + a.Cb) % WKC == 0 && a.Ca % WKC == 0 && !a.sk_wpk &&
          (!a.res || a.res_mode == RS_NONE || a.res_mode == RS_UP) && (a.Ca + a.Cb) <= 1024;
+}
+
+template <class C>
+static int launch_wino_cfg(const ConvArgs& a, hipStream_t stream) {
+  const int tiles_x = a.W / WPW, tiles_img = tiles_x * (a.H / WPH);
+  const long long blocks = (long long)a.B * tiles_img;
+  MCEDM_REQUIRE(blocks > 0 && blocks <= 0x7fffffffLL, "conv_wino: grid out of range");
+  const int Cin = a.Ca + a.Cb, nch = Cin / WKC;
+  const int lds_rows = C::LDS_ROWS_OFF * 4 + Cin * (int)sizeof(Coef);
+  const int lds_xch = (C::XCH_FLOATS + C::RED_FLOATS) * 4;       // exchange area + the statistics records of the two halves
+  const int lds_bytes = lds_rows > lds_xch ? lds_rows : lds_xch;
+  MCEDM_REQUIRE(lds_bytes <= 160 * 1024 / (C::MB == 4 ? 1 : 2), "conv_wino: %d input channels exceed the LDS row table", Cin);
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  MCEDM_HIP_TRY(hipGetDevice(&dev));
+  MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  if (!attr_set[dev].load(std::memory_order_acquire)) {
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[dev].store(true, std::memory_order_release);
+  }
+  char name[64] = "";
+  if (prof_enabled()) snprintf(name, sizeof(name), "conv_wino_kernel<WinoCfg<%d> >", C::MB);      // = rocprofv3's name
+  const double px = (double)a.B * a.H * a.W;
+  // algorithmic cost = the direct convolution's (2 * MAC); the kernel issues 4 / 9 of these as matrix flops
+  ProfScope ps(name, 2.0 * px * a.Cout * (double)Cin * 9,
+               4.0 * ((double)a.B * Cin * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * Cin * 9), stream);
+  hipLaunchKernelGGL(conv_wino_kernel<C>, dim3((unsigned)blocks, a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x, tiles_img,
+                     nch, cout_padded(a.Cout) / 32, wino_mode_env());
+  MCEDM_LAUNCH_CHECK("conv_wino_kernel");
+  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_img, tiles_x, WPH, WPW, a.gsum_rc == 2 ? 2 : 4};
+  return MCEDM_OK;
 }
 
 int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
@@ -407,35 +480,13 @@ int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
                 "conv_wino: bad arguments");
   MCEDM_REQUIRE((unsigned long long)a.H * a.W * 4ull < (1ull << 32), "conv_wino: plane exceeds the 4 GiB offset range");
   { const int rc = conv_resolve_identity(a); if (rc != MCEDM_OK) return rc; }
-  const int tiles_x = a.W / WPW, tiles_img = tiles_x * (a.H / WPH);
-  const long long blocks = (long long)a.B * tiles_img;
-  MCEDM_REQUIRE(blocks > 0 && blocks <= 0x7fffffffLL, "conv_wino: grid out of range");
-  const int Cin = a.Ca + a.Cb, nch = Cin / WKC;
-  const int lds_rows = (LDS_ROWS_OFF * 4 + Cin * (int)sizeof(Coef));
-  const int lds_xch = (XCH_FLOATS + 2 * 32 * 3) * 4;             // exchange area + the statistics records of the two halves
-  const int lds_bytes = lds_rows > lds_xch ? lds_rows : lds_xch;
-  static std::atomic<bool> attr_set[64];
-  int dev = 0;
-  MCEDM_HIP_TRY(hipGetDevice(&dev));
-  MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
-  if (!attr_set[dev].load(std::memory_order_acquire)) {
-    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set[dev].store(true, std::memory_order_release);
-  }
-  const double px = (double)a.B * a.H * a.W;
-  // algorithmic cost = the direct convolution's (2 * MAC); the kernel issues 4 / 9 of these as matrix flops
-  ProfScope ps("conv_wino_kernel", 2.0 * px * a.Cout * (double)Cin * 9,
-               4.0 * ((double)a.B * Cin * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * Cin * 9), stream);
-  hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)blocks, a.Cout / 128), dim3(WNT), lds_bytes, stream, a, tiles_x, tiles_img, nch,
-                     cout_padded(a.Cout) / 32, wino_mode_env());
-  MCEDM_LAUNCH_CHECK("conv_wino_kernel");
-  if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_img, tiles_x, WPH, WPW, 4};
-  return MCEDM_OK;
+  // 128 output channels per workgroup where they divide (fewer passes over the input), else 64
+  return a.Cout % 128 == 0 ? launch_wino_cfg<WinoCfg<4>>(a, stream) : launch_wino_cfg<WinoCfg<2>>(a, stream);
 }
 
 // plan-time question (build_layout): will an un-resampled Cin -> Cout conv on H x W images be served here?
 bool conv_wino_shape_ok(int Cout, int Cin, int H, int W) {
-  return wino_env() != 0 && Cout % 128 == 0 && Cin % WKC == 0 && H % WPH == 0 && W % WPW == 0 && (long long)H * W >= wino_min_hw_env();
+  return wino_env() != 0 && Cout % 64 == 0 && Cin % WKC == 0 && H % WPH == 0 && W % WPW == 0 && (long long)H * W >= wino_min_hw_env();
 }
 // the dispatcher's choice: enabled, and an image large enough for the grid to fill the chip
 bool conv_wino_preferred(const ConvArgs& a) { return wino_env() != 0 && (long long)a.H * a.W >= wino_min_hw_env(); }

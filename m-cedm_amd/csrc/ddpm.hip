@@ -24,7 +24,7 @@
 
 namespace mcedm {
 
-struct DConv { int w = -1, b = -1; int cin = 0, cout = 0, taps = 0; size_t wpk = NONE, bias = NONE; };
+struct DConv { int w = -1, b = -1; int cin = 0, cout = 0, taps = 0; size_t wpk = NONE, bias = NONE, wino = NONE; };   // wino: Winograd table (conv_wino.hip)
 struct DNorm { int w = -1, b = -1; int C = 0; size_t gamma = NONE, beta = NONE; };
 struct DRes {
   std::string key;
@@ -126,6 +126,7 @@ struct DTaker {
 static void dplace(DTaker& t, DConv& c) {
   c.wpk = t.take(conv_packed_floats(c.cout, c.cin, c.taps));
   c.bias = t.take((size_t)(c.cout + 31) / 32 * 32);
+  if (c.taps == 9 && c.cout % 64 == 0 && c.cin % 8 == 0) c.wino = t.take(conv_wino_packed_floats(c.cout, c.cin));
 }
 static void dplace(DTaker& t, DNorm& n) { n.gamma = t.take(n.C); n.beta = t.take(n.C); }
 static void dplace(DTaker& t, DRes& r) {
@@ -282,6 +283,7 @@ static int dcopy(float* dst, const float* src, size_t n, hipStream_t s) {
 static int dpack(const DConv& c, const float* const* params, float* pk, hipStream_t s) {
   int rc = launch_pack_conv(params[c.w], pk + c.wpk, c.cout, c.cin, c.taps, 0, 0, s);
   if (rc) return rc;
+  if (c.wino != NONE && (rc = launch_pack_conv_wino(params[c.w], pk + c.wino, c.cout, c.cin, 0, s))) return rc;
   return dcopy(pk + c.bias, params[c.b], c.cout, s);
 }
 static int dpack(const DNorm& n, const float* const* params, float* pk, hipStream_t s) {
@@ -468,6 +470,7 @@ static void src_of(const DExec& E, ConvArgs& c, int xa, int xb) {
 }
 static void dst_of(DExec& E, ConvArgs& c, int out, const DConv& cv, const float* bias, bool stats) {
   c.wpk = E.pk + cv.wpk; c.bias = bias ? bias : E.pk + cv.bias;
+  c.wino = cv.wino != NONE ? E.pk + cv.wino : nullptr;
   c.out = E.ptr(out); c.Cout = cv.cout; c.B = E.B;
   if (stats && E.t[out].rc) { c.gsum = E.sums(out); c.gsum_rc = E.t[out].rc; c.gsum_tiles = &E.t[out].st; }
 }
@@ -497,7 +500,17 @@ static int res_block(DExec& E, const DRes& r, int xa, int xb, const float* bias_
   src_of(E, c2, h, -1);
   if ((rc = gn_into(E, r.n2, h, -1, c2, &tab))) return rc;
   dst_of(E, c2, y, r.c2, nullptr, true);
-  if (r.has_sc) {
+  int scid = -1;
+  if (r.has_sc && r.c2.wino != NONE && conv_wino_shape_ok(r.cout, r.cout, H, W)) {
+    // conv2 goes to the Winograd kernel, where a 1x1 projection cannot ride along: it runs as its own launch and enters
+    // conv2 as the residual
+    scid = E.act(r.cout, H, W, false);
+    ConvArgs cs{};
+    src_of(E, cs, xa, xb);
+    dst_of(E, cs, scid, r.sc, nullptr, false);
+    if ((rc = run_conv(E, cs, 1, scid))) return rc;
+    c2.res = E.ptr(scid); c2.res_mode = RS_NONE;
+  } else if (r.has_sc) {
     c2.sk_xa = E.ptr(xa); c2.sk_Ca = E.t[xa].C;
     c2.sk_xb = E.ptr(xb); c2.sk_Cb = xb >= 0 ? E.t[xb].C : 0;
     c2.sk_wpk = E.pk + r.sc.wpk; c2.sk_bias = E.pk + r.sc.bias;
@@ -507,6 +520,7 @@ static int res_block(DExec& E, const DRes& r, int xa, int xb, const float* bias_
   if ((rc = run_conv(E, c2, 9, y))) return rc;
   E.release(tab);
   E.release(h);
+  if (scid >= 0) E.release(scid);
   *out_id = y;
   return MCEDM_OK;
 }

@@ -92,8 +92,8 @@ static void place_conv(Taker& t, ConvP& c, bool dgrad) {
   c.bias = t.take((size_t)(c.cout + 31) / 32 * 32);
   if (dgrad) c.wpk_dgrad = t.take(conv_packed_floats(c.cin, c.cout, c.taps));
   if (c.taps == 9 && c.qkv_heads == 0) {       // Winograd tables where the kernel's channel constraints can be met
-    if (c.cout % 128 == 0 && c.cin % 8 == 0) c.wino = t.take(conv_wino_packed_floats(c.cout, c.cin));
-    if (dgrad && c.cin % 128 == 0 && c.cout % 8 == 0) c.wino_dgrad = t.take(conv_wino_packed_floats(c.cin, c.cout));
+    if (c.cout % 64 == 0 && c.cin % 8 == 0) c.wino = t.take(conv_wino_packed_floats(c.cout, c.cin));
+    if (dgrad && c.cin % 64 == 0 && c.cout % 8 == 0) c.wino_dgrad = t.take(conv_wino_packed_floats(c.cin, c.cout));
   }
 }
 static void place_norm(Taker& t, NormP& n) { n.gamma = t.take(n.C); n.beta = t.take(n.C); }

@@ -42,6 +42,9 @@ def coef_table(tag, B, C):
     (1, 8, 0, 128, 8, 16, 0, False, False),       # a single chunk, a single tile, no transform
     (1, 128, 128, 256, 16, 16, 1, True, True),    # two 128-channel output blocks, 32 chunks
     (3, 24, 0, 128, 24, 16, 0, True, False),      # odd chunk count
+    (2, 64, 0, 64, 16, 32, 1, True, True),        # 64 output channels: the 256-thread variant (the ch = 64 networks)
+    (1, 64, 64, 64, 24, 16, 1, True, False),      # ... with a channel concat
+    (1, 16, 0, 192, 8, 32, 0, True, True),        # 192 = 3 x 64 output channels
 ])
 def test_conv_wino_vs_oracle_and_direct(lib, B, Ca, Cb, Cout, H, W, act, use_coef, use_res):
     tag = f"wino/{B}{Ca}{Cb}{Cout}{H}{W}"
