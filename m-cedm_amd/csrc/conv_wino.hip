@@ -47,8 +47,8 @@ struct WinoCfg {
   static constexpr int TI = 4 / MB_;                    // patch rows (of the four) per thread in the input transform
   static constexpr int VBUF = SC * 16 * 288, RBUF = SC * WKC * 208;      // floats per stage (VPOS, RPLANE below)
   static constexpr int LDS_ROWS_OFF = 2 * VBUF + 2 * RBUF;              // transform rows start here (floats; 16-byte aligned)
-  static constexpr int XCH_FLOATS = NW * 32 * 64;                       // epilogue exchange: 32 registers x 64 lanes per wave
-  static constexpr int RED_FLOATS = 2 * (MT / 2) * 3;                   // statistics records of the two halves (pairs at most)
+  static constexpr int XCH_FLOATS = NW * 16 * 64;                       // epilogue exchange: one round of 16 registers x 64 lanes per wave
+  static constexpr int RED_FLOATS = 2 * (MT / 2) * 3 + MT;              // statistics records of the two halves (pairs at most) + the bias row
   static_assert(MB_ == 4 || MB_ == 2, "128 or 64 output channels per workgroup");
   static_assert(LDS_ROWS_OFF % 4 == 0, "LDS layout");
 };
@@ -96,40 +96,54 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(const ConvArgs p, int tiles_x, int tiles_img, int nch, int mblocks, int mode) {
+__global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(const ConvArgs p, int tiles_x, int tiles_img, int nch, int mblocks,
+                                                                          int per, int mode) {
   constexpr int WSC = C::SC, VBUF = C::VBUF, RBUF = C::RBUF, MB = C::MB;
   extern __shared__ float lds[];
+  const int Cin = p.Ca + p.Cb;
   float* const vbuf = lds;
   float* const rbuf = lds + 2 * VBUF;
   Coef* const cfl = reinterpret_cast<Coef*>(lds + C::LDS_ROWS_OFF);
+  float* const xch = lds + C::LDS_ROWS_OFF + 4 * Cin;            // epilogue exchange (one 16-register round), then the records
+  float* const red = xch + C::XCH_FLOATS;
+  float* const bias_l = red + 2 * (C::MT / 2) * 3;                // this workgroup's MT bias values
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mb = wave % MB, hf = wave / MB;
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
-  const int n = blockIdx.x / tiles_img, tile = blockIdx.x % tiles_img;
-  const int y0 = (tile / tiles_x) * WPH, x0 = (tile % tiles_x) * WPW;
+  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 4] = per; }
+  // A workgroup takes `per` consecutive pixel tiles of ONE sample (the launcher picks a divisor of the tiles per image) and
+  // runs their stages as one stream: the pipeline below never drains between tiles, only the accumulators are written out.
+  const int gt0 = blockIdx.x * per;
+  const int n = gt0 / tiles_img, tile0 = gt0 % tiles_img;
   const int m0 = blockIdx.y * C::MT;
-  const int Cin = p.Ca + p.Cb;
-  const size_t HW = (size_t)p.H * p.W;
+  const size_t HW = (size_t)p.H * p.W, HWs = (size_t)p.Hs * p.Ws;
+  const int nst = (nch + WSC - 1) / WSC;                           // stages per tile
+  const int G = per * nst;                                        // stages of this workgroup
 
-  // ---- raw staging geometry: wave w stages channel w of every chunk, lane elements lane, lane + 64, lane + 128 of 180
-  unsigned roff[RSUB], rkeep[RSUB];
+  // ---- raw staging: wave w stages channels w CPW .. of every chunk, lane elements lane, lane + 64, lane + 128 of the 180 of
+  // a channel's 10 x 18 patch.  Geometry (byte offsets, zero-padding masks) of the tile that is being LOADED; the masks of the
+  // tile whose registers are waiting to be COMMITTED are kept beside them (the two differ for one trip at a tile boundary).
+  unsigned roff[RSUB], rkeepL[RSUB], rkeepC[RSUB];
+  auto set_geom = [&](int tile) {
+    const int y0 = (tile / tiles_x) * WPH, x0 = (tile % tiles_x) * WPW;
 #pragma unroll
-  for (int i = 0; i < RSUB; ++i) {
-    const int e = lane + 64 * i;
-    const int r = e / RPITCH, c = e - r * RPITCH;
-    const int y = y0 - 1 + r, x = x0 - 1 + c;
-    const bool inb = e < RROWS * RPITCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-    rkeep[i] = inb ? 0xffffffffu : 0u;
-    // RS_UP: the conv input is the nearest-neighbour 2x up-sampling of the (activated) source (adm_blocks.py:69-73)
-    roff[i] = !inb ? 0u : p.resample == RS_UP ? 4u * (unsigned)((y >> 1) * p.Ws + (x >> 1)) : 4u * (unsigned)(y * p.W + x);
-  }
-  const size_t HWs = (size_t)p.Hs * p.Ws;
+    for (int i = 0; i < RSUB; ++i) {
+      const int e = lane + 64 * i;
+      const int r = e / RPITCH, c = e - r * RPITCH;
+      const int y = y0 - 1 + r, x = x0 - 1 + c;
+      const bool inb = e < RROWS * RPITCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      rkeepL[i] = inb ? 0xffffffffu : 0u;
+      // RS_UP: the conv input is the nearest-neighbour 2x up-sampling of the (activated) source (adm_blocks.py:69-73)
+      roff[i] = !inb ? 0u : p.resample == RS_UP ? 4u * (unsigned)((y >> 1) * p.Ws + (x >> 1)) : 4u * (unsigned)(y * p.W + x);
+    }
+  };
   float raw[WSC][C::CPW][RSUB];
-  auto raw_load1 = [&](int st, int sc) {
+  int ld_st = 0, ld_tile = tile0, cm_st = 0;                       // stage (within its tile) of the next load / commit
+  set_geom(tile0);
+  auto raw_load1 = [&](int sc) {
 #pragma unroll
     for (int cw = 0; cw < C::CPW; ++cw) {
-      const int ci = (st * WSC + sc) * WKC + wave * C::CPW + cw;
+      const int ci = (ld_st * WSC + sc) * WKC + wave * C::CPW + cw;
       const bool in_a = ci < p.Ca;
       const float* src = in_a ? p.xa : p.xb;
       const int cc = in_a ? ci : ci - p.Ca, CC = in_a ? p.Ca : p.Cb;
@@ -139,23 +153,29 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
       for (int i = 0; i < RSUB; ++i) raw[sc][cw][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
     }
   };
-  auto raw_commit1 = [&](int st, int sc, float* rb) {
+  auto raw_load = [&]() {                                          // the next stage of the stream
+#pragma unroll
+    for (int sc = 0; sc < WSC; ++sc) raw_load1(sc);
+#pragma unroll
+    for (int i = 0; i < RSUB; ++i) rkeepC[i] = rkeepL[i];          // these registers are committed one trip from now
+    if (++ld_st == nst) { ld_st = 0; ++ld_tile; set_geom(ld_tile < tiles_img ? ld_tile : tiles_img - 1); }
+  };
+  auto raw_commit1 = [&](int sc, float* rb) {
 #pragma unroll
     for (int cw = 0; cw < C::CPW; ++cw) {
-      const int kl = wave * C::CPW + cw, ci = (st * WSC + sc) * WKC + kl;
+      const int kl = wave * C::CPW + cw, ci = (cm_st * WSC + sc) * WKC + kl;
       const bool ok = ci < Cin && (ci < p.Ca ? p.xa : p.xb) != nullptr;
       const Coef cf = cfl[ci < Cin ? ci : Cin - 1];
       const unsigned ck = ok ? 0xffffffffu : 0u;
 #pragma unroll
       for (int i = 0; i < RSUB; ++i) {
         float v = apply_coef(raw[sc][cw][i], cf, p.act);
-        v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeep[i] & ck));
+        v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeepC[i] & ck));
         if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + kl) * RPLANE + lane + 64 * i] = v;
       }
     }
   };
-  auto raw_load = [&](int st) { for (int sc = 0; sc < WSC; ++sc) raw_load1(st, sc); };
-  auto raw_commit = [&](int st, float* rb) { for (int sc = 0; sc < WSC; ++sc) raw_commit1(st, sc, rb); };
+  auto commit_done = [&]() { if (++cm_st == nst) cm_st = 0; };
   // ---- input transform: thread = (channel k, patch (ty, tx), row half hf): V[xi][nu] for xi in {2 hf, 2 hf + 1}.
   // In two halves (LDS reads / arithmetic + LDS writes) per chunk of the stage, so that the K loop can spread them out.
   // patch rows ty = mb + MB ti, ti < TI
@@ -198,15 +218,15 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   auto transform_read = [&](const float* rb) { for (int sc = 0; sc < WSC; ++sc) transform_read1(sc, rb); };
   auto transform_finish = [&](float* vb) { for (int sc = 0; sc < WSC; ++sc) transform_finish1(sc, vb); };
 
-  // ---- prologue
-  const int nst = (nch + WSC - 1) / WSC;
+  // ---- prologue (once per workgroup): transform rows of the sample, stages 0 .. 2 of the stream
   stage_coef_rows<C::NT>(p, n, cfl, tid);
-  raw_load(0);
+  if (tid < C::MT) bias_l[tid] = p.bias ? p.bias[m0 + tid] : 0.f;
+  raw_load();
   __syncthreads();
-  raw_commit(0, rbuf);
-  if (nst > 1) raw_load(1);
-  if (nst > 1) raw_commit(1, rbuf + RBUF);
-  if (nst > 2) raw_load(2);                                          // stays in registers until trip 0 commits it
+  for (int sc = 0; sc < WSC; ++sc) raw_commit1(sc, rbuf);
+  commit_done();
+  if (G > 1) { raw_load(); for (int sc = 0; sc < WSC; ++sc) raw_commit1(sc, rbuf + RBUF); commit_done(); }
+  if (G > 2) raw_load();                                             // stays in registers until trip 0 commits it
   // this wave's transformed weights: 8 positions x one 16-byte load per chunk
   const size_t ustride = (size_t)mblocks * 16 * 64;                  // f32x4 per chunk
   const f32x4* up = reinterpret_cast<const f32x4*>(p.wino) + ((size_t)(m0 / 32 + mb) * 16 + 8 * hf) * 64 + lane;
@@ -216,17 +236,26 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   __syncthreads();
   transform_read(rbuf);
   transform_finish(vbuf);
+  // Accumulators start at zero, except Winograd position (xi, nu) = (1, 1) -- block 5 of the hf = 0 waves --, which starts at
+  // the bias: A^T has ones in column 1 of both rows, so a constant there comes out as that constant in all four pixels.
   f32x16 acc[8];
+  auto init_acc = [&]() {
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < 8; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    if (hf == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[5][r] = bias_l[32 * mb + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2)];
+    }
+  };
   __syncthreads();
+  init_acc();
 
-  // ---- K loop: one trip = one stage of WSC chunks
+  // ---- the stream of stages: one trip = one stage of WSC chunks
   const int vrd = (8 * hf) * VPOS + (lane >> 5) * VH1 + (lane & 31) * 4;
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime(); }
-#ifdef MCEDM_WINO_TIMELINE      // cycle sums of waves 0 and 4 (lane 0): trip top, MFMA stream, barrier -> dbg[8..12] / dbg[13..15, 7] (diagnostic builds only)
+#ifdef MCEDM_WINO_TIMELINE      // cycle sums of waves 0 and MB (lane 0): MFMA stream, barrier, epilogue -> dbg[8..12] / dbg[13..15, 7] (diagnostic builds only)
   unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #define WINO_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; }
   const bool no_u = mode & 2, no_t = mode & 4, no_r = mode & 8;   // drop the weight reloads / the transform / the raw tile path (wrong results)
@@ -234,37 +263,39 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
 #define WINO_STAMP(i)
   constexpr bool no_u = false, no_t = false, no_r = false;
 #endif
-  // One trip = one stage: 2 x 4 slots of [two B-fragment reads for the next slot | eight MFMAs | two weight reloads] and,
-  // behind each slot's MFMAs, one slice of the side work that prepares later stages -- the transform of stage st + 1 (LDS
-  // reads in slot 0, arithmetic + LDS writes in slots 4 / 5), the commit of the raw tile of stage st + 2 (slots 1 / 2; its
-  // global loads were issued a trip ago) and the loads of stage st + 3 (slot 3).  Sliced like this the side work costs its
-  // issue cycles; as a phase of its own (before or after the MFMAs, or ping-ponged between the two waves of a SIMD) it
-  // cost its latencies: 2400 cycles per chunk and wave against 2048 of MFMAs.  Every slice touches buffers no MFMA of this
-  // trip reads, so one barrier per trip is enough.
-  auto side_slice = [&](int slot, int st, int cur) {
-    const bool more = st + 1 < nst && !no_t, c2 = st + 2 < nst && !no_r, l3 = st + 3 < nst && !no_r;
-    if (WSC == 2) {
-      if (slot == 0 && more) transform_read(rbuf + (cur ^ 1) * RBUF);
-      if (slot == 1 && c2) raw_commit1(st + 2, 0, rbuf + cur * RBUF);
-      if (slot == 2 && c2) raw_commit1(st + 2, 1, rbuf + cur * RBUF);
-      if (slot == 3 && l3) raw_load(st + 3);
-      if (slot == 4 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
+  // One trip = one stage: WSC x 4 slots of [two B-fragment reads for the next slot | eight MFMAs | two weight reloads] and,
+  // behind each slot's MFMAs, one slice of the side work that prepares later stages -- the transform of stage g + 1 (LDS
+  // reads in slots 0 / 3, arithmetic + LDS writes in slots 2 / 5), the commit of the raw tile of stage g + 2 (slots 1 / 4; its
+  // global loads were issued a trip ago) and the loads of stage g + 3 (slot 6); stages past the end of a tile are the first
+  // stages of the workgroup's next tile.  Sliced like this the side work costs its issue cycles; as a phase of its own
+  // (before or after the MFMAs, or ping-ponged between the two waves of a SIMD) it cost its latencies: 2400 cycles per chunk
+  // and wave against 2048 of MFMAs.  Every slice touches buffers no MFMA of this trip reads: one barrier per trip.
+  auto side_slice = [&](int slot, int g, int cur) {
+    const bool more = g + 1 < G && !no_t, c2 = g + 2 < G && !no_r, l3 = g + 3 < G && !no_r;
+    if (WSC == 2) {        // the two chunks' transforms one after the other: their 12 + 12 staging registers are never live together
+      if (slot == 0 && more) transform_read1(0, rbuf + (cur ^ 1) * RBUF);
+      if (slot == 1 && c2) raw_commit1(0, rbuf + cur * RBUF);
+      if (slot == 2 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
+      if (slot == 3 && more) transform_read1(WSC - 1, rbuf + (cur ^ 1) * RBUF);
+      if (slot == 4 && c2) { raw_commit1(WSC - 1, rbuf + cur * RBUF); commit_done(); }
       if (slot == 5 && more) transform_finish1(WSC - 1, vbuf + (cur ^ 1) * VBUF);
+      if (slot == 6 && l3) raw_load();
     } else {
       if (slot == 0 && more) transform_read(rbuf + (cur ^ 1) * RBUF);
-      if (slot == 1 && c2) raw_commit1(st + 2, 0, rbuf + cur * RBUF);
-      if (slot == 2 && l3) raw_load(st + 3);
+      if (slot == 1 && c2) { raw_commit1(0, rbuf + cur * RBUF); commit_done(); }
+      if (slot == 2 && l3) raw_load();
       if (slot == 3 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
     }
   };
   (void)mode;
-  for (int st = 0; st < nst; ++st) {
-    const int cur = st & 1;
+  int st = 0, tile = tile0;                                        // stage within the tile, tile of the accumulators
+  for (int g = 0; g < G; ++g) {
+    const int cur = g & 1;
     WINO_STAMP(0)
 #pragma unroll
     for (int sc = 0; sc < WSC; ++sc) {
       const int c = st * WSC + sc;
-      const f32x4* un = up + (size_t)(c + 1 < nch ? c + 1 : nch - 1) * ustride;
+      const f32x4* un = up + (size_t)(c + 1 < nch ? c + 1 : 0) * ustride;      // after a tile's last chunk: chunk 0 again
       const float* vb = vbuf + cur * VBUF + sc * 16 * VPOS + vrd;
       f32x4 b4[2][2];                                      // B fragments of two positions, one pair ahead of the MFMAs
       b4[0][0] = *reinterpret_cast<const f32x4*>(vb);
@@ -294,117 +325,137 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         __builtin_amdgcn_sched_barrier(0);
-        side_slice(sc * 4 + qp, st, cur);
+        side_slice(sc * 4 + qp, g, cur);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    WINO_STAMP(2)
+    WINO_STAMP(1)
     __syncthreads();
-    WINO_STAMP(4)
-  }
+    WINO_STAMP(2)
+    if (++st < nst) continue;
+    st = 0;
 
-  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime(); }
-#ifdef MCEDM_WINO_TIMELINE
-  if (p.dbg && tid == 0) for (int i = 0; i < 5; ++i) p.dbg[blockIdx.x * 16 + 8 + i] = ph[i];
-  if (p.dbg && tid == 256) { p.dbg[blockIdx.x * 16 + 13] = ph[1]; p.dbg[blockIdx.x * 16 + 14] = ph[2]; p.dbg[blockIdx.x * 16 + 15] = ph[3]; p.dbg[blockIdx.x * 16 + 7] = ph[4]; }
-#endif
-  // ---- output transform.  A^T = [[1,1,1,0],[0,1,-1,-1]].  Over nu (register-local), then over xi across the two halves:
-  // row 0 of the patch = T0 + T1 + T2, row 1 = T1 - T2 - T3 with T_xi the nu-reduced blocks; half 0 holds T0, T1, half 1 T2, T3.
-  const int pt = lane & 31;                             // this wave stores row hf of every patch: pixels
-  const int oy = y0 + 2 * (pt >> 3) + hf, ox = x0 + 2 * (pt & 7);   // (y0 + 2 ty + hf, x0 + 2 tx + {0, 1}), patch = lane & 31
-  const int cbase = m0 + 32 * mb + 4 * (lane >> 5);
-  const size_t obase = ((size_t)n * p.Cout + cbase) * HW + (size_t)oy * p.W + ox;
-  float2 rv[16];                                        // residual and bias: in flight during the transform and the exchange
-  float bv[16];
+    // ---- a tile is complete: output transform, bias, residual, stores, statistics; then the accumulators start over.
+    // (The stream's LDS buffers already hold the first stages of the next tile: the exchange area is a region of its own.)
+    const int y0 = (tile / tiles_x) * WPH, x0 = (tile % tiles_x) * WPW;
+    const int pt = lane & 31;                             // this wave stores row hf of every patch: pixels
+    const int oy = y0 + 2 * (pt >> 3) + hf, ox = x0 + 2 * (pt & 7);   // (y0 + 2 ty + hf, x0 + 2 tx + {0, 1}), patch = lane & 31
+    const int cbase = m0 + 32 * mb + 4 * (lane >> 5);
+    // buffer addressing for the tile's 16 + 16 + 16 memory operations: one descriptor per tensor (this sample's planes) in
+    // SGPRs, one 32-bit lane offset, the channel step in the scalar offset -- no 64-bit address pair per operation
+    const size_t splane = (size_t)p.Cout * HW;                      // this sample's output planes (the launcher checks < 4 GiB)
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out + (size_t)n * splane, 4u * (unsigned)splane);
+    const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.res ? p.res + (size_t)n * (p.res_mode == RS_UP ? splane >> 2 : splane) : nullptr,
+                                                    p.res ? 4u * (unsigned)(p.res_mode == RS_UP ? splane >> 2 : splane) : 0u);
+    const unsigned HWu = (unsigned)HW;
+    const unsigned voff = 4u * ((unsigned)cbase * HWu + (unsigned)oy * p.W + ox);
+    const unsigned rvoff = 4u * ((unsigned)cbase * (HWu >> 2) + (unsigned)(oy >> 1) * (p.W >> 1) + (ox >> 1));
+    // A^T = [[1,1,1,0],[0,1,-1,-1]].  Over nu (register-local), then over xi across the two halves: row 0 of the patch =
+    // T0 + T1 + T2, row 1 = T1 - T2 - T3 with T_xi the nu-reduced blocks; half 0 holds T0, T1, half 1 T2, T3.
+    float2 rv[16];                                        // residual: in flight during the rest of the transform and the exchange
+    f32x16 keep[2], send[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int dr = (r & 3) + 8 * (r >> 2);
-    if (p.res && p.res_mode == RS_UP) {                  // residual at half resolution: both pixels of the pair share a source
-      const float q = p.res[((size_t)n * p.Cout + cbase + dr) * (HW >> 2) + (size_t)(oy >> 1) * (p.W >> 1) + (ox >> 1)];
-      rv[r] = make_float2(q, q);
-    } else {
-      rv[r] = p.res ? *reinterpret_cast<const float2*>(p.res + obase + (size_t)dr * HW) : make_float2(0.f, 0.f);
+    for (int j = 0; j < 2; ++j) {                          // one pixel column at a time: fewer values live beside the accumulators
+      const f32x16 t0 = j == 0 ? acc[0] + acc[1] + acc[2] : acc[1] - acc[2] - acc[3];
+      const f32x16 t1 = j == 0 ? acc[4] + acc[5] + acc[6] : acc[5] - acc[6] - acc[7];
+      if (hf == 0) { keep[j] = t0 + t1; send[j] = t1; }
+      else         { keep[j] = -t0 - t1; send[j] = t0; }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    bv[r] = p.bias ? p.bias[cbase + dr] : 0.f;
-  }
-  f32x16 keep[2], send[2];
-  {
-    f32x16 t[2][2];
+    // chunk 0's weights for the next tile are fetched here (the stream's reload at the tile's last chunk brought them too, but
+    // re-assigning them here ends that copy's life at the last MFMA: 32 registers free while the accumulators are transformed)
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      t[x][0] = acc[4 * x + 0] + acc[4 * x + 1] + acc[4 * x + 2];
-      t[x][1] = acc[4 * x + 1] - acc[4 * x + 2] - acc[4 * x + 3];
-    }
+    for (int q = 0; q < 8; ++q) ua[q] = up[q * 64];
+    __builtin_amdgcn_sched_barrier(0);                    // the accumulators are dead from here to the end of the epilogue
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (hf == 0) { keep[j] = t[0][j] + t[1][j]; send[j] = t[1][j]; }
-      else         { keep[j] = -t[0][j] - t[1][j]; send[j] = t[0][j]; }
-    }
-  }
-  float* xch = lds;                                     // every LDS reader of the K loop is past the last barrier
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xch[(wave * 32 + j * 16 + r) * 64 + lane] = send[j][r];
-  __syncthreads();
-  const int pw = wave ^ MB;
-  float v0[16], v1[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    v0[r] = keep[0][r] + xch[(pw * 32 + r) * 64 + lane] + bv[r] + rv[r].x;
-    v1[r] = keep[1][r] + xch[(pw * 32 + 16 + r) * 64 + lane] + bv[r] + rv[r].y;
-    *reinterpret_cast<float2*>(p.out + obase + (size_t)((r & 3) + 8 * (r >> 2)) * HW) = make_float2(v0[r], v1[r]);
-  }
-  if (p.gsum) {
-    // fused GroupNorm statistics of what was stored (conv_tile.hpp conv_epilogue): one record per 4-channel block =
-    // registers 4 g .. 4 g + 3 of the 32 lanes that share lane >> 5 (or per 2-channel block, gsum_rc == 2: their two
-    // halves); this wave holds one pixel row of every patch, its partner wave the other: (count, sum, M2 about the wave's
-    // own mean) per wave, merged in a fixed order by conv_stats_store.
-    float* red = lds + C::XCH_FLOATS;
-    const bool pairs = p.gsum_rc == 2;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float a[2], b[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        a[e] = (v0[4 * g + 2 * e] + v1[4 * g + 2 * e]) + (v0[4 * g + 2 * e + 1] + v1[4 * g + 2 * e + 1]);
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) a[e] += __shfl_xor(a[e], off);
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      if (p.res && p.res_mode == RS_UP) {                  // residual at half resolution: both pixels of the pair share a source
+        const float q = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, rvoff, 4u * (unsigned)dr * (HWu >> 2), 0));
+        rv[r] = make_float2(q, q);
+      } else {                                             // no residual: a zero-sized descriptor reads zeros
+        rv[r] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff, 4u * (unsigned)dr * HWu, 0));
       }
-      const float cnt = pairs ? 128.f : 256.f;
-      const float mean0 = pairs ? a[0] * (1.0f / 128.0f) : (a[0] + a[1]) * (1.0f / 256.0f);
-      const float mean1 = pairs ? a[1] * (1.0f / 128.0f) : mean0;
+    }
+    const int pw = wave ^ MB;
+    float v0[16], v1[16];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float mean = e ? mean1 : mean0;
-        float q = 0.f;
+    for (int j = 0; j < 2; ++j) {                         // two rounds of 16 registers through the exchange area
 #pragma unroll
-        for (int r = 4 * g + 2 * e; r < 4 * g + 2 * e + 2; ++r) { const float d0 = v0[r] - mean, d1 = v1[r] - mean; q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); }
+      for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = send[j][r];
+      __syncthreads();
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off);
-        b[e] = q;
+      for (int r = 0; r < 16; ++r) {
+        const float got = xch[(pw * 16 + r) * 64 + lane];
+        if (j == 0) v0[r] = keep[0][r] + got + rv[r].x;
+        else        v1[r] = keep[1][r] + got + rv[r].y;
       }
-      if ((lane & 31) == 0) {
-        const int quad = 8 * mb + 2 * g + (lane >> 5);
-        if (pairs) {
+      if (j == 0) __syncthreads();
+    }
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            float* slot = red + (hf * (C::MT / 2) + 2 * quad + e) * 3;
-            slot[0] = cnt; slot[1] = a[e]; slot[2] = b[e];
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, make_float2(v0[r], v1[r])), rs_out, voff,
+                                            4u * (unsigned)((r & 3) + 8 * (r >> 2)) * HWu, 0);
+    if (p.gsum) {
+      // fused GroupNorm statistics of what was stored (conv_tile.hpp conv_epilogue): one record per 4-channel block =
+      // registers 4 g .. 4 g + 3 of the 32 lanes that share lane >> 5 (or per 2-channel block, gsum_rc == 2: their two
+      // halves); this wave holds one pixel row of every patch, its partner wave the other: (count, sum, M2 about the wave's
+      // own mean) per wave, merged in a fixed order by conv_stats_store.
+      const bool pairs = p.gsum_rc == 2;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float a[2], b[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          a[e] = (v0[4 * gq + 2 * e] + v1[4 * gq + 2 * e]) + (v0[4 * gq + 2 * e + 1] + v1[4 * gq + 2 * e + 1]);
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) a[e] += __shfl_xor(a[e], off);
+        }
+        const float cnt = pairs ? 128.f : 256.f;
+        const float mean0 = pairs ? a[0] * (1.0f / 128.0f) : (a[0] + a[1]) * (1.0f / 256.0f);
+        const float mean1 = pairs ? a[1] * (1.0f / 128.0f) : mean0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float mean = e ? mean1 : mean0;
+          float q = 0.f;
+#pragma unroll
+          for (int r = 4 * gq + 2 * e; r < 4 * gq + 2 * e + 2; ++r) { const float d0 = v0[r] - mean, d1 = v1[r] - mean; q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); }
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off);
+          b[e] = q;
+        }
+        if ((lane & 31) == 0) {
+          const int quad = 8 * mb + 2 * gq + (lane >> 5);
+          if (pairs) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float* slot = red + (hf * (C::MT / 2) + 2 * quad + e) * 3;
+              slot[0] = cnt; slot[1] = a[e]; slot[2] = b[e];
+            }
+          } else {
+            float* slot = red + (hf * (C::MT / 4) + quad) * 3;
+            slot[0] = cnt; slot[1] = a[0] + a[1]; slot[2] = b[0] + b[1];
           }
-        } else {
-          float* slot = red + (hf * (C::MT / 4) + quad) * 3;
-          slot[0] = cnt; slot[1] = a[0] + a[1]; slot[2] = b[0] + b[1];
         }
       }
+      __syncthreads();
+      conv_stats_store<C, 2>(p, red, n, m0, tile, tiles_img, tid);
+      // the next epilogue writes `red` only after a whole tile of barriers
     }
-    __syncthreads();
-    conv_stats_store<C, 2>(p, red, n, m0, tile, tiles_img, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    init_acc();
+    ++tile;
+    WINO_STAMP(3)
   }
   if (p.dbg && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p.dbg[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime();
     p.dbg[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memrealtime();
   }
+#ifdef MCEDM_WINO_TIMELINE
+  if (p.dbg && tid == 0) for (int i = 0; i < 5; ++i) p.dbg[blockIdx.x * 16 + 8 + i] = ph[i];
+  if (p.dbg && tid == 64 * MB) { p.dbg[blockIdx.x * 16 + 13] = ph[1]; p.dbg[blockIdx.x * 16 + 14] = ph[2]; p.dbg[blockIdx.x * 16 + 15] = ph[3]; p.dbg[blockIdx.x * 16 + 7] = ph[0]; }
+#endif
 }
 
 static int wino_env() {                                        // MCEDM_WINOGRAD=0: never take this kernel
@@ -441,32 +492,53 @@ bool conv_wino_applicable(const ConvArgs& a, int taps) {
          (!a.res || a.res_mode == RS_NONE || a.res_mode == RS_UP) && (a.Ca + a.Cb) <= 1024;
 }
 
+// Tiles per workgroup: a divisor d of the tiles per image (a workgroup stays inside one sample: one set of transform rows),
+// chosen for the shortest schedule on `slots` concurrent workgroups -- rounds x (d tiles + the un-overlapped start and end
+// of a workgroup, about a fifth of a tile).  A function of the shape and the chip only: results never depend on it.
+static int wino_tiles_per_wg(long long total, int tiles_img, int slots) {
+  int best = 1;
+  double best_t = 1e30;
+  for (int d = 1; d <= tiles_img; ++d) {
+    if (tiles_img % d) continue;
+    const long long wgs = total / d;
+    const double t = (double)((wgs + slots - 1) / slots) * (d + 0.2);
+    if (t < best_t - 1e-9 || (t < best_t + 1e-9 && d > best)) { best_t = t; best = d; }
+  }
+  return best;
+}
+
 template <class C>
 static int launch_wino_cfg(const ConvArgs& a, hipStream_t stream) {
   const int tiles_x = a.W / WPW, tiles_img = tiles_x * (a.H / WPH);
-  const long long blocks = (long long)a.B * tiles_img;
-  MCEDM_REQUIRE(blocks > 0 && blocks <= 0x7fffffffLL, "conv_wino: grid out of range");
+  const long long total = (long long)a.B * tiles_img;
+  MCEDM_REQUIRE(total > 0 && total <= 0x7fffffffLL, "conv_wino: grid out of range");
   const int Cin = a.Ca + a.Cb, nch = Cin / WKC;
-  const int lds_rows = C::LDS_ROWS_OFF * 4 + Cin * (int)sizeof(Coef);
-  const int lds_xch = (C::XCH_FLOATS + C::RED_FLOATS) * 4;       // exchange area + the statistics records of the two halves
-  const int lds_bytes = lds_rows > lds_xch ? lds_rows : lds_xch;
+  const int lds_bytes = (C::LDS_ROWS_OFF + 4 * Cin + C::XCH_FLOATS + C::RED_FLOATS) * 4;
   MCEDM_REQUIRE(lds_bytes <= 160 * 1024 / (C::MB == 4 ? 1 : 2), "conv_wino: %d input channels exceed the LDS row table", Cin);
   static std::atomic<bool> attr_set[64];
+  static std::atomic<int> ncu[64];
   int dev = 0;
   MCEDM_HIP_TRY(hipGetDevice(&dev));
   MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
   if (!attr_set[dev].load(std::memory_order_acquire)) {
+    int n_cu = 0;
+    MCEDM_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    ncu[dev].store(n_cu > 0 ? n_cu : 256, std::memory_order_release);
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[dev].store(true, std::memory_order_release);
   }
+  static int per_env = -1;                                 // MCEDM_WINO_PER: force the tiles per workgroup (A/B runs; must divide)
+  if (per_env < 0) { const char* e = getenv("MCEDM_WINO_PER"); per_env = e ? atoi(e) : 0; }
+  int per = wino_tiles_per_wg(total, tiles_img, ncu[dev].load(std::memory_order_acquire) * (C::MB == 4 ? 1 : 2));
+  if (per_env > 0 && tiles_img % per_env == 0) per = per_env;
   char name[64] = "";
   if (prof_enabled()) snprintf(name, sizeof(name), "conv_wino_kernel<WinoCfg<%d> >", C::MB);      // = rocprofv3's name
   const double px = (double)a.B * a.H * a.W;
   // algorithmic cost = the direct convolution's (2 * MAC); the kernel issues 4 / 9 of these as matrix flops
   ProfScope ps(name, 2.0 * px * a.Cout * (double)Cin * 9,
                4.0 * ((double)a.B * Cin * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * Cin * 9), stream);
-  hipLaunchKernelGGL(conv_wino_kernel<C>, dim3((unsigned)blocks, a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x, tiles_img,
-                     nch, cout_padded(a.Cout) / 32, wino_mode_env());
+  hipLaunchKernelGGL(conv_wino_kernel<C>, dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,
+                     tiles_img, nch, cout_padded(a.Cout) / 32, per, wino_mode_env());
   MCEDM_LAUNCH_CHECK("conv_wino_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_img, tiles_x, WPH, WPW, a.gsum_rc == 2 ? 2 : 4};
   return MCEDM_OK;
@@ -478,7 +550,7 @@ int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
   MCEDM_REQUIRE(conv_wino_applicable(a, 9), "conv_wino: shape not served by the Winograd kernel");
   MCEDM_REQUIRE(a.out && a.B > 0 && (a.resample == RS_UP ? (a.Hs * 2 == a.H && a.Ws * 2 == a.W) : (a.Hs == a.H && a.Ws == a.W)),
                 "conv_wino: bad arguments");
-  MCEDM_REQUIRE((unsigned long long)a.H * a.W * 4ull < (1ull << 32), "conv_wino: plane exceeds the 4 GiB offset range");
+  MCEDM_REQUIRE((unsigned long long)a.H * a.W * 4ull * a.Cout < (1ull << 32), "conv_wino: one sample of the output exceeds the 4 GiB buffer range");
   { const int rc = conv_resolve_identity(a); if (rc != MCEDM_OK) return rc; }
   // 128 output channels per workgroup where they divide (fewer passes over the input), else 64
   return a.Cout % 128 == 0 ? launch_wino_cfg<WinoCfg<4>>(a, stream) : launch_wino_cfg<WinoCfg<2>>(a, stream);

@@ -33,15 +33,16 @@ run()
 torch.cuda.synchronize()
 l.mcedm_op_set_conv_debug(None)
 d = dbg.cpu().numpy().reshape(nb, 16)
+d = d[d[:, 0] != 0]
+per = int(d[0, 4])
 t0 = d[:, 0].min()
 st, pro, loop, end = [(d[:, i] - t0) / 100.0 for i in range(4)]
 flops = 2.0 * B * hw * hw * cout * cin * 9
-cyc = np.median(d[:, 6] - d[:, 5])
+cyc = np.median(d[:, 6] - d[:, 5]) / per
 clk = np.median((d[:, 6] - d[:, 5]) / ((d[:, 2] - d[:, 1]) * 10e-9) / 1e9)
 nch = cin // 8
-print(f"mode {os.environ.get('MCEDM_WINO_MODE', 'default')} B={B} {cin}->{cout} {hw}x{hw}: {us:.1f} us/launch ({flops / us / 1e6:.1f} algorithmic TFLOP/s), {nb} workgroups, "
-      f"span {end.max():.1f} us | prologue {np.mean(pro - st):.2f} | K loop {np.mean(loop - pro):.2f} | epilogue {np.mean(end - loop):.2f} us per workgroup")
-print(f"   K loop {cyc:.0f} cycles = {cyc / nch:.0f} per chunk (matrix floor 4096 per chunk and SIMD), clock {clk:.2f} GHz")
+print(f"B={B} {cin}->{cout} {hw}x{hw}: {us:.1f} us/launch ({flops / us / 1e6:.1f} algorithmic TFLOP/s), {len(d)} workgroups x {per} tiles, "
+      f"span {end.max():.1f} us | prologue {np.mean(pro - st):.2f} us | {np.mean(loop - pro) / per:.2f} us per tile (K loop + epilogue)")
+print(f"   {cyc:.0f} cycles per tile = {cyc / nch:.0f} per chunk incl. the epilogue (matrix floor 4096 per chunk and SIMD), clock {clk:.2f} GHz")
 if d[:, 8:13].max() > 0:
-    print("   wave 0 cycles per chunk: " + "  ".join(f"{nm} {np.mean(d[:, 8 + j]) / nch:.0f}" for j, nm in enumerate(["load-issue", "transform(early)", "mfma-issue", "transform(late)+commit", "barrier"])))
-    print("   wave 4 cycles per chunk: " + "  ".join(f"{nm} {np.mean(d[:, j]) / nch:.0f}" for nm, j in [("transform(early)", 13), ("mfma-issue", 14), ("transform(late)+commit", 15), ("barrier", 7)]))
+    print("   wave 0 cycles per chunk: " + "  ".join(f"{nm} {np.mean(d[:, 8 + j]) / nch / per:.0f}" for j, nm in enumerate(["top", "mfma stream", "barrier", "epilogue"])))
