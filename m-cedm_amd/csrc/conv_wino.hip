@@ -95,7 +95,8 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
   }
 }
 
-template <class C>
+// UP: the conv input is the nearest-neighbour 2x up-sampling of the (activated) source (adm_blocks.py:69-73)
+template <class C, bool UP>
 __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(const ConvArgs p, int tiles_x, int tiles_img, int nch, int mblocks,
                                                                           int per, int mode) {
   constexpr int WSC = C::SC, VBUF = C::VBUF, RBUF = C::RBUF, MB = C::MB;
@@ -120,24 +121,44 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   const int nst = (nch + WSC - 1) / WSC;                           // stages per tile
   const int G = per * nst;                                        // stages of this workgroup
 
-  // ---- raw staging: wave w stages channels w CPW .. of every chunk, lane elements lane, lane + 64, lane + 128 of the 180 of
-  // a channel's 10 x 18 patch.  Geometry (byte offsets, zero-padding masks) of the tile that is being LOADED; the masks of the
-  // tile whose registers are waiting to be COMMITTED are kept beside them (the two differ for one trip at a tile boundary).
-  unsigned roff[RSUB], rkeepL[RSUB], rkeepC[RSUB];
+  // ---- raw staging: wave w stages channels w CPW .. of every chunk: a channel's 10 x 18 patch (tile + halo).
+  //   plain input: ONE 16-byte load per lane and channel -- lane = (patch row r = lane / 6, aligned quad lane % 6 of the 24
+  //   columns x0 - 4 .. x0 + 19): vector-memory instructions are the expensive thing in this loop (~60 cycles of issue
+  //   each), and the 6 columns fetched beyond the patch cost two extra SiLU evaluations per lane instead;
+  //   up-sampled input: elements lane, lane + 64, lane + 128 of the 180, one dword load each (source pixel (y/2, x/2)).
+  // Geometry (byte offsets, zero-padding masks) of the tile that is being LOADED; the masks of the tile whose registers are
+  // waiting to be COMMITTED are kept beside them (the two differ for one trip at a tile boundary).
+  constexpr int NR = UP ? RSUB : 4, NG = UP ? RSUB : 1;             // raw registers / geometry entries per lane and channel
+  unsigned roff[NG], rkeepL[NG], rkeepC[NG];
+  int lofs[4];                                                      // plain input: where the quad's four elements go in the LDS patch
+  if (!UP) {
+    const int r = lane / 6, qd = lane % 6;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = 4 * qd + e - 3;                              // column inside the 18-wide patch; -3 .. -1 and 18 .. 20 are not part of it
+      lofs[e] = (lane < 60 && col >= 0 && col < RPITCH) ? r * RPITCH + col : RROWS * RPITCH + lane % (RPLANE - RROWS * RPITCH);
+    }
+  }
   auto set_geom = [&](int tile) {
     const int y0 = (tile / tiles_x) * WPH, x0 = (tile % tiles_x) * WPW;
+    if (UP) {
 #pragma unroll
-    for (int i = 0; i < RSUB; ++i) {
-      const int e = lane + 64 * i;
-      const int r = e / RPITCH, c = e - r * RPITCH;
-      const int y = y0 - 1 + r, x = x0 - 1 + c;
-      const bool inb = e < RROWS * RPITCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      rkeepL[i] = inb ? 0xffffffffu : 0u;
-      // RS_UP: the conv input is the nearest-neighbour 2x up-sampling of the (activated) source (adm_blocks.py:69-73)
-      roff[i] = !inb ? 0u : p.resample == RS_UP ? 4u * (unsigned)((y >> 1) * p.Ws + (x >> 1)) : 4u * (unsigned)(y * p.W + x);
+      for (int i = 0; i < NG; ++i) {
+        const int e = lane + 64 * i;
+        const int r = e / RPITCH, c = e - r * RPITCH;
+        const int y = y0 - 1 + r, x = x0 - 1 + c;
+        const bool inb = e < RROWS * RPITCH && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        rkeepL[i] = inb ? 0xffffffffu : 0u;
+        roff[i] = !inb ? 0u : 4u * (unsigned)((y >> 1) * p.Ws + (x >> 1));
+      }
+    } else {       // W % 16 == 0 and x0 % 16 == 0: a quad lies wholly inside or wholly outside the image, and is 16-byte aligned
+      const int y = y0 - 1 + lane / 6, x = x0 - 4 + 4 * (lane % 6);
+      const bool inb = lane < 60 && (unsigned)y < (unsigned)p.H && x >= 0 && x < p.W;
+      rkeepL[0] = inb ? 0xffffffffu : 0u;
+      roff[0] = inb ? 4u * (unsigned)(y * p.W + x) : 0u;
     }
   };
-  float raw[WSC][C::CPW][RSUB];
+  float raw[WSC][C::CPW][NR];
   int ld_st = 0, ld_tile = tile0, cm_st = 0;                       // stage (within its tile) of the next load / commit
   set_geom(tile0);
   auto raw_load1 = [&](int sc) {
@@ -149,15 +170,21 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
       const int cc = in_a ? ci : ci - p.Ca, CC = in_a ? p.Ca : p.Cb;
       const bool ok = ci < Cin && src != nullptr;
       const float* plane = ok ? src + ((size_t)n * CC + cc) * HWs : (p.xa ? p.xa : p.xb);
+      if (UP) {
 #pragma unroll
-      for (int i = 0; i < RSUB; ++i) raw[sc][cw][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
+        for (int i = 0; i < NG; ++i) raw[sc][cw][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + roff[i]);
+      } else {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(plane) + roff[0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) raw[sc][cw][e] = q[e];
+      }
     }
   };
   auto raw_load = [&]() {                                          // the next stage of the stream
 #pragma unroll
     for (int sc = 0; sc < WSC; ++sc) raw_load1(sc);
 #pragma unroll
-    for (int i = 0; i < RSUB; ++i) rkeepC[i] = rkeepL[i];          // these registers are committed one trip from now
+    for (int i = 0; i < NG; ++i) rkeepC[i] = rkeepL[i];            // these registers are committed one trip from now
     if (++ld_st == nst) { ld_st = 0; ++ld_tile; set_geom(ld_tile < tiles_img ? ld_tile : tiles_img - 1); }
   };
   auto raw_commit1 = [&](int sc, float* rb) {
@@ -168,10 +195,11 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
       const Coef cf = cfl[ci < Cin ? ci : Cin - 1];
       const unsigned ck = ok ? 0xffffffffu : 0u;
 #pragma unroll
-      for (int i = 0; i < RSUB; ++i) {
+      for (int i = 0; i < NR; ++i) {
         float v = apply_coef(raw[sc][cw][i], cf, p.act);
-        v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeepC[i] & ck));
-        if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + kl) * RPLANE + lane + 64 * i] = v;
+        v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeepC[UP ? i : 0] & ck));
+        if (UP) { if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + kl) * RPLANE + lane + 64 * i] = v; }
+        else rb[(sc * WKC + kl) * RPLANE + lofs[i]] = v;
       }
     }
   };
@@ -524,7 +552,8 @@ static int launch_wino_cfg(const ConvArgs& a, hipStream_t stream) {
     int n_cu = 0;
     MCEDM_HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     ncu[dev].store(n_cu > 0 ? n_cu : 256, std::memory_order_release);
-    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[dev].store(true, std::memory_order_release);
   }
   static int per_env = -1;                                 // MCEDM_WINO_PER: force the tiles per workgroup (A/B runs; must divide)
@@ -532,13 +561,17 @@ static int launch_wino_cfg(const ConvArgs& a, hipStream_t stream) {
   int per = wino_tiles_per_wg(total, tiles_img, ncu[dev].load(std::memory_order_acquire) * (C::MB == 4 ? 1 : 2));
   if (per_env > 0 && tiles_img % per_env == 0) per = per_env;
   char name[64] = "";
-  if (prof_enabled()) snprintf(name, sizeof(name), "conv_wino_kernel<WinoCfg<%d> >", C::MB);      // = rocprofv3's name
+  if (prof_enabled()) snprintf(name, sizeof(name), "conv_wino_kernel<WinoCfg<%d>, %s>", C::MB, a.resample == RS_UP ? "true" : "false");   // = rocprofv3's name
   const double px = (double)a.B * a.H * a.W;
   // algorithmic cost = the direct convolution's (2 * MAC); the kernel issues 4 / 9 of these as matrix flops
   ProfScope ps(name, 2.0 * px * a.Cout * (double)Cin * 9,
                4.0 * ((double)a.B * Cin * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * Cin * 9), stream);
-  hipLaunchKernelGGL(conv_wino_kernel<C>, dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,
-                     tiles_img, nch, cout_padded(a.Cout) / 32, per, wino_mode_env());
+  if (a.resample == RS_UP)
+    hipLaunchKernelGGL((conv_wino_kernel<C, true>), dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,
+                       tiles_img, nch, cout_padded(a.Cout) / 32, per, wino_mode_env());
+  else
+    hipLaunchKernelGGL((conv_wino_kernel<C, false>), dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,
+                       tiles_img, nch, cout_padded(a.Cout) / 32, per, wino_mode_env());
   MCEDM_LAUNCH_CHECK("conv_wino_kernel");
   if (a.gsum_tiles) *a.gsum_tiles = SumTiles{tiles_img, tiles_x, WPH, WPW, a.gsum_rc == 2 ? 2 : 4};
   return MCEDM_OK;
