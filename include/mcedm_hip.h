@@ -281,6 +281,11 @@ int mcedm_op_set_conv8(int enable);
  * MCEDM_CONV_RESIDENT, else on).  Bit-identical to conv_mfma_kernel per tile configuration except the K-split tile used
  * at <= 8 x 8 (same result for a given shape, grouped differently).  Process-global, not thread-safe. */
 int mcedm_op_set_conv_resident(int enable);
+/* The Winograd F(2x2, 3x3) kernels (conv_wino.hip) in the network paths: 1 on, 0 off (direct kernels everywhere), -1 back to
+ * the default (env MCEDM_WINOGRAD, else on).  Read when a plan lays out its workspace (whether a block's 1x1 skip projection
+ * is folded into conv1 depends on it) and at every launch: set it before mcedm_unet_plan_create / the first forward.
+ * Process-global, not thread-safe. */
+int mcedm_op_set_conv_wino(int enable);
 /* The single-launch attention part of a UNetBlock at 8 x 8 x 64 channels (attn_fused.hip; inference only): 1 on, 0 off
  * (qkv conv + attention kernel + proj conv), -1 back to the default (env MCEDM_ATTN_FUSED, else on).  Process-global. */
 int mcedm_op_set_attn_fused(int enable);

@@ -136,6 +136,7 @@ size_t conv_wino_packed_floats(int Cout, int Cin);
 int launch_pack_conv_wino(const float* w, float* dst, int Cout, int Cin, int transpose_flip, hipStream_t stream);   // w [Cout][Cin][3][3]; transpose_flip: w is [Cin][Cout][3][3], build the data-gradient weights
 bool conv_wino_applicable(const ConvArgs& a, int taps);
 bool conv_wino_shape_ok(int Cout, int Cin, int H, int W);
+void set_conv_wino(int enable);                          // 1 / 0, -1: default (env MCEDM_WINOGRAD, else on)
 bool conv_wino_preferred(const ConvArgs& a);              // env MCEDM_WINOGRAD (default on), MCEDM_WINO_MIN_HW (default 32 x 32)
 int launch_conv_wino(const ConvArgs& a, hipStream_t stream);
 static inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }     // channel padding of the packed tables

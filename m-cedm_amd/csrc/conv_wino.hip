@@ -486,7 +486,10 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
 #endif
 }
 
+static int g_wino = -1;      // -1: default (env MCEDM_WINOGRAD, else on); 0 / 1: forced by mcedm_op_set_conv_wino
+void set_conv_wino(int enable) { g_wino = enable; }
 static int wino_env() {                                        // MCEDM_WINOGRAD=0: never take this kernel
+  if (g_wino >= 0) return g_wino;
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_WINOGRAD"); env = e ? atoi(e) : 1; }
   return env;

@@ -142,6 +142,11 @@ extern "C" int mcedm_op_set_conv8(int enable) {
   return MCEDM_OK;
 }
 
+extern "C" int mcedm_op_set_conv_wino(int enable) {
+  set_conv_wino(enable);
+  return MCEDM_OK;
+}
+
 extern "C" int mcedm_op_set_conv_resident(int enable) {
   set_conv_resident(enable);
   return MCEDM_OK;

@@ -105,6 +105,46 @@ from oracle import ddpm_oracle as dorc  # noqa: E402
 CFG_D128 = dorc.DdpmConfig()            # resolution 128, ch 64, ch_mult (1, 1, 1), attn_resolutions (32,), self_cond
 
 
+def test_winograd_and_direct_kernels_agree_full_size(net):
+    """The S128 network with the Winograd F(2x2, 3x3) kernels (default: 26 of its 34 3x3 launches, csrc/conv_wino.hip) against
+    the same network on the direct kernels only: one forward and one whole 18-step sampler call (35 evaluations), at the
+    north_star tolerance; and the direct-kernel run is the one the oracle spot check above pins from the other side."""
+    lib, plan, packed, _ = net
+    B = 2
+    cond, m, init = inputs(B, seed=3)
+    sd = lib.sampler_desc(orc.SamplerParams(timesteps=18))
+    lab = torch.tensor([0.7]).cuda()
+    names = []
+    lib.prof_enable(True)
+    try:
+        Fw = plan.forward(packed, init.cuda(), lab, cond=cond.cuda())
+        torch.cuda.synchronize()
+        names = [r["name"] for r in lib.prof_report()]
+    finally:
+        lib.prof_enable(False)
+    assert any(n.startswith("conv_wino_kernel<WinoCfg<4>") for n in names), names
+    xw = plan.sample(packed, sd, cond.cuda(), m.cuda(), init.cuda(), None)
+    lib.set_conv_wino(0)
+    try:
+        lib.prof_enable(True)
+        Fd = plan.forward(packed, init.cuda(), lab, cond=cond.cuda())
+        torch.cuda.synchronize()
+        names = [r["name"] for r in lib.prof_report()]
+        lib.prof_enable(False)
+        assert not any(n.startswith("conv_wino") for n in names), names
+        xd = plan.sample(packed, sd, cond.cuda(), m.cuda(), init.cuda(), None)
+    finally:
+        lib.prof_enable(False)
+        lib.set_conv_wino(-1)
+    err = (Fw - Fd).abs()
+    assert bool((err <= 1e-5 + 1e-4 * Fd.abs()).all()), f"forward: max |winograd - direct| = {float(err.max()):.3e} at |F| <= {float(Fd.abs().max()):.3e}"
+    scale = float(xd.abs().max())
+    err = (xw - xd).abs()
+    assert bool((err <= 1e-5 * max(1.0, scale) + 1e-4 * xd.abs()).all()), f"sampler: max |winograd - direct| = {float(err.max()):.3e} (scale {scale:.3e})"
+    obs = (m == 0).permute(0, 2, 3, 1)
+    assert torch.equal(xw[:, 0].cpu()[obs], xd[:, 0].cpu()[obs]), "observed entries are exact in both"
+
+
 @pytest.fixture(scope="module")
 def ddpm_net():
     import mcedm_amd  # noqa: F401

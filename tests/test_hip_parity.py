@@ -267,6 +267,32 @@ def test_unet_forward_resident_on_off(lib, net_P):
     close(F1, F0.cpu(), rtol=1e-5, atol=2e-6, what="resident on / off")
 
 
+def test_unet_forward_winograd_on_off(lib, golden, net_P):
+    """The reference's ch = 64 network at 32 x 32: its 32 x 32 level runs on the 64-channel Winograd kernel by default
+    (csrc/conv_wino.hip, WinoCfg<2>).  Both that forward and the direct-kernel forward must meet the reference's golden output
+    at the north_star tolerance, and each other."""
+    plan, packed, P = net_P
+    x, cond = fx.randn("unet_P/x", 4, 2, 32, 32), fx.randn("unet_P/cond", 4, 2, 32, 32)
+    labels = dev(fx.UNET_LABELS["nB"])
+    lib.prof_enable(True)
+    try:
+        F1 = plan.forward(packed, dev(x), labels, cond=dev(cond))
+        torch.cuda.synchronize()
+        names = [r["name"] for r in lib.prof_report()]
+    finally:
+        lib.prof_enable(False)
+    assert any(n.startswith("conv_wino_kernel<WinoCfg<2>") for n in names), names
+    lib.set_conv_wino(0)
+    try:
+        F0 = plan.forward(packed, dev(x), labels, cond=dev(cond))
+    finally:
+        lib.set_conv_wino(-1)
+    g = golden("unet_P.npz")["F_nB"]
+    close(F1, g, what="winograd forward vs the reference")
+    close(F0, g, what="direct forward vs the reference")
+    close(F1, F0.cpu(), what="winograd on / off")
+
+
 def test_unet_32x32_batch_shard_invariance(lib, net_P):
     """Every kernel of the 32 x 32 network (input-resident convs in all three tilings incl. the K-split one, multi-pass
     staging, fused attention block, fused statistics) is chosen by shape only and computes each sample on its own: a batch
