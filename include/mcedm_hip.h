@@ -227,8 +227,8 @@ int mcedm_op_conv(const float* xa, const float* xb, int Ca, int Cb, const mcedm_
                   int resample, int Hs, int Ws, int H, int W, const float* wpk, const float* bias_pk,
                   const float* res, int res_mode, float* out, int Cout, int B, int k, void* stream);
 /* The same convolution (3x3, pad 1) in Winograd F(2x2, 3x3) form: 4/9 of the matrix instructions of mcedm_op_conv.
- * Serves Cout % 128 == 0, H % 8 == 0, W % 16 == 0, Ca % 8 == 0, Cb % 8 == 0, resample / res_mode 0 (none) or 1 (nearest-2x
- * up: the source / residual is [.., H/2, W/2]); results agree with mcedm_op_conv to fp32 rounding (a different
+ * Serves Cout % 64 == 0, H % 8 == 0, W % 16 == 0, Ca % 8 == 0, Cb % 8 == 0, resample 0 (none) or 1 (nearest-2x up: the
+ * source is [.., H/2, W/2]), res_mode 0, 1 (residual [.., H/2, W/2]) or 2 (2x2 mean of a residual [.., 2H, 2W]); results agree with mcedm_op_conv to fp32 rounding (a different
  * summation), not bit for bit.  w [Cout][Cin][3][3] -> wino (mcedm_op_conv_wino_packed_floats floats); bias [Cout] in
  * natural order or NULL; (H, W) is the conv (= output) size. */
 size_t mcedm_op_conv_wino_packed_floats(int Cout, int Cin);

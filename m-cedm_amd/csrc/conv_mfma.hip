@@ -143,7 +143,23 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   WeightGeom<C> wgeom;
   make_wgeom<C>(p.wpk, wgeom, m0, coutp, (p.Ca + p.Cb + C::KC - 1) / C::KC, tid);
   load_weights<C>(wgeom, win, 0, coutp);
-  load_input<C, RS, false>(p, geom, xin, n, 0);
+  // 1x1 convs on 16-byte addressable rows stage four pixels per load (conv_tile.hpp Vec4Geom); wave-uniform choice
+  constexpr bool V4 = Vec4Geom<C>::OK && RS == RS_NONE;
+  Vec4Geom<C> vgeom;
+  bool v4 = false;
+  if constexpr (V4) {
+    v4 = (p.W & 3) == 0 && ((reinterpret_cast<size_t>(p.xa) | reinterpret_cast<size_t>(p.xb)) & 15) == 0;
+    make_vec4_geom<C>(p, vgeom, y0, x0, tid);
+  }
+  auto load_in = [&](int c0) {
+    if constexpr (V4) { if (v4) { load_input_v4<C, RS>(p, vgeom, xin, n, c0, wave); return; } }
+    load_input<C, RS, false>(p, geom, xin, n, c0);
+  };
+  auto store_in = [&](int c0) {
+    if constexpr (V4) { if (v4) { store_input_v4<C, RS>(p, vgeom, xl, xin, c0, tid, wave, cfl); return; } }
+    store_input<C, RS>(p, geom, xl, xin, c0, tid, cfl);
+  };
+  load_in(0);
   stage_coef_rows<C::NT>(p, n, cfl, tid);
   // after the first chunk's loads are issued: the residual tile streams in behind them
   if (wave < C::NWAVE) {
@@ -168,7 +184,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
   __syncthreads();            // transform rows visible to every wave
   for (int ch = 0; ch < nchunks; ++ch) {
     store_weights<C>(wl, win, tid);
-    store_input<C, RS>(p, geom, xl, xin, ch * C::KCI, tid, cfl);
+    store_in(ch * C::KCI);
     MCEDM_STAMP(0)
     __syncthreads();
     MCEDM_STAMP(1)
@@ -177,7 +193,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* xl, float* w
         // resolves with a vmcnt(0) + register copies right here, in front of the MFMA loop.
       const int chn = ch + 1 < nchunks ? ch + 1 : ch;
       load_weights<C>(wgeom, win, chn, coutp);
-      load_input<C, RS, false>(p, geom, xin, n, chn * C::KCI);
+      load_in(chn * C::KCI);
     }
     MCEDM_STAMP(2)
     if (wave < C::NWAVE) {

@@ -241,6 +241,60 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
   }
 }
 
+// ---- 1x1 convs on rows that are 16-byte addressable (W % 4 == 0, aligned planes): the 8 x 32 tile has no halo, so a thread
+// stages FOUR consecutive pixels of a channel with one 16-byte load and one 16-byte LDS store -- KCI / 4 vector-memory
+// instructions per thread and chunk instead of KCI (each costs ~60 cycles of issue beside the MFMAs).  Same registers
+// (InputRegs::raw, element 4 it + e = pixel e of this thread's quad in channel wave + 4 it), same LDS image, same values.
+template <class C>
+struct Vec4Geom {
+  static constexpr bool OK = C::TAPS == 1 && C::MT == 128 && C::PW == 32 && C::PLANE == 256 && C::NT == 256 && C::KCI % 4 == 0;   // the 128-channel tile only: the smaller ones run three workgroups per CU on 168 registers and would spill with two staging paths
+  unsigned off;     // byte offset of the quad inside a channel plane
+  unsigned keep;    // all-ones: inside the image
+};
+template <class C>
+__device__ __forceinline__ void make_vec4_geom(const ConvArgs& p, Vec4Geom<C>& G, int y0, int x0, int tid) {
+  const int pix = 4 * (tid & 63);
+  const int y = y0 + pix / C::PW, x = x0 + pix % C::PW;
+  const bool inb = y < p.H && x < p.W;              // W % 4 == 0: the quad is wholly inside or wholly outside
+  G.keep = inb ? 0xffffffffu : 0u;
+  G.off = inb ? 4u * (unsigned)(y * p.Ws + x) : 0u;
+}
+template <class C, int RS>
+__device__ __forceinline__ void load_input_v4(const ConvArgs& p, const Vec4Geom<C>& G, InputRegs<C, RS>& R, int n, int c0, int wave) {
+  const int Cin = p.Ca + p.Cb;
+  const size_t src_plane = (size_t)p.Hs * p.Ws;
+  const float* safe = p.xa ? p.xa : p.xb;
+#pragma unroll
+  for (int it = 0; it < C::KCI / 4; ++it) {
+    const int ci = c0 + wave + 4 * it;
+    const bool in_a = ci < p.Ca;
+    const float* src = in_a ? p.xa : p.xb;
+    const int cc = in_a ? ci : ci - p.Ca, CC = in_a ? p.Ca : p.Cb;
+    const bool chan_ok = (ci < Cin) && (src != nullptr);
+    const float* plane = chan_ok ? src + ((size_t)n * CC + cc) * src_plane : safe;
+    const f32x4 q = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(plane) + G.off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) R.raw[4 * it + e][0][0] = q[e];
+  }
+}
+template <class C, int RS>
+__device__ __forceinline__ void store_input_v4(const ConvArgs& p, const Vec4Geom<C>& G, float* xl, const InputRegs<C, RS>& R, int c0,
+                                               int tid, int wave, const Coef* cfl) {
+  const int Cin = p.Ca + p.Cb;
+#pragma unroll
+  for (int it = 0; it < C::KCI / 4; ++it) {
+    const int cil = wave + 4 * it, ci = c0 + cil;
+    const Coef cfr = cfl[ci < Cin ? ci : Cin - 1];
+    const bool chan_ok = (ci < Cin) && ((ci < p.Ca ? p.xa : p.xb) != nullptr);
+    const unsigned m = G.keep & (chan_ok ? 0xffffffffu : 0u);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, apply_coef(R.raw[4 * it + e][0][0], cfr, p.act)) & m);
+    *reinterpret_cast<f32x4*>(xl + cil * C::PLANE + 4 * (tid & 63)) = v;
+  }
+}
+
 // weights: rows of MT floats out of the packed [chunk][tap][ci_local][CoutP] table
 template <class C>
 struct WeightRegs {

@@ -373,8 +373,8 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
     // SGPRs, one 32-bit lane offset, the channel step in the scalar offset -- no 64-bit address pair per operation
     const size_t splane = (size_t)p.Cout * HW;                      // this sample's output planes (the launcher checks < 4 GiB)
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out + (size_t)n * splane, 4u * (unsigned)splane);
-    const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.res ? p.res + (size_t)n * (p.res_mode == RS_UP ? splane >> 2 : splane) : nullptr,
-                                                    p.res ? 4u * (unsigned)(p.res_mode == RS_UP ? splane >> 2 : splane) : 0u);
+    const size_t rplane = p.res_mode == RS_UP ? splane >> 2 : p.res_mode == RS_DOWN ? splane << 2 : splane;   // the residual's planes of this sample
+    const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.res ? p.res + (size_t)n * rplane : nullptr, p.res ? 4u * (unsigned)rplane : 0u);
     const unsigned HWu = (unsigned)HW;
     const unsigned voff = 4u * ((unsigned)cbase * HWu + (unsigned)oy * p.W + ox);
     const unsigned rvoff = 4u * ((unsigned)cbase * (HWu >> 2) + (unsigned)(oy >> 1) * (p.W >> 1) + (ox >> 1));
@@ -395,14 +395,33 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
 #pragma unroll
     for (int q = 0; q < 8; ++q) ua[q] = up[q * 64];
     __builtin_amdgcn_sched_barrier(0);                    // the accumulators are dead from here to the end of the epilogue
+    if (p.res && p.res_mode == RS_DOWN) {
+      // residual at double resolution: the 2x2 mean of the source (adm_blocks.py:75-77), two 16-byte loads per channel and
+      // pixel pair, four channels in flight at a time (all sixteen would need 128 registers)
+      const unsigned dvoff = 4u * ((unsigned)cbase * (HWu << 2) + (unsigned)(2 * oy) * (unsigned)(2 * p.W) + (unsigned)(2 * ox));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dr = (r & 3) + 8 * (r >> 2);
-      if (p.res && p.res_mode == RS_UP) {                  // residual at half resolution: both pixels of the pair share a source
-        const float q = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, rvoff, 4u * (unsigned)dr * (HWu >> 2), 0));
-        rv[r] = make_float2(q, q);
-      } else {                                             // no residual: a zero-sized descriptor reads zeros
-        rv[r] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff, 4u * (unsigned)dr * HWu, 0));
+      for (int r0 = 0; r0 < 16; r0 += 4) {
+        f32x4 ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned so = 4u * (unsigned)(((r0 + k) & 3) + 8 * ((r0 + k) >> 2)) * (HWu << 2);
+          ta[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, dvoff, so, 0));
+          tb[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, dvoff + 8u * (unsigned)p.W, so, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          rv[r0 + k] = make_float2(0.25f * ((ta[k][0] + ta[k][1]) + (tb[k][0] + tb[k][1])), 0.25f * ((ta[k][2] + ta[k][3]) + (tb[k][2] + tb[k][3])));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (p.res && p.res_mode == RS_UP) {                // residual at half resolution: both pixels of the pair share a source
+          const float q = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, rvoff, 4u * (unsigned)dr * (HWu >> 2), 0));
+          rv[r] = make_float2(q, q);
+        } else {                                           // no residual: a zero-sized descriptor reads zeros
+          rv[r] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff, 4u * (unsigned)dr * HWu, 0));
+        }
       }
     }
     const int pw = wave ^ MB;
@@ -520,7 +539,7 @@ int launch_pack_conv_wino(const float* w, float* dst, int Cout, int Cin, int tra
 bool conv_wino_applicable(const ConvArgs& a, int taps) {
   return taps == 9 && a.wino && (a.resample == RS_NONE || a.resample == RS_UP) && a.Cout % 64 == 0 && a.H % WPH == 0 &&
          a.W % WPW == 0 && (a.Ca + a.Cb) % WKC == 0 && a.Ca % WKC == 0 && !a.sk_wpk &&
-         (!a.res || a.res_mode == RS_NONE || a.res_mode == RS_UP) && (a.Ca + a.Cb) <= 1024;
+         (!a.res || a.res_mode == RS_NONE || a.res_mode == RS_UP || a.res_mode == RS_DOWN) && (a.Ca + a.Cb) <= 1024;
 }
 
 // Tiles per workgroup: a divisor d of the tiles per image (a workgroup stays inside one sample: one set of transform rows),
@@ -586,7 +605,8 @@ int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
   MCEDM_REQUIRE(conv_wino_applicable(a, 9), "conv_wino: shape not served by the Winograd kernel");
   MCEDM_REQUIRE(a.out && a.B > 0 && (a.resample == RS_UP ? (a.Hs * 2 == a.H && a.Ws * 2 == a.W) : (a.Hs == a.H && a.Ws == a.W)),
                 "conv_wino: bad arguments");
-  MCEDM_REQUIRE((unsigned long long)a.H * a.W * 4ull * a.Cout < (1ull << 32), "conv_wino: one sample of the output exceeds the 4 GiB buffer range");
+  MCEDM_REQUIRE((unsigned long long)a.H * a.W * 4ull * a.Cout * (a.res && a.res_mode == RS_DOWN ? 4 : 1) < (1ull << 32),
+                "conv_wino: one sample of the output / residual exceeds the 4 GiB buffer range");
   { const int rc = conv_resolve_identity(a); if (rc != MCEDM_OK) return rc; }
   // 128 output channels per workgroup where they divide (fewer passes over the input), else 64
   return a.Cout % 128 == 0 ? launch_wino_cfg<WinoCfg<4>>(a, stream) : launch_wino_cfg<WinoCfg<2>>(a, stream);

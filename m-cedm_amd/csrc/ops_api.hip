@@ -59,8 +59,8 @@ extern "C" int mcedm_op_pack_conv_wino(const float* w, int Cout, int Cin, float*
 extern "C" int mcedm_op_conv_wino(const float* xa, const float* xb, int Ca, int Cb, const mcedm_coef* coef, int coef_batch,
                                   int act, int resample, int H, int W, const float* wino, const float* bias, const float* res,
                                   int res_mode, float* out, int Cout, int B, void* stream) {
-  MCEDM_REQUIRE((resample == RS_NONE || resample == RS_UP) && (res_mode == RS_NONE || res_mode == RS_UP),
-                "op_conv_wino: resample / res_mode must be 0 (none) or 1 (nearest-2x up)");
+  MCEDM_REQUIRE((resample == RS_NONE || resample == RS_UP) && (res_mode == RS_NONE || res_mode == RS_UP || res_mode == RS_DOWN),
+                "op_conv_wino: resample must be 0 (none) or 1 (nearest-2x up), res_mode 0, 1 or 2 (2x2-mean down)");
   ConvArgs a{};
   a.xa = xa; a.xb = xb; a.Ca = Ca; a.Cb = Cb;
   a.coef = reinterpret_cast<const Coef*>(coef); a.coef_batch = coef_batch; a.act = act;

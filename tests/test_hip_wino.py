@@ -102,6 +102,12 @@ def test_conv_wino_upsampled_input_and_residual(lib):
         torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest").double()
     got = lib.op_conv_wino(dev(h), None, wino, dev(b), 128, res=dev(x), res_mode=lib.RS_UP)
     close(got, ref, "winograd with an up-sampled residual vs fp64")
+    # the down block's conv1: residual = 2x2 mean of the block input at twice the resolution (adm_blocks.py:75-77, 171)
+    big = fx.randn("wino/down/res", B, C, 4 * Hs, 4 * Ws)
+    ref = torch.nn.functional.conv2d(h.double(), w.double(), b.double(), padding=1) + torch.nn.functional.avg_pool2d(big.double(), 2)
+    got = lib.op_conv_wino(dev(h), None, wino, dev(b), 128, res=dev(big), res_mode=lib.RS_DOWN)
+    close(got, ref, "winograd with a 2x2-mean residual vs fp64")
+    close(got, lib.op_conv(dev(h), None, wpk, bpk, 128, 3, res=dev(big), res_mode=lib.RS_DOWN), "vs the direct kernel")
 
 
 def test_conv_wino_is_batch_invariant(lib):
