@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MCEDM_ABI_VERSION 1
+#define MCEDM_ABI_VERSION 2
 #define MCEDM_MAX_LEVELS 8
 
 typedef enum {
@@ -40,8 +40,13 @@ typedef enum {
 } mcedm_status;
 
 /* Architecture of DhariwalUNet as read from hparams.model (models/adm_blocks.py:203-317,
- * configs/model/adm_edm_mcedm_res32.yaml:4-28).  Only the cat_cond=True, dx_cond=False,
- * self_cond=False, label_dim=augment_dim=0, dropout=0 configuration is on the hot path. */
+ * configs/model/adm_edm_mcedm_res32.yaml:4-28).  cat_cond=True, self_cond=False, label_dim=augment_dim=0,
+ * dropout=0; dx_cond (network conditioning on the PDE-residual gradient, adm_blocks.py:233-280, 334-362) in both of
+ * the reference's forms: dx_mode. */
+#define MCEDM_DX_NONE 0   /* dx_cond False */
+#define MCEDM_DX_CAT 1    /* dx_cond True, cat_dx True: conv_in reads cat(cond, x, dx) (adm_blocks.py:238, 334-339) */
+#define MCEDM_DX_ENC 2    /* dx_cond True, cat_dx False: x_feat = combine_enc(cat(conv_in(.), dx_enc(dx))), dx_enc =
+                             Conv3x3 -> GELU -> Conv3x3; dx None -> zero features (adm_blocks.py:266-280, 352-362) */
 typedef struct {
   int32_t in_channels;       /* state channels (h_ch + u_ch), 2 */
   int32_t cond_channels;     /* concatenated conditioning channels, 2 (0 = none) */
@@ -55,6 +60,8 @@ typedef struct {
   int32_t attn_resolutions[MCEDM_MAX_LEVELS];
   int32_t channels_per_head; /* 64 */
   float eps;                 /* GroupNorm eps, 1e-5 */
+  int32_t dx_channels;       /* channels of the dx input = hparams.model.in_channels when dx_cond, else 0 */
+  int32_t dx_mode;           /* MCEDM_DX_* */
 } mcedm_unet_desc;
 
 /* Sampler parameters (configs/diff_sampler/edm_sampler.yaml:1-20; fields read by
@@ -141,6 +148,35 @@ typedef struct {
 } mcedm_guidance_desc;
 int mcedm_heun_sample_guided(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
                              const mcedm_guidance_desc* gd, const float* cond, const float* mask,
+                             const float* init_noise, const double* step_noise, double* out, int return_last,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+/* ---- dx_cond: the network conditioned on the PDE-residual gradient (plans with dx_mode != MCEDM_DX_NONE) ----------
+ * The same three calls with the extra network input dx [B, dx_channels, H, W] (DhariwalUNet.forward(..., dx=dx),
+ * adm_blocks.py:364-388; model_precond / get_denoised with dx, models/ddim.py:1661-1666, 1745-1763).  dx == NULL is the
+ * reference's dx=None: zeros concatenated (cat_dx) or zero dx features (dx_enc).  The entry points without _dx accept such
+ * plans too and mean dx = NULL.  dx carries no gradient (torch.autograd.grad without create_graph, models/pde_loss.py:233;
+ * dx_detach); the backward returns the gradients of dx_enc / combine_enc like every other parameter.  n_buckets == 0: no
+ * bucket events. */
+int mcedm_unet_forward_dx(const mcedm_plan* plan, const void* packed, const float* x, const float* dx, const float* cond,
+                          const float* x_scale, const float* noise_labels, int n_noise, float* out, void* workspace,
+                          size_t workspace_bytes, int B, int H, int W, int training, void* stream);
+int mcedm_edm_denoise_dx(const mcedm_plan* plan, const void* packed, const float* x, const float* dx, const float* sigma,
+                         int n_sigma, const float* cond, float* D_out, float* F_out, void* workspace,
+                         size_t workspace_bytes, int B, int H, int W, int training, double sigma_data, void* stream);
+int mcedm_edm_denoise_backward_dx(const mcedm_plan* plan, const void* packed, const float* const* params, const float* x,
+                                  const float* dx, const float* sigma, int n_sigma, const float* cond, const float* dD,
+                                  float* const* grads, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                                  double sigma_data, int n_buckets, const int32_t* bucket_first_param,
+                                  void* const* bucket_events, void* stream);
+/* PlCondEdm.sample_edm of a dx_cond model (models/ddim.py:1532-1601): before EVERY denoiser call
+ * dx_in = get_dx_input(h, x) (:601-639 with dx_norm == 'prob', the only normalisation the single-task get_dx_pde :1424-1450
+ * can feed: its calc_prob=False result is 3-D and the other branches fail to unpack it) = the mean over the two fields of
+ * the log-probability residual gradient at x_unnorm = (h from cond[:, 0], u = the CURRENT NOISY state cast to fp32), fed to
+ * the network as dx.  dxc describes that residual (same fields as for mcedm_heun_sample_guided; weight unused); gd != NULL
+ * additionally applies guide_dx to the denoised state as in mcedm_heun_sample_guided.  With sp->w != 0 the unconditional
+ * branch runs without cond AND without dx (:1759-1760). */
+int mcedm_heun_sample_dxcond(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                             const mcedm_guidance_desc* dxc, const mcedm_guidance_desc* gd, const float* cond,
                              const float* init_noise, const double* step_noise, double* out, int return_last,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 /* Host helper: the float64 sigma schedule of mcedm.py:584-588 (timesteps+1 values, last = 0). */

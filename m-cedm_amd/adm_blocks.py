@@ -5,9 +5,11 @@ unchanged, incl. the ``resample_filter`` buffers) and the same ``forward`` signa
 
 The sub-modules below only OWN parameters (initialised with the reference's distributions,
 models/adm_blocks.py:10-15,221-222); the network is executed as one fused schedule by the C library,
-not module by module.  Configurations outside the hot path (cond_enc / dx_enc / self-conditioning /
-class or augment labels / dropout) raise NotImplementedError instead of silently computing something
-else.  There is no PyTorch fallback: without the HIP library or on a CPU tensor, forward raises.
+not module by module.  ``dx_cond`` (the network conditioned on the PDE-residual gradient, models/adm_blocks.py:233-280,
+334-362) is built in both of the reference's forms: ``cat_dx=True`` (dx concatenated to conv_in's input) and
+``cat_dx=False`` (``dx_enc`` = Conv3x3 -> GELU -> Conv3x3 and ``combine_enc``).  Configurations outside the hot path
+(cond_enc / self-conditioning / class or augment labels / dropout) raise NotImplementedError instead of silently computing
+something else.  There is no PyTorch fallback: without the HIP library or on a CPU tensor, forward raises.
 """
 from __future__ import annotations
 
@@ -96,8 +98,6 @@ class DhariwalUNet(nn.Module):
         unsupported = []
         if _get(m, "self_cond", False):
             unsupported.append("self_cond")
-        if _get(m, "dx_cond", False):
-            unsupported.append("dx_cond")
         if m.augment_dim or m.label_dim:
             unsupported.append("augment_dim/label_dim")
         if m.dropout:
@@ -115,23 +115,30 @@ class DhariwalUNet(nn.Module):
         if unsupported:
             raise NotImplementedError("outside the MI355X hot path (SURVEY.md section 8a): " + ", ".join(unsupported))
         self.resolution = m.resolution
-        self.in_channels = m.in_channels + cond_channels
+        self.dx_cond = bool(_get(m, "dx_cond", False))
+        self.cat_dx = bool(_get(m, "cat_dx", False))
+        dx_mode = _lib.DX_NONE if not self.dx_cond else (_lib.DX_CAT if self.cat_dx else _lib.DX_ENC)
+        # adm_blocks.py:236-238: cond and (cat_dx) dx are stacked to the input
+        self.in_channels = m.in_channels + cond_channels + (m.in_channels if dx_mode == _lib.DX_CAT else 0)
         self.cond_channels = cond_channels
         self.state_channels = m.in_channels
         self.out_channels = m.out_ch
         self.cat_condition = True
         self.self_condition = False
-        self.dx_cond = False
         self.label_dropout = m.label_dropout
         self._arch = dict(in_channels=m.in_channels, cond_channels=cond_channels, out_channels=m.out_ch, ch=ch,
                           ch_mult=mult, num_res_blocks=m.num_res_blocks, attn_resolutions=tuple(m.attn_resolutions),
-                          resolution=m.resolution)
+                          resolution=m.resolution, dx_channels=m.in_channels if self.dx_cond else 0, dx_mode=dx_mode)
         self.map_noise = PositionalEmbedding(ch)
         self.map_augment = None
         self.map_layer0 = Linear(ch, ch)
         self.map_layer1 = Linear(ch, ch)
         self.map_label = None
         self.cond_enc = self.dx_enc = self.combine_enc = None
+        if dx_mode == _lib.DX_ENC:           # adm_blocks.py:266-280 (registered before self.enc: state_dict order)
+            c0 = ch * mult[0]
+            self.dx_enc = nn.Sequential(Conv2d(m.in_channels, c0, 3), nn.GELU(), Conv2d(c0, c0, 3))
+            self.combine_enc = Conv2d(2 * c0, c0, 3)
         self.enc = nn.ModuleDict()
         cout = self.in_channels
         skips = []
@@ -204,8 +211,10 @@ class DhariwalUNet(nn.Module):
         return self._packed
 
     def _check_extra(self, x_self_cond, dx, class_labels, augment_labels):
-        if x_self_cond is not None or dx is not None or class_labels is not None or augment_labels is not None:
-            raise NotImplementedError("x_self_cond / dx / class_labels / augment_labels are outside the hot path")
+        if x_self_cond is not None or class_labels is not None or augment_labels is not None:
+            raise NotImplementedError("x_self_cond / class_labels / augment_labels are outside the hot path")
+        if dx is not None and not self.dx_cond:
+            raise NotImplementedError("dx given to a network built with dx_cond=False (the reference ignores it silently)")
 
     def forward(self, x, noise_labels, cond=None, x_self_cond=None, dx=None, class_labels=None, augment_labels=None):
         self._check_extra(x_self_cond, dx, class_labels, augment_labels)
@@ -215,7 +224,8 @@ class DhariwalUNet(nn.Module):
         x = x.to(torch.float32).contiguous()
         labels = noise_labels.to(torch.float32).reshape(-1).contiguous()
         cond = cond.to(torch.float32).contiguous() if cond is not None else None
-        return self.plan.forward(self.packed_weights(), x, labels, cond=cond, ws=self._ws)
+        dx = dx.to(torch.float32).contiguous() if dx is not None else None
+        return self.plan.forward(self.packed_weights(), x, labels, cond=cond, ws=self._ws, dx=dx)
 
 
 class EmaModel(nn.Module):

@@ -67,6 +67,15 @@ __global__ void silu_map_kernel(const float* __restrict__ u, const float* __rest
   if (i < n) out[i] = mode ? g[i] * dsilu_b(u[i]) : silu_b(u[i]);
 }
 
+// [B, 2c, hw] -> two dense [B, c, hw] tensors (the data gradient of combine_enc's concatenated input)
+__global__ void split_channels_kernel(const float* __restrict__ src, size_t half, size_t total, float* __restrict__ a,
+                                      float* __restrict__ b) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / (2 * half), r = i - n * 2 * half;
+    if (r < half) a[n * half + r] = src[i]; else b[n * half + (r - half)] = src[i];
+  }
+}
+
 // out[c] = sum_r A[r][c]
 __global__ void colsum_kernel(const float* __restrict__ A, int rows, int cols, int lda, float* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,6 +103,11 @@ static BwdScratch make_scratch(const mcedm_plan& P, const Layout& L, int B, int 
   size_t bi = 0;
   auto conv_scr = [&](const ConvP& c) { max_wg = max_sz(max_wg, wgrad_scratch_floats(c.cout, c.cin, c.taps)); };
   conv_scr(P.conv_in); conv_scr(P.conv_out);
+  if (P.desc.dx_mode == MCEDM_DX_ENC) {      // gradients of conv_in's output, of dx_enc's output and of GELU(dx_enc.0)
+    want(L.xf); want(L.d2); want(L.g1);
+    conv_scr(P.dx_enc0); conv_scr(P.dx_enc2); conv_scr(P.combine);
+    max_dact = (size_t)B * 2 * P.conv_in.cout * H * W;      // combine_enc's data gradient, both halves
+  }
   for (auto* v : {&P.enc, &P.dec})
     for (const BlockP& b : *v) {
       const BlockLayout& bl = L.blocks[bi++];
@@ -287,12 +301,13 @@ extern "C" int mcedm_unet_grad_buckets(const mcedm_plan* plan, int max_buckets, 
 }
 
 static int denoise_backward_impl(const mcedm_plan* plan, const void* packed, const float* const* params,
-                                 const float* x, int n_sigma, const float* cond,
+                                 const float* x, const float* dx, int n_sigma, const float* cond,
                                  const float* dD, float* const* grads, void* workspace, size_t workspace_bytes,
                                  int B, int H, int W, int n_buckets, const int32_t* bucket_first,
                                  void* const* bucket_events, void* stream) {
   MCEDM_REQUIRE(plan && packed && params && x && dD && grads && workspace, "denoise_backward: null argument");
   const mcedm_plan& P = *plan;
+  MCEDM_REQUIRE(dx == nullptr || P.desc.dx_mode != MCEDM_DX_NONE, "denoise_backward: dx given to a plan without dx_cond");
   if (n_buckets > 0) {
     MCEDM_REQUIRE(bucket_first && bucket_events, "denoise_backward: null bucket arrays");
     const std::vector<int> cand = bucket_candidates(P);
@@ -363,9 +378,36 @@ static int denoise_backward_impl(const mcedm_plan* plan, const void* packed, con
   for (size_t i = nenc; i-- > 0;)
     if ((rc = block_backward(c, P.enc[i], L.blocks[i]))) return rc;
 
+  // dx_cond head (adm_blocks.py:352-362), in reverse: t0 = combine_enc(cat(xf, d2)), d2 = dx_enc.2(GELU(dx_enc.0(dx)))
+  const float* dy_in = c.G(L.t0);
+  if (P.desc.dx_mode == MCEDM_DX_ENC) {
+    const int c0 = P.conv_in.cout;
+    const size_t half = (size_t)c0 * H * W;
+    WgradArgs wc{c.G(L.t0), c.T(L.xf), c.T(L.d2), c0, c0, nullptr, 0, 0, RS_NONE, H, W, H, W, c0, B, c.X(S.wg), nullptr};
+    if ((rc = launch_wgrad(wc, 9, grads[P.combine.w], grads[P.combine.b], 0, c.X(c.S.xact), s))) return rc;
+    if ((rc = dgrad(c, P.combine, c.G(L.t0), H, W, c.X(S.dact)))) return rc;
+    hipLaunchKernelGGL(split_channels_kernel, dim3(grid_for(2 * half * B)), dim3(256), 0, s, c.X(S.dact), half, 2 * half * B,
+                       c.G(L.xf), c.G(L.d2));
+    MCEDM_LAUNCH_CHECK("split_channels_kernel");
+    if (dx) {
+      WgradArgs w2{c.G(L.d2), c.T(L.g1), nullptr, c0, 0, nullptr, 0, 0, RS_NONE, H, W, H, W, c0, B, c.X(S.wg), nullptr};
+      if ((rc = launch_wgrad(w2, 9, grads[P.dx_enc2.w], grads[P.dx_enc2.b], 0, c.X(c.S.xact), s))) return rc;
+      if ((rc = dgrad(c, P.dx_enc2, c.G(L.d2), H, W, c.G(L.g1)))) return rc;
+      if ((rc = launch_gelu(c.T(L.d1), c.G(L.g1), c.G(L.g1), (size_t)B * half, 1, s))) return rc;      // in place: d GELU
+      WgradArgs w1{c.G(L.g1), dx, nullptr, P.desc.dx_channels, 0, nullptr, 0, 0, RS_NONE, H, W, H, W, c0, B, c.X(S.wg), nullptr};
+      if ((rc = launch_wgrad(w1, 9, grads[P.dx_enc0.w], grads[P.dx_enc0.b], 0, c.X(c.S.xact), s))) return rc;
+    } else {                                  // dx None: zero features, no path to dx_enc (adm_blocks.py:355-357)
+      for (const ConvP* cv : {&P.dx_enc0, &P.dx_enc2}) {
+        MCEDM_HIP_TRY(hipMemsetAsync(grads[cv->w], 0, (size_t)P.params[cv->w].numel * sizeof(float), s));
+        MCEDM_HIP_TRY(hipMemsetAsync(grads[cv->b], 0, (size_t)P.params[cv->b].numel * sizeof(float), s));
+      }
+    }
+    dy_in = c.G(L.xf);
+  }
   // conv_in: weight / bias gradient only (its inputs carry no gradient)
-  WgradArgs wi{c.G(L.t0), cond, x, P.desc.cond_channels, P.desc.in_channels, at<Coef>(workspace, hd.coef_in),
-               n_sigma > 1 ? 1 : 0, 0, RS_NONE, H, W, H, W, P.conv_in.cout, B, c.X(S.wg), nullptr};
+  const bool catdx = P.desc.dx_mode == MCEDM_DX_CAT;
+  WgradArgs wi{dy_in, cond, catdx ? c.T(L.xdx) : x, P.desc.cond_channels, P.desc.in_channels + (catdx ? P.desc.dx_channels : 0),
+               at<Coef>(workspace, hd.coef_in), n_sigma > 1 ? 1 : 0, 0, RS_NONE, H, W, H, W, P.conv_in.cout, B, c.X(S.wg), nullptr};
   if ((rc = launch_wgrad(wi, 9, grads[P.conv_in.w], grads[P.conv_in.b], 0, c.X(c.S.xact), s))) return rc;
 
   // mapping MLP: film = emb Waff^T + baff, emb = silu(u2), u2 = W1 silu(u1) + b1, u1 = W0 pe + b0
@@ -390,8 +432,19 @@ extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* pa
                                           const float* dD, float* const* grads, void* workspace, size_t workspace_bytes,
                                           int B, int H, int W, double sigma_data, void* stream) {
   (void)sigma; (void)sigma_data;
-  return denoise_backward_impl(plan, packed, params, x, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W, 0,
+  return denoise_backward_impl(plan, packed, params, x, nullptr, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W, 0,
                                nullptr, nullptr, stream);
+}
+
+extern "C" int mcedm_edm_denoise_backward_dx(const mcedm_plan* plan, const void* packed, const float* const* params,
+                                             const float* x, const float* dx, const float* sigma, int n_sigma,
+                                             const float* cond, const float* dD, float* const* grads, void* workspace,
+                                             size_t workspace_bytes, int B, int H, int W, double sigma_data, int n_buckets,
+                                             const int32_t* bucket_first_param, void* const* bucket_events, void* stream) {
+  (void)sigma; (void)sigma_data;
+  MCEDM_REQUIRE(n_buckets >= 0, "denoise_backward_dx: n_buckets must be >= 0");
+  return denoise_backward_impl(plan, packed, params, x, dx, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W,
+                               n_buckets, bucket_first_param, bucket_events, stream);
 }
 
 extern "C" int mcedm_edm_denoise_backward_bucketed(const mcedm_plan* plan, const void* packed, const float* const* params,
@@ -402,6 +455,6 @@ extern "C" int mcedm_edm_denoise_backward_bucketed(const mcedm_plan* plan, const
                                                    void* const* bucket_events, void* stream) {
   (void)sigma; (void)sigma_data;
   MCEDM_REQUIRE(n_buckets >= 1, "denoise_backward_bucketed: n_buckets must be >= 1");
-  return denoise_backward_impl(plan, packed, params, x, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W,
+  return denoise_backward_impl(plan, packed, params, x, nullptr, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W,
                                n_buckets, bucket_first_param, bucket_events, stream);
 }

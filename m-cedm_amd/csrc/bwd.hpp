@@ -50,6 +50,9 @@ int launch_gn_param_grads(const float* ab, const float* gamma, const float* beta
                           int film_stride, int B, int C, float* dgamma, float* dbeta, float* dfilm, int dfilm_stride,
                           hipStream_t s);
 
+// torch.nn.GELU() of the dx_enc head (plan.hip): mode 0: out = GELU(v);  mode 1: out = g * dGELU(v)
+int launch_gelu(const float* v, const float* g, float* out, size_t n, int mode, hipStream_t s);
+
 // tiny dense helpers for the embedding MLP backward:  C[m][n] (+)= sum_k op(A)[m][k] * op(B)[k][n]
 int launch_small_gemm(const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc,
                       int transA, int transB, int accumulate, hipStream_t s);

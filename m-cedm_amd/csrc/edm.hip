@@ -18,7 +18,7 @@ static inline int grid_for(size_t n) {
 // Writes c_skip/c_out/c_in/c_noise rows and the conv_in transform table: cond channels pass
 // through, state channels are scaled by c_in (mcedm.py:208: only x is scaled, not cond).
 __global__ void precond_prepare_kernel(const float* __restrict__ sigma_dev, float sigma_host, int use_host, int n,
-                                       float sigma_data, int cond_ch, int in_ch, float* __restrict__ coefs4,
+                                       float sigma_data, int cond_ch, int in_ch, int dx_ch, float* __restrict__ coefs4,
                                        float* __restrict__ c_noise, Coef* __restrict__ conv_in_coef) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -34,15 +34,17 @@ __global__ void precond_prepare_kernel(const float* __restrict__ sigma_dev, floa
   coefs4[4 * i + 2] = c_in;
   coefs4[4 * i + 3] = cn;
   c_noise[i] = cn;
-  const int Ct = cond_ch + in_ch;
-  for (int c = 0; c < Ct; ++c) conv_in_coef[(size_t)i * Ct + c] = Coef{0.f, c < cond_ch ? 1.0f : c_in, 0.f, 0.f};
+  // rows of cat(cond, x, dx): only x is scaled by c_in (adm_blocks.py:319-340 is handed c_in * x, mcedm.py:208)
+  const int Ct = cond_ch + in_ch + dx_ch;
+  for (int c = 0; c < Ct; ++c)
+    conv_in_coef[(size_t)i * Ct + c] = Coef{0.f, (c < cond_ch || c >= cond_ch + in_ch) ? 1.0f : c_in, 0.f, 0.f};
 }
 
 int launch_precond_prepare(const float* sigma_dev, float sigma_host, int use_host, int n, float sigma_data,
-                           int cond_ch, int in_ch, float* coefs4, float* c_noise, Coef* conv_in_coef,
+                           int cond_ch, int in_ch, int dx_ch, float* coefs4, float* c_noise, Coef* conv_in_coef,
                            hipStream_t stream) {
   hipLaunchKernelGGL(precond_prepare_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, stream, sigma_dev, sigma_host,
-                     use_host, n, sigma_data, cond_ch, in_ch, coefs4, c_noise, conv_in_coef);
+                     use_host, n, sigma_data, cond_ch, in_ch, dx_ch, coefs4, c_noise, conv_in_coef);
   MCEDM_LAUNCH_CHECK("precond_prepare_kernel");
   return MCEDM_OK;
 }

@@ -5,7 +5,7 @@
 namespace mcedm {
 
 int launch_precond_prepare(const float* sigma_dev, float sigma_host, int use_host, int n, float sigma_data,
-                           int cond_ch, int in_ch, float* coefs4, float* c_noise, Coef* conv_in_coef,
+                           int cond_ch, int in_ch, int dx_ch, float* coefs4, float* c_noise, Coef* conv_in_coef,
                            hipStream_t stream);
 int launch_precond_finish(const float* x, const float* F, const float* Fu, float w, const float* coefs4, int n_sigma,
                           size_t per_sample, size_t total, float* D, float* F_out, hipStream_t stream);

@@ -120,6 +120,9 @@ extern "C" int mcedm_unet_plan_create(const mcedm_unet_desc* d, mcedm_plan** out
     const int c = d->ch * d->ch_mult[l];
     MCEDM_REQUIRE(d->ch_mult[l] >= 1 && c % 8 == 0, "plan_create: level %d width %d must be a multiple of 8", l, c);
   }
+  MCEDM_REQUIRE(d->dx_mode == MCEDM_DX_NONE || d->dx_mode == MCEDM_DX_CAT || d->dx_mode == MCEDM_DX_ENC, "plan_create: dx_mode=%d", d->dx_mode);
+  MCEDM_REQUIRE((d->dx_mode == MCEDM_DX_NONE) == (d->dx_channels == 0) && d->dx_channels >= 0,
+                "plan_create: dx_channels=%d does not go with dx_mode=%d", d->dx_channels, d->dx_mode);
   mcedm_plan* Pp = new mcedm_plan();
   mcedm_plan& P = *Pp;
   P.desc = *d;
@@ -132,8 +135,14 @@ extern "C" int mcedm_unet_plan_create(const mcedm_unet_desc* d, mcedm_plan** out
   P.map0_b = add_param(P, "map_layer0.bias", {ch});
   P.map1_w = add_param(P, "map_layer1.weight", {ch, ch});
   P.map1_b = add_param(P, "map_layer1.bias", {ch});
+  if (d->dx_mode == MCEDM_DX_ENC) {        // registered before self.enc (adm_blocks.py:266-280): state_dict order
+    const int c0 = ch * d->ch_mult[0];
+    P.dx_enc0 = make_conv(P, "dx_enc.0", d->dx_channels, c0, 3);
+    P.dx_enc2 = make_conv(P, "dx_enc.2", c0, c0, 3);
+    P.combine = make_conv(P, "combine_enc", 2 * c0, c0, 3);
+  }
   std::vector<int> skips;
-  int cout = d->in_channels + d->cond_channels;
+  int cout = d->in_channels + d->cond_channels + (d->dx_mode == MCEDM_DX_CAT ? d->dx_channels : 0);   // adm_blocks.py:236-238
   for (int level = 0; level < d->n_levels; ++level) {
     const int res = d->resolution >> level, mult = d->ch_mult[level];
     if (level == 0) {
@@ -194,6 +203,7 @@ extern "C" int mcedm_unet_plan_create(const mcedm_unet_desc* d, mcedm_plan** out
   P.waff = t.take((size_t)rows * ch);
   P.baff = t.take(rows);
   place_conv(t, P.conv_in, false);
+  if (d->dx_mode == MCEDM_DX_ENC) { place_conv(t, P.dx_enc0, false); place_conv(t, P.dx_enc2, true); place_conv(t, P.combine, true); }
   for (auto* v : {&P.enc, &P.dec})
     for (BlockP& b : *v) {
       place_norm(t, b.norm0); place_conv(t, b.conv0, true);
@@ -310,6 +320,11 @@ extern "C" int mcedm_unet_pack_weights(const mcedm_plan* plan, const float* cons
   cp.add(params[P.map1_w], pk + P.w1, (size_t)ch * ch); cp.add(params[P.map1_b], pk + P.b1, ch);
   int rc = pack_conv(P.conv_in, params, pk, cp, s);
   if (rc) return rc;
+  if (P.desc.dx_mode == MCEDM_DX_ENC) {
+    if ((rc = pack_conv(P.dx_enc0, params, pk, cp, s))) return rc;
+    if ((rc = pack_conv(P.dx_enc2, params, pk, cp, s))) return rc;
+    if ((rc = pack_conv(P.combine, params, pk, cp, s))) return rc;
+  }
   for (auto* v : {&P.enc, &P.dec})
     for (const BlockP& b : *v) {
       cp.add(params[b.aff_w], pk + P.waff + (size_t)b.film_row0 * ch, (size_t)2 * b.cout * ch);
@@ -388,8 +403,16 @@ int build_layout(const mcedm_plan& P, int B, int H, int W, int training, int n_n
     L.t[id].sums = sums_cur;
     sums_cur += sums_sz(L.t[id].C, L.t[id].H, L.t[id].W);
   };
+  if (P.desc.dx_mode == MCEDM_DX_CAT) L.xdx = lb.act(P.desc.in_channels + P.desc.dx_channels, H, W);
+  if (P.desc.dx_mode == MCEDM_DX_ENC) {
+    L.xf = lb.act(P.conv_in.cout, H, W);
+    L.d1 = lb.act(P.conv_in.cout, H, W);
+    L.g1 = lb.act(P.conv_in.cout, H, W);
+    L.d2 = lb.act(P.conv_in.cout, H, W);
+  }
   L.t0 = lb.act(P.conv_in.cout, H, W);
   give_sums(L.t0);
+  lb.drop(L.xdx); lb.drop(L.xf); lb.drop(L.d1); lb.drop(L.g1); lb.drop(L.d2);      // the head's temporaries (kept in training)
   std::vector<int> skips;
   int cur = L.t0;
   lb.retain(cur);                 // chain reference
@@ -473,7 +496,7 @@ Header header_for(const mcedm_plan& P, int B, int H, int W) {
   Header h;
   size_t cur = 0;
   auto take = [&](size_t bytes) { size_t o = cur; cur += align_up(bytes, 256); return o; };
-  const int Ct = P.desc.in_channels + P.desc.cond_channels;
+  const int Ct = P.desc.in_channels + P.desc.cond_channels + P.desc.dx_channels;
   h.coefs4 = take((size_t)B * 4 * sizeof(float));
   h.c_noise = take((size_t)B * sizeof(float));
   h.coef_in = take((size_t)B * Ct * sizeof(Coef));
@@ -593,11 +616,37 @@ static int run_block(const mcedm_plan& P, const BlockP& b, const BlockLayout& bl
   return launch_conv(cp, 1, s);
 }
 
+// ---- dx_cond head (adm_blocks.py:334-362) ------------------------------------------------------------------
+// out[B, cx + cd, HW] = cat(x[B, cx, HW], dx[B, cd, HW] or zeros)   (cat_dx: adm_blocks.py:335-339)
+__global__ void concat_x_dx_kernel(const float* __restrict__ x, const float* __restrict__ dx, int cx, int cd, size_t hw,
+                                   size_t total, float* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t per = (size_t)(cx + cd) * hw;
+    const size_t n = i / per, r = i - n * per;
+    out[i] = r < (size_t)cx * hw ? x[n * cx * hw + r] : (dx ? dx[n * cd * hw + (r - (size_t)cx * hw)] : 0.f);
+  }
+}
+// torch.nn.GELU() (approximate='none'): y = 0.5 v (1 + erf(v / sqrt(2)));  mode 1: out = g * dGELU(v)
+__global__ void gelu_kernel(const float* __restrict__ v, const float* g, float* out, size_t n, int mode) {      // out may be g
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float a = v[i];
+    const float cdf = 0.5f * (1.0f + erff(a * 0.70710678118654752440f));
+    out[i] = mode ? g[i] * (cdf + a * 0.39894228040143267794f * expf(-0.5f * a * a)) : a * cdf;
+  }
+}
+int launch_gelu(const float* v, const float* g, float* out, size_t n, int mode, hipStream_t s) {
+  const size_t b = (n + 255) / 256;
+  hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)(b < 4096 ? (b ? b : 1) : 4096)), dim3(256), 0, s, v, g, out, n, mode);
+  MCEDM_LAUNCH_CHECK("gelu_kernel");
+  return MCEDM_OK;
+}
+
 // act = start of the activation region (after the header)
-static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, const float* x, const float* cond,
+static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, const float* x, const float* dx, const float* cond,
                         const Coef* coef_in, int coef_batch, const float* noise_labels, int n_noise, float* out,
                         void* act, int B, int H, int W, hipStream_t s) {
   const int ch = P.desc.ch;
+  const int dxm = P.desc.dx_mode;
   int rc;
   EmbArgs e{noise_labels, n_noise, ch, pk + P.freqs, pk + P.w0, pk + P.b0, pk + P.w1, pk + P.b1,
             pk + P.waff, pk + P.baff, P.film_rows, nullptr, at<float>(act, L.t[L.film].off)};
@@ -607,12 +656,51 @@ static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, c
   ConvArgs ci{};
   ci.xa = cond; ci.Ca = P.desc.cond_channels;
   ci.xb = x; ci.Cb = P.desc.in_channels;
+  if (dxm == MCEDM_DX_CAT) {         // cat(cond, x, dx): x and dx meet in one staging tensor (the kernels take two sources)
+    float* xdx = at<float>(act, L.t[L.xdx].off);
+    const size_t hw = (size_t)H * W, total = (size_t)B * (P.desc.in_channels + P.desc.dx_channels) * hw;
+    const size_t nb = (total + 255) / 256;
+    hipLaunchKernelGGL(concat_x_dx_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, s, x, dx, P.desc.in_channels,
+                       P.desc.dx_channels, hw, total, xdx);
+    MCEDM_LAUNCH_CHECK("concat_x_dx_kernel");
+    ci.xb = xdx; ci.Cb = P.desc.in_channels + P.desc.dx_channels;
+  }
   ci.coef = coef_in; ci.coef_batch = coef_batch; ci.act = 0;
   ci.Hs = H; ci.Ws = W; ci.H = H; ci.W = W;
   ci.wpk = pk + P.conv_in.wpk; ci.bias = pk + P.conv_in.bias;
   ci.out = at<float>(act, L.t[L.t0].off); ci.Cout = P.conv_in.cout; ci.B = B;
   ci.gsum = at<float>(act, L.t[L.t0].sums); ci.gsum_tiles = &st[L.t0];
+  if (dxm == MCEDM_DX_ENC) { ci.out = at<float>(act, L.t[L.xf].off); ci.gsum = nullptr; ci.gsum_tiles = nullptr; }
   if ((rc = launch_conv(ci, 9, s))) return rc;
+  if (dxm == MCEDM_DX_ENC) {
+    // x_feat = combine_enc(cat(conv_in(.), dx_enc(dx))), dx_enc = Conv3x3 -> GELU -> Conv3x3; dx None: zero features, NOT
+    // dx_enc(0) (adm_blocks.py:352-362)
+    const int c0 = P.conv_in.cout;
+    float* d2 = at<float>(act, L.t[L.d2].off);
+    auto plain = [&](const ConvP& cv, const float* xa, int Ca, const float* xb, int Cb, float* o) {
+      ConvArgs c{};
+      c.xa = xa; c.Ca = Ca; c.xb = xb; c.Cb = Cb;
+      c.Hs = H; c.Ws = W; c.H = H; c.W = W;
+      c.wpk = pk + cv.wpk; c.bias = pk + cv.bias;
+      c.wino = cv.wino != NONE ? pk + cv.wino : nullptr;
+      c.out = o; c.Cout = cv.cout; c.B = B;
+      return c;
+    };
+    if (dx) {
+      float* d1 = at<float>(act, L.t[L.d1].off);
+      float* g1 = at<float>(act, L.t[L.g1].off);
+      ConvArgs ca = plain(P.dx_enc0, dx, P.desc.dx_channels, nullptr, 0, d1);
+      if ((rc = launch_conv(ca, 9, s))) return rc;
+      if ((rc = launch_gelu(d1, nullptr, g1, (size_t)B * c0 * H * W, 0, s))) return rc;
+      ConvArgs cb = plain(P.dx_enc2, g1, c0, nullptr, 0, d2);
+      if ((rc = launch_conv(cb, 9, s))) return rc;
+    } else {
+      MCEDM_HIP_TRY(hipMemsetAsync(d2, 0, L.t[L.d2].bytes, s));
+    }
+    ConvArgs cc = plain(P.combine, at<float>(act, L.t[L.xf].off), c0, d2, c0, at<float>(act, L.t[L.t0].off));
+    cc.gsum = at<float>(act, L.t[L.t0].sums); cc.gsum_tiles = &st[L.t0];
+    if ((rc = launch_conv(cc, 9, s))) return rc;
+  }
   size_t bi = 0;
   for (const BlockP& b : P.enc) if ((rc = run_block(P, b, L.blocks[bi++], L, act, pk, B, n_noise, s, st))) return rc;
   for (const BlockP& b : P.dec) if ((rc = run_block(P, b, L.blocks[bi++], L, act, pk, B, n_noise, s, st))) return rc;
@@ -632,15 +720,15 @@ static int forward_impl(const mcedm_plan& P, const Layout& L, const float* pk, c
   return launch_conv(co, 9, s);
 }
 
-__global__ void scale_to_coef_kernel(const float* __restrict__ x_scale, int n, int cond_ch, int in_ch, Coef* out) {
+__global__ void scale_to_coef_kernel(const float* __restrict__ x_scale, int n, int cond_ch, int in_ch, int dx_ch, Coef* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int Ct = cond_ch + in_ch;
-  for (int c = 0; c < Ct; ++c) out[(size_t)i * Ct + c] = Coef{0.f, c < cond_ch ? 1.0f : x_scale[i], 0.f, 0.f};
+  const int Ct = cond_ch + in_ch + dx_ch;
+  for (int c = 0; c < Ct; ++c) out[(size_t)i * Ct + c] = Coef{0.f, (c < cond_ch || c >= cond_ch + in_ch) ? 1.0f : x_scale[i], 0.f, 0.f};
 }
 
 // D = c_skip x + c_out F(c_in x; ln(sigma)/4; cond) with sigma from the device (n_sigma rows) or from the host
-static int denoise_impl(const mcedm_plan& P, const Layout& L, const Header& hd, const float* pk, const float* x,
+static int denoise_impl(const mcedm_plan& P, const Layout& L, const Header& hd, const float* pk, const float* x, const float* dx,
                         const float* sigma_dev, float sigma_host, int use_host, int n_sigma, const float* cond,
                         float w, float* D_out, float* F_out, void* ws, int B, int H, int W, float sigma_data,
                         hipStream_t s) {
@@ -651,12 +739,15 @@ static int denoise_impl(const mcedm_plan& P, const Layout& L, const Header& hd, 
   float* Fbuf = at<float>(ws, hd.F);
   void* act = at<char>(ws, hd.total);
   if ((rc = launch_precond_prepare(sigma_dev, sigma_host, use_host, n_sigma, sigma_data, P.desc.cond_channels,
-                                   P.desc.in_channels, coefs4, c_noise, coef_in, s))) return rc;
-  if ((rc = forward_impl(P, L, pk, x, cond, coef_in, n_sigma > 1 ? 1 : 0, c_noise, n_sigma, Fbuf, act, B, H, W, s))) return rc;
+                                   P.desc.in_channels, P.desc.dx_mode == MCEDM_DX_CAT ? P.desc.dx_channels : 0, coefs4, c_noise,
+                                   coef_in, s))) return rc;
+  if ((rc = forward_impl(P, L, pk, x, dx, cond, coef_in, n_sigma > 1 ? 1 : 0, c_noise, n_sigma, Fbuf, act, B, H, W, s))) return rc;
   const float* Fu = nullptr;
-  if (fabsf(w) >= 0.001f && cond != nullptr) {      // classifier-free branch, mcedm.py:453-458
+  // classifier-free branch, mcedm.py:453-458; models/ddim.py:1755-1760: taken when cond OR dx is given, and the
+  // unconditional evaluation drops both
+  if (fabsf(w) >= 0.001f && (cond != nullptr || dx != nullptr)) {
     float* Fubuf = at<float>(ws, hd.Fu);
-    if ((rc = forward_impl(P, L, pk, x, nullptr, coef_in, n_sigma > 1 ? 1 : 0, c_noise, n_sigma, Fubuf, act, B, H, W, s))) return rc;
+    if ((rc = forward_impl(P, L, pk, x, nullptr, nullptr, coef_in, n_sigma > 1 ? 1 : 0, c_noise, n_sigma, Fubuf, act, B, H, W, s))) return rc;
     Fu = Fubuf;
   }
   const size_t per = (size_t)P.desc.out_channels * H * W;
@@ -674,11 +765,12 @@ extern "C" int mcedm_unet_workspace_bytes(const mcedm_plan* plan, int B, int H, 
   return MCEDM_OK;
 }
 
-extern "C" int mcedm_unet_forward(const mcedm_plan* plan, const void* packed, const float* x, const float* cond,
-                                  const float* x_scale, const float* noise_labels, int n_noise, float* out,
-                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
-                                  void* stream) {
+extern "C" int mcedm_unet_forward_dx(const mcedm_plan* plan, const void* packed, const float* x, const float* dx, const float* cond,
+                                     const float* x_scale, const float* noise_labels, int n_noise, float* out,
+                                     void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
+                                     void* stream) {
   MCEDM_REQUIRE(plan && packed && x && noise_labels && out && workspace, "unet_forward: null argument");
+  MCEDM_REQUIRE(dx == nullptr || plan->desc.dx_mode != MCEDM_DX_NONE, "unet_forward: dx given to a plan without dx_cond");
   Layout L;
   int rc = build_layout(*plan, B, H, W, training, n_noise, &L);
   if (rc) return rc;
@@ -692,19 +784,29 @@ extern "C" int mcedm_unet_forward(const mcedm_plan* plan, const void* packed, co
   if (x_scale) {
     Coef* c = at<Coef>(workspace, hd.coef_in);
     hipLaunchKernelGGL(scale_to_coef_kernel, dim3(ceil_div(n_noise, 64)), dim3(64), 0, s, x_scale, n_noise,
-                       plan->desc.cond_channels, plan->desc.in_channels, c);
+                       plan->desc.cond_channels, plan->desc.in_channels,
+                       plan->desc.dx_mode == MCEDM_DX_CAT ? plan->desc.dx_channels : 0, c);
     MCEDM_LAUNCH_CHECK("scale_to_coef_kernel");
     coef_in = c;
   }
-  return forward_impl(*plan, L, (const float*)packed, x, cond, coef_in, n_noise > 1 ? 1 : 0, noise_labels, n_noise, out,
+  return forward_impl(*plan, L, (const float*)packed, x, dx, cond, coef_in, n_noise > 1 ? 1 : 0, noise_labels, n_noise, out,
                       at<char>(workspace, hd.total), B, H, W, s);
 }
 
-extern "C" int mcedm_edm_denoise(const mcedm_plan* plan, const void* packed, const float* x, const float* sigma,
-                                 int n_sigma, const float* cond, float* D_out, float* F_out, void* workspace,
-                                 size_t workspace_bytes, int B, int H, int W, int training, double sigma_data,
-                                 void* stream) {
+extern "C" int mcedm_unet_forward(const mcedm_plan* plan, const void* packed, const float* x, const float* cond,
+                                  const float* x_scale, const float* noise_labels, int n_noise, float* out,
+                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
+                                  void* stream) {
+  return mcedm_unet_forward_dx(plan, packed, x, nullptr, cond, x_scale, noise_labels, n_noise, out, workspace, workspace_bytes, B, H,
+                               W, training, stream);
+}
+
+extern "C" int mcedm_edm_denoise_dx(const mcedm_plan* plan, const void* packed, const float* x, const float* dx, const float* sigma,
+                                    int n_sigma, const float* cond, float* D_out, float* F_out, void* workspace,
+                                    size_t workspace_bytes, int B, int H, int W, int training, double sigma_data,
+                                    void* stream) {
   MCEDM_REQUIRE(plan && packed && x && sigma && D_out && workspace, "edm_denoise: null argument");
+  MCEDM_REQUIRE(dx == nullptr || plan->desc.dx_mode != MCEDM_DX_NONE, "edm_denoise: dx given to a plan without dx_cond");
   Layout L;
   int rc = build_layout(*plan, B, H, W, training, n_sigma, &L);
   if (rc) return rc;
@@ -713,8 +815,16 @@ extern "C" int mcedm_edm_denoise(const mcedm_plan* plan, const void* packed, con
     set_error("edm_denoise: workspace too small (%zu < %zu bytes)", workspace_bytes, hd.total + L.total_bytes);
     return MCEDM_ERR_WORKSPACE;
   }
-  return denoise_impl(*plan, L, hd, (const float*)packed, x, sigma, 0.f, 0, n_sigma, cond, 0.f, D_out, F_out, workspace,
+  return denoise_impl(*plan, L, hd, (const float*)packed, x, dx, sigma, 0.f, 0, n_sigma, cond, 0.f, D_out, F_out, workspace,
                       B, H, W, (float)sigma_data, (hipStream_t)stream);
+}
+
+extern "C" int mcedm_edm_denoise(const mcedm_plan* plan, const void* packed, const float* x, const float* sigma,
+                                 int n_sigma, const float* cond, float* D_out, float* F_out, void* workspace,
+                                 size_t workspace_bytes, int B, int H, int W, int training, double sigma_data,
+                                 void* stream) {
+  return mcedm_edm_denoise_dx(plan, packed, x, nullptr, sigma, n_sigma, cond, D_out, F_out, workspace, workspace_bytes, B, H, W,
+                              training, sigma_data, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -733,7 +843,7 @@ extern "C" int mcedm_edm_t_steps(const mcedm_sampler_desc* sp, double* t) {
 }
 
 namespace mcedm {
-struct SamplerBufs { size_t x, xn, d, x32, D, dx, g, total; };
+struct SamplerBufs { size_t x, xn, d, x32, D, dx, g, dxin, total; };
 static SamplerBufs sampler_bufs(const mcedm_plan& P, int B, int H, int W) {
   SamplerBufs s;
   size_t cur = 0;
@@ -741,6 +851,7 @@ static SamplerBufs sampler_bufs(const mcedm_plan& P, int B, int H, int W) {
   const size_t n = (size_t)B * P.desc.in_channels * H * W;
   s.x = take(n * 8); s.xn = take(n * 8); s.d = take(n * 8); s.x32 = take(n * 4); s.D = take(n * 4);
   s.dx = take(n * 4); s.g = take(n * 4);          // PDE guidance: gradient and the Darcy interior scratch
+  s.dxin = take(n * 4);                           // dx_cond: the network's dx input
   s.total = cur;
   return s;
 }
@@ -759,6 +870,7 @@ namespace mcedm {
 // dx = get_dx_log_prob(h, denoised, guide_dx) of the single-task models (models/ddim.py:641-650 -> get_dx_pde :1424-1450):
 // the residual of x_unnorm = (h from the conditioning, u = the denoised state), differentiated w.r.t. x_unnorm, then the
 // MEAN over the two field gradients (calc_prob=True) -> [B, 1, H, W]
+// (the same call on the current noisy state instead of D is get_dx_input(h, x) with dx_norm == 'prob', ddim.py:601-613)
 static int guidance_dx(const mcedm_plan& P, const mcedm_guidance_desc& g, const float* cond, const float* D, float* dx,
                        float* scratch, int B, int H, int W, hipStream_t s) {
   GuideIO io{};
@@ -778,7 +890,8 @@ static int guidance_dx(const mcedm_plan& P, const mcedm_guidance_desc& g, const 
 static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
                             const float* cond, const float* mask, const float* init_noise,
                             const double* step_noise, double* out, int return_last, void* workspace,
-                            size_t workspace_bytes, int B, int H, int W, const mcedm_guidance_desc* gd, void* stream);
+                            size_t workspace_bytes, int B, int H, int W, const mcedm_guidance_desc* gd, void* stream,
+                            const mcedm_guidance_desc* dxc = nullptr);
 
 extern "C" int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
                                  const float* cond, const float* mask, const float* init_noise,
@@ -800,10 +913,25 @@ extern "C" int mcedm_heun_sample_guided(const mcedm_plan* plan, const void* pack
                           B, H, W, gd, stream);
 }
 
+extern "C" int mcedm_heun_sample_dxcond(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                                        const mcedm_guidance_desc* dxc, const mcedm_guidance_desc* gd, const float* cond,
+                                        const float* init_noise, const double* step_noise, double* out, int return_last,
+                                        void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  MCEDM_REQUIRE(dxc != nullptr && (dxc->system == 1 || dxc->system == 2), "heun_sample_dxcond: dx system must be 1 (SWE) or 2 (Darcy)");
+  MCEDM_REQUIRE(gd == nullptr || gd->system == 1 || gd->system == 2, "heun_sample_dxcond: guidance system must be 1 (SWE) or 2 (Darcy)");
+  MCEDM_REQUIRE(plan && plan->desc.dx_mode != MCEDM_DX_NONE && plan->desc.dx_channels == 1 && plan->desc.in_channels == 1 &&
+                    plan->desc.cond_channels >= 1 && cond != nullptr,
+                "heun_sample_dxcond: needs a dx_cond plan of the single-task model (state u, conditioning h in cond[:, 0], one dx "
+                "channel), models/ddim.py:1424-1450, 1532-1601");
+  return heun_sample_impl(plan, packed, sp, cond, nullptr, init_noise, step_noise, out, return_last, workspace, workspace_bytes,
+                          B, H, W, gd, stream, dxc);
+}
+
 static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
                             const float* cond, const float* mask, const float* init_noise,
                             const double* step_noise, double* out, int return_last, void* workspace,
-                            size_t workspace_bytes, int B, int H, int W, const mcedm_guidance_desc* gd, void* stream) {
+                            size_t workspace_bytes, int B, int H, int W, const mcedm_guidance_desc* gd, void* stream,
+                            const mcedm_guidance_desc* dxc) {
   MCEDM_REQUIRE(plan && packed && sp && init_noise && out && workspace, "heun_sample: null argument");
   const mcedm_plan& P = *plan;
   MCEDM_REQUIRE(P.desc.in_channels == P.desc.out_channels, "heun_sample: in_channels != out_channels");
@@ -851,8 +979,13 @@ static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mc
       const double c = std::sqrt(t_hat * t_hat - t_cur * t_cur) * sp->S_noise;
       if ((rc = launch_heun_churn(x, step_noise + (size_t)i * total, mask, c, total, x32, s))) return rc;
     }
-    // Euler step (mcedm.py:611-618)
-    if ((rc = denoise_impl(P, L, hd, pk, x32, nullptr, (float)t_hat, 1, 1, cond, w, D, nullptr, uws, B, H, W, sd, s))) return rc;
+    // Euler step (mcedm.py:611-618); dx_cond: dx_in = get_dx_input(h, x_hat) first (ddim.py:1571)
+    float* dxin = nullptr;
+    if (dxc) {
+      dxin = at<float>(workspace, sb.dxin);
+      if ((rc = guidance_dx(P, *dxc, cond, x32, dxin, at<float>(workspace, sb.g), B, H, W, s))) return rc;
+    }
+    if ((rc = denoise_impl(P, L, hd, pk, x32, dxin, nullptr, (float)t_hat, 1, 1, cond, w, D, nullptr, uws, B, H, W, sd, s))) return rc;
     const float* dxg = nullptr;
     const float wgt = gd ? (float)gd->weight : 0.f;
     if (gd) {
@@ -862,7 +995,8 @@ static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mc
     if ((rc = launch_heun_euler(x, D, mask, t_hat, t_next - t_hat, total, dcur, xn, x32, s, dxg, wgt, (float)t_hat))) return rc;
     // 2nd-order correction (mcedm.py:621-628)
     if (i < N - 1) {
-      if ((rc = denoise_impl(P, L, hd, pk, x32, nullptr, (float)t_next, 1, 1, cond, w, D, nullptr, uws, B, H, W, sd, s))) return rc;
+      if (dxc && (rc = guidance_dx(P, *dxc, cond, x32, dxin, at<float>(workspace, sb.g), B, H, W, s))) return rc;   // on x_next (ddim.py:1584)
+      if ((rc = denoise_impl(P, L, hd, pk, x32, dxin, nullptr, (float)t_next, 1, 1, cond, w, D, nullptr, uws, B, H, W, sd, s))) return rc;
       if (gd && (rc = guidance_dx(P, *gd, cond, D, at<float>(workspace, sb.dx), at<float>(workspace, sb.g), B, H, W, s))) return rc;
       if ((rc = launch_heun_correct(x, dcur, D, mask, t_next, t_next - t_hat, total, xn, x32, s, dxg, wgt, (float)t_hat))) return rc;
     }

@@ -99,6 +99,9 @@ struct Layout {
   std::vector<TRef> t;         // all tensors
   std::vector<BlockLayout> blocks;   // encoder blocks then decoder blocks
   int film = -1, t0 = -1, coef_out = -1, stats_out = -1, last = -1;
+  // dx_cond head (adm_blocks.py:334-362): cat(x, dx) staging buffer (MCEDM_DX_CAT); conv_in output, dx_enc.0 output, its
+  // GELU, dx_enc.2 output in front of combine_enc, whose output is then t0 (MCEDM_DX_ENC)
+  int xdx = -1, xf = -1, d1 = -1, g1 = -1, d2 = -1;
   size_t sums_base = 0, sums_bytes = 0;   // arena of all fused-statistics tables
   size_t total_bytes = 0;
 };
@@ -109,6 +112,7 @@ struct mcedm_plan {
   mcedm_unet_desc desc;
   std::vector<mcedm::ParamInfo> params;
   mcedm::ConvP conv_in, conv_out;
+  mcedm::ConvP dx_enc0, dx_enc2, combine;      // MCEDM_DX_ENC only (adm_blocks.py:266-280)
   mcedm::NormP out_norm;
   std::vector<mcedm::BlockP> enc, dec;
   int map0_w = -1, map0_b = -1, map1_w = -1, map1_b = -1;

@@ -132,9 +132,19 @@ class PlCondEdm(_EvalMetrics, _Base):
         super().__init__()
         self.save_hyperparameters()
         m, o, d, df = hparams.model, hparams.optimization, hparams.data, hparams.diffusion
-        for flag in ("dx_cond", "node_type", "self_cond"):
+        for flag in ("node_type", "self_cond"):
             if hasattr(m, flag) and getattr(m, flag):
                 raise NotImplementedError(f"hparams.model.{flag}=True is outside the MI355X hot path")
+        # dx_cond (models/ddim.py:33-35): the network also sees the PDE-residual gradient at its input state.  For the
+        # single-task model only dx_norm == 'prob' can run in the reference -- get_dx_pde (:1424-1450) returns a 3-D tensor
+        # with calc_prob=False and get_dx_input (:601-639) fails to unpack it (pinned: tests/golden/dxcond.npz
+        # 'dx_norm_l2_raises') -- so the other normalisations raise here as well
+        self.dx_cond = bool(m.dx_cond) if hasattr(m, "dx_cond") else False
+        self.dx_norm = m.dx_norm if hasattr(m, "dx_norm") else "l2"
+        self.dx_detach = m.dx_detach if hasattr(m, "dx_detach") else False
+        if self.dx_cond and self.dx_norm != "prob":
+            raise NotImplementedError(f"dx_cond with dx_norm={self.dx_norm!r}: PlCondEdm.get_dx_input raises in the reference for "
+                                      "every dx_norm other than 'prob' (models/ddim.py:608-611, 1445-1448)")
         if not str(hparams.name).startswith("adm"):
             raise NotImplementedError("only the ADM/EDM U-Net (hparams.name = 'adm*') is on the hot path")
         # DDPM schedule buffers of PlDdim (kept for checkpoint compatibility; the EDM path never reads them)
@@ -149,7 +159,7 @@ class PlCondEdm(_EvalMetrics, _Base):
         elif m.var_type == "fixedsmall":
             self.register_buffer("logvar", post_var.clamp(min=1e-20).log())
         self.cond_p = m.cond_p if hasattr(m, "cond_p") else 0.8
-        self.dx_cond = self.node_type = False
+        self.node_type = False
         self.model = DhariwalUNet(hparams)
         self.ema_model = EmaModel(self.model, beta=m.ema_rate) if m.ema else None
         self.normalization, self.rescaled = d.normalization, d.rescaled
@@ -246,27 +256,36 @@ class PlCondEdm(_EvalMetrics, _Base):
             off += p.numel()
         return views
 
+    def _dx_arg(self, net, dx):
+        if dx is None:
+            return None
+        if not net.dx_cond:
+            raise NotImplementedError("dx given to a network built with dx_cond=False (the reference ignores it silently)")
+        return dx.to(torch.float32).contiguous()
+
     def model_precond(self, x_noise, sigma, cond=None, x_self_cond=None, dx=None):
-        if x_self_cond is not None or dx is not None:
-            raise NotImplementedError("x_self_cond / dx are outside the hot path")
+        if x_self_cond is not None:
+            raise NotImplementedError("x_self_cond is outside the hot path")
         net = self.model
         with torch.no_grad():
             return net.plan.denoise(net.packed_weights(), x_noise.float().contiguous(),
                                     sigma.to(torch.float32).reshape(-1).contiguous(),
                                     cond=None if cond is None else cond.float().contiguous(), ws=net._ws,
-                                    sigma_data=self.sigma_data)
+                                    sigma_data=self.sigma_data, dx=self._dx_arg(net, dx))
 
     def get_denoised(self, model, xt, t, cond=None, x_self_cond=None, dx=None, w=None):
-        if x_self_cond is not None or dx is not None:
-            raise NotImplementedError("x_self_cond / dx are outside the hot path")
+        if x_self_cond is not None:
+            raise NotImplementedError("x_self_cond is outside the hot path")
         net = self._net(model)
         xt = xt.to(torch.float32).contiguous()
         sigma = torch.as_tensor(t).to(torch.float32).reshape(-1).contiguous().to(xt.device)
         cond = None if cond is None else cond.float().contiguous()
+        dx = self._dx_arg(net, dx)
         pk = net.packed_weights()
         with torch.no_grad():
-            D, F = net.plan.denoise(pk, xt, sigma, cond=cond, ws=net._ws, sigma_data=self.sigma_data, want_F=True)
-            if not (w is None or abs(w) < 0.001 or cond is None):
+            D, F = net.plan.denoise(pk, xt, sigma, cond=cond, ws=net._ws, sigma_data=self.sigma_data, want_F=True, dx=dx)
+            # models/ddim.py:1755-1760: the branch is taken when cond OR dx is given; its second evaluation drops both
+            if not (w is None or abs(w) < 0.001 or (cond is None and dx is None)):
                 _, Fu = net.plan.denoise(pk, xt, sigma, cond=None, ws=net._ws, sigma_data=self.sigma_data, want_F=True)
                 F = (w + 1) * F - w * Fu
                 s = sigma.reshape(-1, 1, 1, 1)
@@ -284,8 +303,11 @@ class PlCondEdm(_EvalMetrics, _Base):
         noise = torch.randn_like(u)
         rnd_normal = torch.randn([u.shape[0], 1, 1, 1]).type_as(u)
         u_noise, sigma = _lib.edm_noise_inputs(u, None, noise, rnd_normal.reshape(-1).contiguous(), self.P_mean, self.P_std)
-        torch.rand(1)                                            # the cond_p draw of models/ddim.py:1675 (cond_p = 1)
-        loss = _EdmTrainLoss.apply(self, u, u_noise, sigma, cond_in, None, *self.model.parameters())
+        dx = None
+        if self.dx_cond and torch.rand(1) > 0.1:                 # models/ddim.py:1672-1677: dx off with a small probability
+            dx = self.get_dx_input(cond_in[:, 0:self.h_ch], u_noise)     # on the NOISED target; carries no gradient
+        torch.rand(1)                                            # the cond_p draw of models/ddim.py:1683 (cond_p = 1)
+        loss = _EdmTrainLoss.apply(self, u, u_noise, sigma, cond_in, None, dx, *self.model.parameters())
         self.log("train_loss", loss, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
         return loss
 
@@ -300,6 +322,13 @@ class PlCondEdm(_EvalMetrics, _Base):
         d = self.pde_loss(x_un, x_un, self.normalizer_input, self.normalizer_target, True, calc_prob).permute(0, 3, 1, 2)
         return torch.mean(d, dim=1, keepdim=True) if calc_prob else torch.sum(d, dim=1)
 
+    def get_dx_input(self, cond, x_denoised):
+        """models/ddim.py:601-639 with dx_norm == 'prob' (see __init__): the log-probability residual gradient itself.  The
+        reference's NaN test never fires: both residual classes zero the NaNs of the gradient they return."""
+        if not self.dx_cond:
+            return None
+        return self.get_dx_pde(cond, x_denoised, calc_prob=True).contiguous()
+
     def get_dx_log_prob(self, cond, x_denoised, guide_dx):
         """models/ddim.py:641-650 (the residual classes already zero the NaNs of the gradient)."""
         if not guide_dx:
@@ -310,13 +339,16 @@ class PlCondEdm(_EvalMetrics, _Base):
         """h, u_noise in the reference's 'b h w c' layout; returns [b, t, h, w, c] float64 (models/ddim.py:1532-1601).
         guide_dx=True: after every denoiser call d -= 5 * dx / t_hat with dx the PDE-residual gradient, evaluated on the
         device by the stencils' analytic adjoints (csrc/pde.hip) instead of torch.autograd."""
-        guidance = None
-        if guide_dx:
+        guidance = dx_input = None
+        if guide_dx or self.dx_cond:
             if self.pde_loss is None or not hasattr(self.pde_loss, "guidance_desc"):
-                raise NotImplementedError("guide_dx=True needs set_pde_loss_function('swe' | 'swe_per' | 'darcy')")
+                raise NotImplementedError("guide_dx / dx_cond need set_pde_loss_function('swe' | 'swe_per' | 'darcy')")
             if self.rescaled or self.normalization == "min_max" or self.h_ch != 1 or self.u_ch != 1:
-                raise NotImplementedError("guide_dx=True is built for scalar gauss-normalised fields h, u")
-            guidance = self.pde_loss.guidance_desc(self.normalizer_input, self.normalizer_target, h.shape[1], h.shape[2])
+                raise NotImplementedError("guide_dx / dx_cond are built for scalar gauss-normalised fields h, u")
+            gdesc = self.pde_loss.guidance_desc(self.normalizer_input, self.normalizer_target, h.shape[1], h.shape[2])
+            guidance = gdesc if guide_dx else None
+            # dx_cond: dx_in = get_dx_input(h, x) on the current noisy state before every denoiser call (:1571, :1584)
+            dx_input = gdesc if self.dx_cond else None
         net = self._net(self.ema_model if self.ema_model is not None else self.model)
         h, init = _nchw(h).float(), _nchw(u_noise).float()
         sd = _lib.sampler_desc(sparams, self.sigma_data, self.sigma_min, self.sigma_max)
@@ -326,8 +358,8 @@ class PlCondEdm(_EvalMetrics, _Base):
         with torch.no_grad():
             packed = net.packed_weights()
             eager = lambda c, m_, i, sn: net.plan.sample(packed, sd, c, None, i, sn, return_last=return_last, ws=self._sample_ws,
-                                                         guidance=guidance)
-            if guidance is not None or os.environ.get("MCEDM_HIP_GRAPH", "1") == "0":
+                                                         guidance=guidance, dx_input=dx_input)
+            if guidance is not None or dx_input is not None or os.environ.get("MCEDM_HIP_GRAPH", "1") == "0":
                 return eager(h, None, init, step_noise)
             # the unguided call replays from one HIP graph, like PlMcedm.sample_edm (the evaluation loops repeat it)
             B, _, H, W = init.shape

@@ -30,6 +30,7 @@ EXPORTS = [
     "mcedm_ddpm_denoise", "mcedm_repaint_schedule", "mcedm_repaint_workspace_bytes", "mcedm_repaint_sample",
     "mcedm_repaint_sample_rng", "mcedm_normal_fill", "mcedm_ddpm_forward_sc", "mcedm_ddim_workspace_bytes",
     "mcedm_ddim_repaint_sample",
+    "mcedm_unet_forward_dx", "mcedm_edm_denoise_dx", "mcedm_edm_denoise_backward_dx", "mcedm_heun_sample_dxcond",
 ]
 
 
@@ -37,7 +38,11 @@ class UNetDesc(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("cond_channels", C.c_int32), ("out_channels", C.c_int32),
                 ("ch", C.c_int32), ("n_levels", C.c_int32), ("ch_mult", C.c_int32 * MAX_LEVELS),
                 ("num_res_blocks", C.c_int32), ("resolution", C.c_int32), ("n_attn_resolutions", C.c_int32),
-                ("attn_resolutions", C.c_int32 * MAX_LEVELS), ("channels_per_head", C.c_int32), ("eps", C.c_float)]
+                ("attn_resolutions", C.c_int32 * MAX_LEVELS), ("channels_per_head", C.c_int32), ("eps", C.c_float),
+                ("dx_channels", C.c_int32), ("dx_mode", C.c_int32)]
+
+
+DX_NONE, DX_CAT, DX_ENC = 0, 1, 2      # MCEDM_DX_* (include/mcedm_hip.h)
 
 
 class SamplerDesc(C.Structure):
@@ -113,6 +118,14 @@ def load() -> C.CDLL:
                                                         vp, sz, i32, i32, i32, C.c_double, i32, C.POINTER(C.c_int32),
                                                         C.POINTER(vp), vp]
     lib.mcedm_unet_grad_buckets.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+    lib.mcedm_unet_forward_dx.argtypes = [vp, vp, f32p, f32p, f32p, f32p, f32p, i32, f32p, vp, sz, i32, i32, i32, i32, vp]
+    lib.mcedm_edm_denoise_dx.argtypes = [vp, vp, f32p, f32p, f32p, i32, f32p, f32p, f32p, vp, sz, i32, i32, i32, i32,
+                                         C.c_double, vp]
+    lib.mcedm_edm_denoise_backward_dx.argtypes = [vp, vp, C.POINTER(vp), f32p, f32p, f32p, i32, f32p, f32p, C.POINTER(vp),
+                                                  vp, sz, i32, i32, i32, C.c_double, i32, C.POINTER(C.c_int32),
+                                                  C.POINTER(vp), vp]
+    lib.mcedm_heun_sample_dxcond.argtypes = [vp, vp, C.POINTER(SamplerDesc), C.POINTER(GuidanceDesc), C.POINTER(GuidanceDesc),
+                                             f32p, f32p, f64p, f64p, i32, vp, sz, i32, i32, i32, vp]
     lib.mcedm_sqnorm.argtypes = [f32p, sz, f64p, vp]
     lib.mcedm_adam_ema_step.argtypes = [f32p, f32p, f32p, f32p, f32p, sz, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_double, f64p, C.c_double, C.c_double, C.c_double, C.c_int64, vp]
@@ -204,7 +217,7 @@ class Plan:
 
     def __init__(self, in_channels: int, cond_channels: int, out_channels: int, ch: int, ch_mult: Sequence[int],
                  num_res_blocks: int, attn_resolutions: Sequence[int], resolution: int, channels_per_head: int = 64,
-                 eps: float = 1e-5):
+                 eps: float = 1e-5, dx_channels: int = 0, dx_mode: int = DX_NONE):
         lib = load()
         if len(ch_mult) > MAX_LEVELS or len(attn_resolutions) > MAX_LEVELS:
             raise RuntimeError("too many levels / attention resolutions")
@@ -218,6 +231,8 @@ class Plan:
         for i, r in enumerate(attn_resolutions):
             d.attn_resolutions[i] = int(r)
         d.channels_per_head, d.eps = channels_per_head, eps
+        d.dx_channels, d.dx_mode = int(dx_channels), int(dx_mode)
+        self.dx_channels, self.dx_mode = int(dx_channels), int(dx_mode)
         self.desc = d
         h = C.c_void_p()
         check(lib.mcedm_unet_plan_create(C.byref(d), C.byref(h)), "plan_create")
@@ -269,30 +284,40 @@ class Plan:
         return sz.value
 
     # ---- compute ---------------------------------------------------------------------------
+    def _check_dx(self, x, dx):
+        if dx is None:
+            return
+        if self.dx_mode == DX_NONE:
+            raise RuntimeError("dx given to a plan without dx_cond")
+        if tuple(dx.shape) != (x.shape[0], self.dx_channels, x.shape[2], x.shape[3]) or dx.dtype != torch.float32:
+            raise RuntimeError(f"dx must be fp32 [B, {self.dx_channels}, H, W], got {tuple(dx.shape)} {dx.dtype}")
+
     def forward(self, packed, x, noise_labels, cond=None, x_scale=None, ws: Optional[Workspace] = None,
-                training: bool = False) -> torch.Tensor:
+                training: bool = False, dx=None) -> torch.Tensor:
+        self._check_dx(x, dx)
         B, _, H, W = x.shape
         n_noise = noise_labels.numel()
         ws = ws or Workspace()
         need = self.workspace_bytes(B, H, W, training)
         buf = ws.get(need, x.device)
         out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
-        check(self._lib.mcedm_unet_forward(self._h, packed.data_ptr(), _ptr(x), _ptr(cond), _ptr(x_scale),
-                                           _ptr(noise_labels), n_noise, _ptr(out), buf.data_ptr(), buf.numel(), B, H, W,
-                                           int(training), _stream()), "unet_forward")
+        check(self._lib.mcedm_unet_forward_dx(self._h, packed.data_ptr(), _ptr(x), _ptr(dx), _ptr(cond), _ptr(x_scale),
+                                              _ptr(noise_labels), n_noise, _ptr(out), buf.data_ptr(), buf.numel(), B, H, W,
+                                              int(training), _stream()), "unet_forward")
         return out
 
     def denoise(self, packed, x, sigma, cond=None, ws: Optional[Workspace] = None, training: bool = False,
-                sigma_data: float = 1.0, want_F: bool = False):
+                sigma_data: float = 1.0, want_F: bool = False, dx=None):
+        self._check_dx(x, dx)
         B, _, H, W = x.shape
         n_sigma = sigma.numel()
         ws = ws or Workspace()
         buf = ws.get(self.workspace_bytes(B, H, W, training), x.device)
         D = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         F = torch.empty_like(D) if want_F else None
-        check(self._lib.mcedm_edm_denoise(self._h, packed.data_ptr(), _ptr(x), _ptr(sigma), n_sigma, _ptr(cond), _ptr(D),
-                                          _ptr(F), buf.data_ptr(), buf.numel(), B, H, W, int(training), float(sigma_data),
-                                          _stream()), "edm_denoise")
+        check(self._lib.mcedm_edm_denoise_dx(self._h, packed.data_ptr(), _ptr(x), _ptr(dx), _ptr(sigma), n_sigma, _ptr(cond),
+                                             _ptr(D), _ptr(F), buf.data_ptr(), buf.numel(), B, H, W, int(training),
+                                             float(sigma_data), _stream()), "edm_denoise")
         return (D, F) if want_F else D
 
     def grad_buckets(self, max_buckets: int) -> List[int]:
@@ -304,13 +329,20 @@ class Plan:
 
     def denoise_backward(self, packed, params: Dict[str, torch.Tensor], x, sigma, cond, dD, grads: Sequence[torch.Tensor],
                          ws: Workspace, sigma_data: float = 1.0, bucket_first: Optional[Sequence[int]] = None,
-                         bucket_events: Optional[Sequence[torch.cuda.Event]] = None) -> None:
+                         bucket_events: Optional[Sequence[torch.cuda.Event]] = None, dx=None) -> None:
         """Backward of denoise(..., training=True) on the SAME workspace: grads[i] <- dLoss/dparam_i (overwritten).
         With bucket_first / bucket_events the library records event k once every parameter >= bucket_first[k] is done."""
+        self._check_dx(x, dx)
         B, _, H, W = x.shape
         buf = ws.get(self.workspace_bytes(B, H, W, True), x.device)
         parr = (C.c_void_p * len(self.param_names))(*[_ptr(params[n].detach()) for n in self.param_names])
         garr = (C.c_void_p * len(self.param_names))(*[_ptr(g) for g in grads])
+        if dx is not None and bucket_first is None:
+            check(self._lib.mcedm_edm_denoise_backward_dx(self._h, packed.data_ptr(), parr, _ptr(x), _ptr(dx), _ptr(sigma),
+                                                          sigma.numel(), _ptr(cond), _ptr(dD), garr, buf.data_ptr(), buf.numel(),
+                                                          B, H, W, float(sigma_data), 0, None, None, _stream()),
+                  "edm_denoise_backward_dx")
+            return
         if bucket_first is None:
             check(self._lib.mcedm_edm_denoise_backward(self._h, packed.data_ptr(), parr, _ptr(x), _ptr(sigma), sigma.numel(),
                                                        _ptr(cond), _ptr(dD), garr, buf.data_ptr(), buf.numel(), B, H, W,
@@ -322,14 +354,15 @@ class Plan:
         if len(handles) != nb or not all(handles):
             raise RuntimeError("denoise_backward: one created (recorded at least once) torch.cuda.Event per bucket is needed")
         evs = (C.c_void_p * nb)(*handles)
-        check(self._lib.mcedm_edm_denoise_backward_bucketed(self._h, packed.data_ptr(), parr, _ptr(x), _ptr(sigma),
-                                                            sigma.numel(), _ptr(cond), _ptr(dD), garr, buf.data_ptr(),
-                                                            buf.numel(), B, H, W, float(sigma_data), nb, firsts, evs,
-                                                            _stream()), "edm_denoise_backward_bucketed")
+        check(self._lib.mcedm_edm_denoise_backward_dx(self._h, packed.data_ptr(), parr, _ptr(x), _ptr(dx), _ptr(sigma),
+                                                      sigma.numel(), _ptr(cond), _ptr(dD), garr, buf.data_ptr(),
+                                                      buf.numel(), B, H, W, float(sigma_data), nb, firsts, evs,
+                                                      _stream()), "edm_denoise_backward_dx")
 
     def sample(self, packed, sd: SamplerDesc, cond, mask, init_noise, step_noise=None, return_last: bool = True,
                ws: Optional[Workspace] = None, out: Optional[torch.Tensor] = None,
-               guidance: Optional["GuidanceDesc"] = None) -> torch.Tensor:
+               guidance: Optional["GuidanceDesc"] = None, dx_input: Optional["GuidanceDesc"] = None) -> torch.Tensor:
+        """dx_input: the residual whose gradient at the current state is the network's dx input (dx_cond plans)."""
         B, _, H, W = init_noise.shape
         ws = ws or Workspace()
         buf = ws.get(self.sampler_workspace_bytes(B, H, W), init_noise.device)
@@ -338,6 +371,15 @@ class Plan:
             out = torch.empty((B, T, H, W, self.in_channels), dtype=torch.float64, device=init_noise.device)
         elif tuple(out.shape) != (B, T, H, W, self.in_channels):
             raise RuntimeError(f"sample: out has shape {tuple(out.shape)}, expected {(B, T, H, W, self.in_channels)}")
+        if dx_input is not None:
+            if mask is not None:
+                raise RuntimeError("sample: dx_cond sampling is the unmasked single-task sampler")
+            check(self._lib.mcedm_heun_sample_dxcond(self._h, packed.data_ptr(), C.byref(sd), C.byref(dx_input),
+                                                     C.byref(guidance) if guidance is not None else None, _ptr(cond),
+                                                     _ptr(init_noise), _ptr(step_noise, torch.float64), _ptr(out, torch.float64),
+                                                     int(return_last), buf.data_ptr(), buf.numel(), B, H, W, _stream()),
+                  "heun_sample_dxcond")
+            return out
         if guidance is not None:
             check(self._lib.mcedm_heun_sample_guided(self._h, packed.data_ptr(), C.byref(sd), C.byref(guidance), _ptr(cond),
                                                      _ptr(mask), _ptr(init_noise), _ptr(step_noise, torch.float64),

@@ -11,7 +11,9 @@ Deliberate differences, all documented in INTEGRATION.md:
   * sample_edm draws the per-step churn noise only for steps with gamma > 0 (the reference draws and
     multiplies by zero otherwise, mcedm.py:608), so device RNG streams differ for S_churn = 0;
   * guide_dx=True raises: the reference's joint-model guidance hook itself raises (models/mcedm.py:500-518 slices the
-    wrong axis); PDE guidance runs on the device for the single-task sampler (mcedm_amd.ddim.PlCondEdm).  dx_cond is not built.
+    wrong axis); PDE guidance runs on the device for the single-task sampler (mcedm_amd.ddim.PlCondEdm).  dx_cond of the JOINT
+    model goes through the same failing hook in the reference (get_dx_input -> get_dx_pde, models/mcedm.py:519-526), so it is
+    rejected here; the dx-conditioned network itself is built and runs for the single-task model (mcedm_amd.ddim.PlCondEdm).
 """
 from __future__ import annotations
 
@@ -82,16 +84,17 @@ class _EdmTrainLoss(torch.autograd.Function):
     Parameters enter as inputs so that Lightning's automatic optimisation and DDP see ordinary .grad tensors."""
 
     @staticmethod
-    def forward(ctx, module, x, x_noise, sigma, cond, mask, *params):
+    def forward(ctx, module, x, x_noise, sigma, cond, mask, dx, *params):
         net: DhariwalUNet = module.model
         plan, packed = net.plan, net.packed_weights()
         B, _, H, W = x.shape
         ws = module._train_ws
-        D = plan.denoise(packed, x_noise, sigma, cond=cond, ws=ws, training=True, sigma_data=module.sigma_data)
+        # dx: the network's PDE-gradient input of dx_cond models (PlCondEdm.training_step) or None; no gradient flows into it
+        D = plan.denoise(packed, x_noise, sigma, cond=cond, ws=ws, training=True, sigma_data=module.sigma_data, dx=dx)
         loss, dD = _lib.edm_loss(D, x, mask, sigma, sigma_data=module.sigma_data, want_grad=True)
         # the activations of THIS forward live in the module's single training workspace until its backward runs
         module._train_generation += 1
-        ctx.module, ctx.saved, ctx.generation = module, (x_noise, sigma, cond, dD), module._train_generation
+        ctx.module, ctx.saved, ctx.generation = module, (x_noise, sigma, cond, dD, dx), module._train_generation
         return loss.reshape(())
 
     @staticmethod
@@ -101,11 +104,11 @@ class _EdmTrainLoss(torch.autograd.Function):
         if ctx.generation != module._train_generation:
             raise RuntimeError("training_step: another training forward overwrote this one's activations before its "
                                "backward ran (one outstanding forward per module; run backward before the next forward)")
-        x_noise, sigma, cond, dD = ctx.saved
+        x_noise, sigma, cond, dD, dx = ctx.saved
         params = list(net.parameters())
         grads = module._grad_views(params)
         net.plan.denoise_backward(net.packed_weights(), net.named_param_dict(), x_noise, sigma, cond, dD, grads,
-                                  ws=module._train_ws, sigma_data=module.sigma_data)
+                                  ws=module._train_ws, sigma_data=module.sigma_data, dx=dx)
         # one scale of the flat buffer into a FRESH tensor (autograd may keep the returned views as .grad, so they
         # must not alias the buffer the next backward overwrites) instead of one multiply per parameter
         flat = module._grad_buf * g.to(torch.float32)
@@ -113,7 +116,7 @@ class _EdmTrainLoss(torch.autograd.Function):
         for p in params:
             out.append(flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
-        return (None, None, None, None, None, None) + tuple(out)
+        return (None, None, None, None, None, None, None) + tuple(out)
 
 
 class PlMcedm(_Base):
@@ -293,7 +296,7 @@ class PlMcedm(_Base):
         mask_c = _nchw(mask).to(torch.float32)
         x_noise, sigma = _lib.edm_noise_inputs(x, mask_c, noise, rnd_normal.reshape(-1).contiguous(), self.P_mean, self.P_std)
         torch.rand(1)                                                      # the cond_p draw of mcedm.py:231 (cond_p = 1: never drops)
-        loss = _EdmTrainLoss.apply(self, x, x_noise, sigma, cond_in, mask_c, *self.model.parameters())
+        loss = _EdmTrainLoss.apply(self, x, x_noise, sigma, cond_in, mask_c, None, *self.model.parameters())
         self.log("train_loss", loss, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
         return loss
 

@@ -366,3 +366,20 @@ def ddim_inputs(tag: str, B: int = REPAINT_B):
     init = randn(f"ddim/{tag}/init", B, 2, S, S)
     eta = [torch.from_numpy(_rng(f"ddim/{tag}/eta{i}").random(size=(B, 2, S, S)).astype(np.float32)) for i in range(max(N, 8))]
     return h, u, init, eta
+
+
+# ---- dx_cond (second clause): the network conditioned on the PDE-residual gradient ------------
+def dxcond_net_inputs(B: int = 3, H: int = 32, W: int = 32):
+    """x, cond, dx [B, 1, H, W] and sigma [B] for DhariwalUNet.forward(..., dx=dx) / get_denoised of the single-task model."""
+    x = randn("dxcond/x", B, 1, H, W)
+    cond = randn("dxcond/cond", B, 1, H, W)
+    dx = randn("dxcond/dx", B, 1, H, W) * 0.7
+    sigma = torch.tensor([0.3, 2.0, 11.0], dtype=torch.float32)[:B]
+    return x, cond, dx, sigma
+
+
+DXCOND_GRAD_NAMES = {
+    "cat": ["enc.128x128_conv.weight", "enc.128x128_conv.bias", "out_conv.weight", "map_layer1.weight", "dec.32x32_in0.qkv.weight"],
+    "enc": ["dx_enc.0.weight", "dx_enc.0.bias", "dx_enc.2.weight", "dx_enc.2.bias", "combine_enc.weight", "combine_enc.bias",
+            "enc.128x128_conv.weight", "out_conv.weight"],
+}

@@ -46,6 +46,10 @@ class UNetConfig:
     resolution: int = 128
     channels_per_head: int = 64
     eps: float = 1e-5
+    # dx_cond (adm_blocks.py:233-238, 266-280): channels of the dx input (= hparams.model.in_channels) and how it enters:
+    # "cat" (cat_dx=True: concatenated to conv_in's input) or "enc" (dx_enc + combine_enc); 0 / "" = dx_cond False
+    dx_channels: int = 0
+    dx_mode: str = ""
 
 
 @dataclass
@@ -139,8 +143,12 @@ def param_shapes(cfg: UNetConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     out: List[Tuple[str, Tuple[int, ...]]] = []
     out += [("map_layer0.weight", (emb, ch)), ("map_layer0.bias", (emb,)),
             ("map_layer1.weight", (emb, emb)), ("map_layer1.bias", (emb,))]
-    in_total = cfg.in_channels + cfg.cond_channels
+    in_total = cfg.in_channels + cfg.cond_channels + (cfg.dx_channels if cfg.dx_mode == "cat" else 0)   # adm_blocks.py:238
     c0 = ch * cfg.ch_mult[0]
+    if cfg.dx_mode == "enc":      # registered before self.enc (adm_blocks.py:266-280)
+        out += [("dx_enc.0.weight", (c0, cfg.dx_channels, 3, 3)), ("dx_enc.0.bias", (c0,)),
+                ("dx_enc.2.weight", (c0, c0, 3, 3)), ("dx_enc.2.bias", (c0,)),
+                ("combine_enc.weight", (c0, 2 * c0, 3, 3)), ("combine_enc.bias", (c0,))]
     # ModuleDict order: conv_in first, then encoder blocks in creation order
     out += [(f"{spec.conv_in_key}.weight", (c0, in_total, 3, 3)), (f"{spec.conv_in_key}.bias", (c0,))]
     for b in spec.enc:
@@ -267,15 +275,25 @@ def noise_embedding(P: Dict[str, Tensor], cfg: UNetConfig, noise_labels: Tensor)
 
 
 def unet_forward(P: Dict[str, Tensor], cfg: UNetConfig, x: Tensor, noise_labels: Tensor,
-                 cond: Optional[Tensor] = None, spec: Optional[UNetSpec] = None) -> Tensor:
-    """DhariwalUNet.forward, adm_blocks.py:364-404 (cat_cond=True; cond_enc/dx_enc/self_cond off)."""
+                 cond: Optional[Tensor] = None, spec: Optional[UNetSpec] = None, dx: Optional[Tensor] = None) -> Tensor:
+    """DhariwalUNet.forward, adm_blocks.py:364-404 (cat_cond=True; cond_enc/self_cond off; dx_cond per cfg.dx_mode)."""
     spec = spec or build_spec(cfg)
     emb = noise_embedding(P, cfg, noise_labels)
+    x_in = x
     if cfg.cond_channels > 0:
         if cond is None:                                 # adm_blocks.py:328-331
             cond = torch.zeros((x.shape[0], cfg.cond_channels) + tuple(x.shape[2:]), dtype=x.dtype)
         x = torch.cat((cond, x), dim=1)                  # cond FIRST (adm_blocks.py:332)
+    if cfg.dx_mode == "cat":                             # adm_blocks.py:335-339: dx LAST, zeros when None
+        x = torch.cat((x, torch.zeros_like(x_in[:, :cfg.dx_channels]) if dx is None else dx), dim=1)
     x = conv2d(x, P[f"{spec.conv_in_key}.weight"], P[f"{spec.conv_in_key}.bias"])
+    if cfg.dx_mode == "enc":                             # adm_blocks.py:352-362
+        if dx is not None:
+            d = conv2d(dx, P["dx_enc.0.weight"], P["dx_enc.0.bias"])
+            d = conv2d(F.gelu(d), P["dx_enc.2.weight"], P["dx_enc.2.bias"])
+        else:
+            d = torch.zeros_like(x)
+        x = conv2d(torch.cat([x, d], dim=1), P["combine_enc.weight"], P["combine_enc.bias"])
     skips = [x]
     for b in spec.enc:
         x = unet_block(P, b, x, emb, cfg.eps)
@@ -307,24 +325,26 @@ def precond_coeffs(sigma: Tensor, sigma_data: float = SIGMA_DATA):
 
 
 def model_precond(P, cfg, x_noise: Tensor, sigma: Tensor, cond: Optional[Tensor] = None,
-                  return_F: bool = False):
+                  return_F: bool = False, dx: Optional[Tensor] = None):
     """PlMcedm.model_precond, mcedm.py:199-211 (== get_denoised, :443-461, with w=0)."""
     sigma = sigma.to(torch.float32).reshape(-1, 1, 1, 1)
     c_skip, c_out, c_in, c_noise = precond_coeffs(sigma)
-    F_x = unet_forward(P, cfg, c_in * x_noise, c_noise.flatten(), cond)
+    F_x = unet_forward(P, cfg, c_in * x_noise, c_noise.flatten(), cond, dx=dx)
     D_x = c_skip * x_noise + c_out * F_x
     return (D_x, F_x) if return_F else D_x
 
 
-def get_denoised(P, cfg, xt: Tensor, t: Tensor, cond: Optional[Tensor] = None, w: Optional[float] = None):
-    """PlMcedm.get_denoised, mcedm.py:443-461 including the classifier-free branch."""
+def get_denoised(P, cfg, xt: Tensor, t: Tensor, cond: Optional[Tensor] = None, w: Optional[float] = None,
+                 dx: Optional[Tensor] = None):
+    """PlMcedm.get_denoised, mcedm.py:443-461 including the classifier-free branch (models/ddim.py:1745-1763 with dx: the
+    branch is taken when cond OR dx is given, and its unconditional evaluation drops both)."""
     xt = xt.to(torch.float32)
     sigma = t.to(torch.float32).reshape(-1, 1, 1, 1)
     c_skip, c_out, c_in, c_noise = precond_coeffs(sigma)
-    if w is None or abs(w) < 0.001 or cond is None:
-        F_x = unet_forward(P, cfg, c_in * xt, c_noise.flatten(), cond)
+    if w is None or abs(w) < 0.001 or (cond is None and dx is None):
+        F_x = unet_forward(P, cfg, c_in * xt, c_noise.flatten(), cond, dx=dx)
     else:
-        F_x = (w + 1) * unet_forward(P, cfg, c_in * xt, c_noise.flatten(), cond) \
+        F_x = (w + 1) * unet_forward(P, cfg, c_in * xt, c_noise.flatten(), cond, dx=dx) \
             - w * unet_forward(P, cfg, c_in * xt, c_noise.flatten(), None)
     D_x = c_skip * xt + c_out * F_x
     return D_x, F_x
@@ -346,12 +366,15 @@ def training_loss(P, cfg, x: Tensor, cond_in: Tensor, mask_c: Tensor, noise: Ten
     return loss_matrix.sum(dim=(1, 2, 3)).mean()
 
 
-def training_loss_cond(P, cfg, u: Tensor, cond_in: Tensor, noise: Tensor, rnd_normal: Tensor) -> Tensor:
+def training_loss_cond(P, cfg, u: Tensor, cond_in: Tensor, noise: Tensor, rnd_normal: Tensor, dx_input=None) -> Tensor:
     """PlCondEdm.training_step (single-task conditional EDM), models/ddim.py:1700-1727 + forward :1661-1687
-    with cond_p = 1, dx_cond False, self_cond False: unmasked noising and loss."""
+    with cond_p = 1, self_cond False: unmasked noising and loss.  dx_input (dx_cond, :1673-1681): callable
+    (h, x_noise) -> dx, evaluated on the NOISED target and carrying no gradient; None = the 10 % branch without dx."""
     sigma = (rnd_normal * P_STD + P_MEAN).exp()
     weight = loss_weight(sigma)
-    D_x = model_precond(P, cfg, u + noise * sigma, sigma.float(), cond_in)
+    x_noise = u + noise * sigma
+    dx = None if dx_input is None else dx_input(cond_in, x_noise).detach()
+    D_x = model_precond(P, cfg, x_noise, sigma.float(), cond_in, dx=dx)
     return (weight * (D_x - u) ** 2).sum(dim=(1, 2, 3)).mean()
 
 
@@ -401,10 +424,13 @@ def guidance_dx_cond(system: str, h: Tensor, denoised: Tensor, norm_stats) -> Te
 
 
 def sample_edm_cond(P, cfg, h: Tensor, sp: SamplerParams, init_noise: Tensor,
-                    step_noise: Optional[Sequence[Tensor]] = None, return_last: bool = True, guidance=None) -> Tensor:
+                    step_noise: Optional[Sequence[Tensor]] = None, return_last: bool = True, guidance=None,
+                    dx_input=None) -> Tensor:
     """PlCondEdm.sample_edm, models/ddim.py:1532-1601 (guide_dx False, no self-conditioning): the unmasked Heun
     sampler; ``h`` [B, cond_ch, H, W] is pure conditioning, ``init_noise`` [B, out_ch, H, W].
-    ``guidance`` (guide_dx=True): callable (h, denoised[f64]) -> dx [B, 1, H, W] fp32, see guidance_dx_cond."""
+    ``guidance`` (guide_dx=True): callable (h, denoised[f64]) -> dx [B, 1, H, W] fp32, see guidance_dx_cond.
+    ``dx_input`` (dx_cond models, ddim.py:1571, 1584): callable (h, x[f64]) -> the network's dx input, evaluated on the
+    current NOISY state before each denoiser call (get_dx_input with dx_norm='prob' == guidance_dx_cond)."""
     N = sp.timesteps
     t_steps = edm_t_steps(N, sp.sigma_min, sp.sigma_max, sp.rho)
     x_next = init_noise.to(torch.float64) * t_steps[0]
@@ -415,13 +441,15 @@ def sample_edm_cond(P, cfg, h: Tensor, sp: SamplerParams, init_noise: Tensor,
         t_hat = t_cur + gamma * t_cur
         eps_i = step_noise[i] if step_noise is not None else torch.zeros_like(x_next)
         x_hat = x_next + (t_hat ** 2 - t_cur ** 2).sqrt() * sp.S_noise * eps_i
-        denoised = get_denoised(P, cfg, x_hat, t_hat, cond=h, w=sp.w)[0].to(torch.float64)
+        dxi = None if dx_input is None else dx_input(h, x_hat)
+        denoised = get_denoised(P, cfg, x_hat, t_hat, cond=h, w=sp.w, dx=dxi)[0].to(torch.float64)
         d_cur = (x_hat - denoised) / t_hat
         if guidance is not None:                 # guide_dx: - weight * dx / t_hat, weight = 5 (ddim.py:1577-1579)
             d_cur = d_cur - 5. * guidance(h, denoised) / t_hat
         x_next = x_hat + (t_next - t_hat) * d_cur
         if i < N - 1:
-            denoised = get_denoised(P, cfg, x_next, t_next, cond=h, w=sp.w)[0].to(torch.float64)
+            dxi = None if dx_input is None else dx_input(h, x_next)
+            denoised = get_denoised(P, cfg, x_next, t_next, cond=h, w=sp.w, dx=dxi)[0].to(torch.float64)
             d_prime = (x_next - denoised) / t_next
             if guidance is not None:             # the reference divides by t_hat here too (ddim.py:1590-1591)
                 d_prime = d_prime - 5. * guidance(h, denoised) / t_hat

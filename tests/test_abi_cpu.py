@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     exported = sorted(set(re.findall(r"\bT (mcedm_[a-z0-9_]+)$", nm, flags=re.M)))
     assert exported == names, (set(exported) ^ set(names))
     assert sorted(set(L.EXPORTS + L.OP_EXPORTS)) == names, set(L.EXPORTS + L.OP_EXPORTS) ^ set(names)
-    assert lib.mcedm_version() == 1
+    assert lib.mcedm_version() == 2
 
 
 def test_plan_parameter_table_matches_state_dict_order():
@@ -46,6 +46,21 @@ def test_plan_parameter_table_matches_state_dict_order():
         assert plan.packed_bytes > 4 * sum(int(torch.tensor(s).prod()) for _, s in ref)
         assert plan.workspace_bytes(2, 32, 32) < plan.workspace_bytes(2, 32, 32, training=True)
         assert plan.sampler_workspace_bytes(2, 32, 32) > plan.workspace_bytes(2, 32, 32)
+
+
+def test_dx_cond_plans_list_the_head_parameters_in_state_dict_order():
+    """dx_cond (adm_blocks.py:233-280): cat_dx widens conv_in; dx_enc / combine_enc are registered before self.enc."""
+    import dataclasses
+    for mode, code in (("cat", L.DX_CAT), ("enc", L.DX_ENC)):
+        cfg = dataclasses.replace(orc.UNetConfig(in_channels=1, cond_channels=1, out_ch=1), dx_channels=1, dx_mode=mode)
+        plan = L.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks,
+                      cfg.attn_resolutions, cfg.resolution, dx_channels=1, dx_mode=code)
+        ref = orc.param_shapes(cfg)
+        assert plan.param_names == [n for n, _ in ref] and plan.param_shapes == [tuple(s) for _, s in ref]
+    assert plan.param_names[4:10] == ["dx_enc.0.weight", "dx_enc.0.bias", "dx_enc.2.weight", "dx_enc.2.bias",
+                                      "combine_enc.weight", "combine_enc.bias"]
+    with pytest.raises(RuntimeError, match="dx_channels"):
+        L.Plan(1, 1, 1, 64, (1, 1, 1), 1, (32,), 128, dx_channels=1, dx_mode=L.DX_NONE)
 
 
 def test_t_steps_host_helper_matches_oracle():

@@ -340,3 +340,27 @@ def test_eval_plddim_test_step_with_the_ddim_sampler(golden):
         o = dorc.eval_test_step(P, cfg, h, u, st, dorc.DdimParams(timesteps=N, skip_type=skip, eta=eta, n_repeat=R, n_time_h=nth,
                                                                    n_time_u=ntu), n, system, init)
     assert _check_eval(g, "ddpm_ddim", o) >= 3
+
+
+@pytest.mark.parametrize("mode", ["cat", "enc"])
+def test_dx_cond_network_and_sampler(golden, mode):
+    """dx_cond (second clause): the oracle's dx-conditioned network, classifier-free branch and the
+    single-task sampler with dx_in = get_dx_input(h, x) against the reference's outputs (oracle/make_golden_dxcond.py)."""
+    import dataclasses
+    g = golden("dxcond.npz")
+    cfg = dataclasses.replace(fx.CFG_C, dx_channels=1, dx_mode=mode)
+    P = orc.make_params(cfg, int(g["seed"]))
+    x, cond, dx, sig = fx.dxcond_net_inputs()
+    with torch.no_grad():
+        close(orc.unet_forward(P, cfg, x, sig.log() / 4, cond, dx=dx), g[f"{mode}_F_dx"])
+        close(orc.unet_forward(P, cfg, x, sig.log() / 4, cond, dx=None), g[f"{mode}_F_none"])
+        D, F = orc.get_denoised(P, cfg, x.double(), sig, cond=cond, w=0.5, dx=dx)
+        close(D, g[f"{mode}_D_w"])
+        close(F, g[f"{mode}_F_w"])
+        if mode == "enc":
+            h, u_noise, steps = fx.cond_sampler_inputs("det")
+            st = fx.STEP_NORM_STATS
+            xs = orc.sample_edm_cond(P, cfg, h.permute(0, 3, 1, 2), orc.SamplerParams(), u_noise.permute(0, 3, 1, 2), steps,
+                                     dx_input=lambda hh, d: orc.guidance_dx_cond("swe_per", hh, d, st))
+            ref = torch.as_tensor(g["enc_swe_per_xs_last"])
+            torch.testing.assert_close(xs, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
