@@ -359,15 +359,17 @@ class PlCondEdm(_EvalMetrics, _Base):
             packed = net.packed_weights()
             eager = lambda c, m_, i, sn: net.plan.sample(packed, sd, c, None, i, sn, return_last=return_last, ws=self._sample_ws,
                                                          guidance=guidance, dx_input=dx_input)
-            if guidance is not None or dx_input is not None or os.environ.get("MCEDM_HIP_GRAPH", "1") == "0":
+            if os.environ.get("MCEDM_HIP_GRAPH", "1") == "0":
                 return eager(h, None, init, step_noise)
-            # the unguided call replays from one HIP graph, like PlMcedm.sample_edm (the evaluation loops repeat it)
+            # the call replays from one HIP graph, like PlMcedm.sample_edm (the evaluation loops repeat it); the residual
+            # descriptions of guide_dx / dx_cond are host-side structs, so they are part of the key and of the capture
             B, _, H, W = init.shape
+            dkey = lambda d: None if d is None else tuple(getattr(d, f) for f, _ in d._fields_)      # noqa: E731
             key = (B, H, W, bool(return_last), churn, packed.data_ptr(), init.device.index,
-                   tuple(getattr(sd, f) for f, _ in sd._fields_))
+                   tuple(getattr(sd, f) for f, _ in sd._fields_), dkey(guidance), dkey(dx_input))
             fn = _lib.graphed_or_eager(self._graphs, key, lambda: _lib.GraphedSampler(
                 net.plan, packed, sd, B, H, W, masked=False, has_cond=True, churn=churn, return_last=return_last,
-                ws=self._sample_ws), eager)
+                ws=self._sample_ws, guidance=guidance, dx_input=dx_input), eager)
             out = fn(h, None, init, step_noise)
             return out.clone() if fn is not eager else out
 

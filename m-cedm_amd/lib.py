@@ -616,9 +616,11 @@ class GraphedSampler:
     module are serial on one stream, so one buffer serves both); the instance keeps the buffer it captured with alive."""
 
     def __init__(self, plan: "Plan", packed: torch.Tensor, sd: SamplerDesc, B: int, H: int, W: int, masked: bool = True,
-                 has_cond: bool = True, churn: bool = False, return_last: bool = True, ws: Optional[Workspace] = None):
+                 has_cond: bool = True, churn: bool = False, return_last: bool = True, ws: Optional[Workspace] = None,
+                 guidance: Optional["GuidanceDesc"] = None, dx_input: Optional["GuidanceDesc"] = None):
         dev = packed.device
         self.plan, self.packed, self.sd, self.return_last = plan, packed, sd, return_last
+        self.guidance, self.dx_input = guidance, dx_input      # host-side descriptions, baked into the captured kernel arguments
         C = plan.in_channels
         self.cond = torch.zeros((B, plan.cond_channels, H, W), device=dev) if has_cond else None
         self.mask = torch.zeros((B, C, H, W), device=dev) if masked else None
@@ -631,7 +633,7 @@ class GraphedSampler:
 
     def _run(self):
         self.plan.sample(self.packed, self.sd, self.cond, self.mask, self.init, self.step_noise, self.return_last, self.ws,
-                         out=self.out)
+                         out=self.out, guidance=self.guidance, dx_input=self.dx_input)
 
     def __call__(self, cond, mask, init_noise, step_noise=None) -> torch.Tensor:
         """Returns the instance's static output tensor (overwritten by the next call)."""

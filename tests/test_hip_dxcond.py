@@ -148,3 +148,20 @@ def test_other_dx_norms_are_rejected_like_the_reference(golden):
     hp.model.update(dx_cond=True, cat_dx=True, dx_norm="l2")
     with pytest.raises(NotImplementedError, match="raises in the reference"):
         PlCondEdm(hp)
+
+
+def test_dx_cond_and_guided_sampler_replay_from_a_graph_bit_identically(golden, monkeypatch):
+    """sample_edm of a dx_cond model with guide_dx on top: the HIP-graph replay (default) equals the eager launches bit for
+    bit, and a second replay reproduces the first."""
+    m, _ = make_module("enc", golden, guide_dx=True)
+    st = fx.STEP_NORM_STATS
+    m.normalizer_input.set_stats(torch.tensor(st[0]), torch.tensor(st[1]))
+    m.normalizer_target.set_stats(torch.tensor(st[2]), torch.tensor(st[3]))
+    m.set_pde_loss_function("swe_per", False)
+    h, u_noise, _ = fx.cond_sampler_inputs("det")
+    a = m.sample_edm(h.cuda(), u_noise.cuda(), m.sparams, return_last=True, guide_dx=True)
+    b = m.sample_edm(h.cuda(), u_noise.cuda(), m.sparams, return_last=True, guide_dx=True)
+    assert len(m._graphs) == 1, "the call must have been captured"
+    monkeypatch.setenv("MCEDM_HIP_GRAPH", "0")
+    c = m.sample_edm(h.cuda(), u_noise.cuda(), m.sparams, return_last=True, guide_dx=True)
+    assert torch.equal(a, b) and torch.equal(a, c)
