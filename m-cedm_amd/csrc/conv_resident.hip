@@ -768,9 +768,14 @@ int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream) {
   // ~32 x 32 images (the decoder's skip projections there, launched on their own since conv1 runs on the Winograd kernel):
   // 1024 tiles per 64 samples, two workgroups per CU.  conv_mfma_kernel's <32, 8, 32> tile walks 8-16 chunks of
   // load -> barrier -> MFMA -> barrier with one accumulator block per wave and sits at 28 TFLOP/s there.
-  static int p32 = -1;               // MCEDM_RES_1X1_32: 0 keeps these convs on conv_mfma_kernel (A/B runs)
-  if (p32 < 0) { const char* e = getenv("MCEDM_RES_1X1_32"); p32 = e ? atoi(e) : 1; }
+  static int p32 = -1;               // MCEDM_RES_1X1_32 (A/B runs): 0 keeps these convs on conv_mfma_kernel, 1: 8 x 8-pixel tiles, 2 (default): 8 x 16
+  if (p32 < 0) { const char* e = getenv("MCEDM_RES_1X1_32"); p32 = e ? atoi(e) : 2; }
   if (p32 > 0 && !small && a.W >= 24 && (long long)a.H * a.W <= 1024 && !a.sk_wpk && cout_padded(a.Cout) % 64 == 0) {
+    if (p32 == 2) {              // 8 x 16-pixel tiles: 512 workgroups per 64 samples = ONE round of two per CU (S32 1750 -> 1781 states/s; 8 x 8: two rounds)
+      typedef ResCfg<64, 8, 16, 1, 4, 1, 16> P16;
+      const ResidentPlan pl = resident_plan<P16, false>(a, half_cu, 64);
+      if (pl.pass_c && pl.wide) return launch_resident<P16, RS_NONE>(a, pl, stream);
+    }
     const ResidentPlan pl = resident_plan<P, false>(a, half_cu, 64);
     if (pl.pass_c && pl.wide) return launch_resident<P, RS_NONE>(a, pl, stream);
   }
