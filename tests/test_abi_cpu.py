@@ -95,6 +95,26 @@ def test_host_side_argument_validation():
         plan.forward(torch.zeros(8), torch.zeros(1, 2, 32, 32), torch.zeros(1))
 
 
+def test_dx_entry_points_validate_before_any_launch():
+    """The dx_cond entry points reject a dx tensor / a dx-conditioned sampler on a plan built without dx_cond, and a wrong
+    dx shape, on the host (no GPU in this container: the checks run before anything is enqueued)."""
+    import ctypes as C
+    lib = L.load()
+    plain = L.Plan(1, 1, 1, 64, (1, 1, 1), 1, (32,), 128)
+    x = torch.zeros(1, 1, 32, 32)
+    with pytest.raises(RuntimeError, match="without dx_cond"):
+        plain.denoise(torch.zeros(8), x, torch.ones(1), cond=x, dx=x)
+    dxp = L.Plan(1, 1, 1, 64, (1, 1, 1), 1, (32,), 128, dx_channels=1, dx_mode=L.DX_ENC)
+    with pytest.raises(RuntimeError, match=r"dx must be fp32 \[B, 1, H, W\]"):
+        dxp.denoise(torch.zeros(8), x, torch.ones(1), cond=x, dx=torch.zeros(1, 2, 32, 32))
+    sd = L.sampler_desc(orc.SamplerParams(timesteps=18))
+    gd = L.GuidanceDesc(1, 0.002, 0.03125, 0.0, 0.0, 1.0, 0.0, 1.0, 5.0)
+    one = C.c_void_p(16)          # never dereferenced: the plan check comes first
+    rc = lib.mcedm_heun_sample_dxcond(plain._h, one, C.byref(sd), C.byref(gd), None, one, one, None, one, 1, one, 1 << 30, 1, 32, 32, None)
+    assert rc == -1 and b"dx_cond plan" in lib.mcedm_last_error()
+    assert dxp.workspace_bytes(2, 32, 32) > plain.workspace_bytes(2, 32, 32)      # the head's tensors are in the layout
+
+
 def test_repaint_schedule_and_ddpm_plan_host_side():
     """f1 host pieces: the DDPM parameter table in Model.state_dict() order and the rounded sigma schedule
     (round_sigma of models/ddim.py:949-957 restated as an exact nearest-neighbour search) against the oracle's torch.cdist."""

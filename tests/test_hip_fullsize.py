@@ -218,3 +218,54 @@ def test_ddpm_forward_full_size_against_oracle(ddpm_net):
     with torch.no_grad():
         ref = dorc.model_forward(P, CFG_D128, x, torch.tensor([417.0]))
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-5 * max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("mode", ["cat", "enc"])
+def test_dx_conditioned_network_at_full_size(mode):
+    """dx_cond (second clause) at the BASELINE config-4 size (single-task Darcy model: 1 + 1 -> 1 channels,
+    ch = 128, 128 x 128): the dx-conditioned sampler is reproducible bit for bit; dx = zeros is dx = None exactly in the cat_dx
+    form and differs from it in the dx_enc form (zero FEATURES, not dx_enc(0)); the training backward returns finite gradients
+    for every parameter, non-zero for the dx head.  (NOT batch-shard invariant, by the reference's own definition: dx is the
+    gradient of the residual's MEAN over the whole batch, models/pde_loss.py:231-236, so it scales with 1 / B -- a sharded call
+    sees twice the dx of the unsharded one, exactly like one DDP rank of the reference; checked below.)"""
+    import dataclasses
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd import lib
+    cfg = dataclasses.replace(CFG, in_channels=1, cond_channels=1, out_ch=1, dx_channels=1, dx_mode=mode)
+    plan = lib.Plan(1, 1, 1, cfg.ch, cfg.ch_mult, cfg.num_res_blocks, cfg.attn_resolutions, cfg.resolution, dx_channels=1,
+                    dx_mode=lib.DX_CAT if mode == "cat" else lib.DX_ENC)
+    P = {k: v.cuda() for k, v in orc.make_params(cfg, 11).items()}
+    assert plan.param_names == list(P)
+    packed = plan.pack(P)
+    B = 8
+    g = torch.Generator().manual_seed(5)
+    cond = (torch.randn(B, 1, H, W, generator=g) * 0.3).cuda()
+    init = torch.randn(B, 1, H, W, generator=g).cuda()
+    sd = lib.sampler_desc(orc.SamplerParams(timesteps=3))
+    # Darcy residual of (a = cond * 0.05 + 1.4, u = x * 0.1): the statistics of fx.STEP_NORM_STATS
+    gd = lib.GuidanceDesc(2, 0.0, 0.0, float(torch.tensor(2 * (1.0 / H), dtype=torch.float32)), 1.4, 0.05, 0.0, 0.1, 5.0)
+    full = plan.sample(packed, sd, cond, None, init, None, dx_input=gd)
+    again = plan.sample(packed, sd, cond, None, init, None, dx_input=gd)
+    halves = [plan.sample(packed, sd, cond[s].contiguous(), None, init[s].contiguous(), None, dx_input=gd) for s in (slice(0, 4), slice(4, 8))]
+    assert torch.equal(full, again) and bool(torch.isfinite(full).all())
+    assert float((full - torch.cat(halves)).abs().max()) > 0 and all(bool(torch.isfinite(h_).all()) for h_ in halves)      # 1 / B in the batch-mean gradient
+    plain = plan.sample(packed, sd, cond, None, init, None)                   # the same network without its dx input
+    assert float((plain - full).abs().max()) > 0
+    # network level: dx = zeros against dx = None
+    x, sig = init * 0.5, torch.full((B,), 0.7, device="cuda")
+    z = torch.zeros_like(x)
+    D0, Dz = plan.denoise(packed, x, sig, cond=cond), plan.denoise(packed, x, sig, cond=cond, dx=z)
+    assert torch.equal(D0, Dz) if mode == "cat" else float((D0 - Dz).abs().max()) > 1e-6
+    # training: forward that keeps the activations + backward with dx
+    dx = torch.randn(B, 1, H, W, generator=g).cuda() * 0.5
+    ws = lib.Workspace()
+    D = plan.denoise(packed, x, sig, cond=cond, ws=ws, training=True, dx=dx)
+    assert torch.allclose(D, plan.denoise(packed, x, sig, cond=cond, dx=dx), rtol=1e-5, atol=1e-5)
+    grads = [torch.full_like(P[n], float("nan")) for n in plan.param_names]
+    plan.denoise_backward(packed, P, x, sig, cond, torch.ones_like(D), grads, ws=ws, dx=dx)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(g_).all()) for g_ in grads)
+    if mode == "enc":
+        for n, g_ in zip(plan.param_names, grads):
+            if n.startswith(("dx_enc.", "combine_enc.")):
+                assert float(g_.abs().max()) > 0, n
