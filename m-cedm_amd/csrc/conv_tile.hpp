@@ -247,7 +247,9 @@ __device__ __forceinline__ void store_input(const ConvArgs& p, const TileGeom<C,
 // (InputRegs::raw, element 4 it + e = pixel e of this thread's quad in channel wave + 4 it), same LDS image, same values.
 template <class C>
 struct Vec4Geom {
-  static constexpr bool OK = C::TAPS == 1 && C::MT == 128 && C::PW == 32 && C::PLANE == 256 && C::NT == 256 && C::KCI % 4 == 0;   // the 128-channel tile only: the smaller ones run three workgroups per CU on 168 registers and would spill with two staging paths
+  // the 128- and 64-channel tiles (the 64-channel one runs three workgroups per CU on 168 registers: 13 instead of 6 spilled
+  // registers with the second staging path, outside the chunk loop; ref128 179.4 -> 182.8 states/s, repaint128 6.16 -> 6.30)
+  static constexpr bool OK = C::TAPS == 1 && (C::MT == 128 || C::MT == 64) && C::PW == 32 && C::PLANE == 256 && C::NT == 256 && C::KCI % 4 == 0;
   unsigned off;     // byte offset of the quad inside a channel plane
   unsigned keep;    // all-ones: inside the image
 };
