@@ -64,6 +64,7 @@ WORKLOADS = {
 REPAINT = dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32, n_repeat=32, n_time_h=0, n_time_u=64,
                name="SWE dam-break 128x128 RePaint (n_time_h=0, n_time_u=64, 32 resample loops/step), DDPM U-Net ch=64 "
                     "(BASELINE config 5)")
+TRAIN_LEG_TIMEOUT_S = 300      # watchdog of the multi-rank training leg (an untimed extra of the line)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
 STEPS = 18                      # Heun steps -> 2*18 - 1 = 35 U-Net evaluations per state
@@ -438,10 +439,28 @@ def main():
     prof = run.profile(args.profile_steps) if rank == 0 else []
     fwd_ms = run.fwd_ms()
 
+    def headline_line(train_ms_):
+        states = B * world * args.steps
+        return {
+            "metric": "denoised_states_per_sec_18step_edm_heun", "value": states / elapsed, "unit": "states/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "states_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
+                       "sampler": (f"EDM Heun + RePaint, 18 steps x {wl['n_repeat']} resampling loops, {run.nfe} NFE/state, S_churn=0, "
+                                   "re-noising draws generated on the device (Philox), fp64 state / fp32 net") if repaint else
+                                  "EDM Heun, 18 steps, 35 NFE/state, S_churn=0, w=0, fp64 state / fp32 net",
+                       "parallelism": f"batch-sharded x{world}, no data-path collective",
+                       "launch": "eager" if args.no_graph else "one HIP graph per sampler call"},
+            "timed_with_profiler": False, "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B, "train_step_ms": train_ms_,
+            "train_samples_per_sec": (B * world / (train_ms_ * 1e-3)) if train_ms_ else None,
+            "roofline": roofline_of(prof), "kernels": kernel_table(prof)[:8], "csrc_digest": csrc_digest(),
+        }
+
     # one data-parallel training step (models/mcedm.py:254-281 + clip/Adam/EMA), outside the timed region:
     # noise -> denoise(training) -> loss -> backward -> gradient all-reduce -> fused clip+Adam+EMA
-    train_ms, train_prof = None, None
-    if not args.no_train:
+    train_ms, train_prof, train_error = None, None, None
+
+    def train_leg():
         from mcedm_amd.train import FlatTrainState
         ts = FlatTrainState(run.plan, run.params, packed=run.packed)
         gen = torch.Generator(device="cpu").manual_seed(7 + rank)
@@ -455,9 +474,9 @@ def main():
         for _ in range(nt):
             loss = ts.step(xs, run.cond, run.mask, nz, rn)
         barrier()
-        train_ms = (time.perf_counter() - t1) / nt * 1e3
+        ms = (time.perf_counter() - t1) / nt * 1e3
         assert torch.isfinite(loss).all()
-        train_prof = None
+        tp = None
         if world == 1:            # one more step, launched eagerly with HIP event pairs around every kernel (single rank
                                   # only: a step contains the gradient all-reduce, which every rank must enter)
             ts.use_graph = False
@@ -467,30 +486,44 @@ def main():
             ts.step(xs, run.cond, run.mask, nz, rn)
             torch.cuda.synchronize()
             lib.prof_enable(False)
-            train_prof = lib.prof_report()
+            tp = lib.prof_report()
         del ts
+        return ms, tp
+
+    if not args.no_train:
+        if world == 1:
+            train_ms, train_prof = train_leg()
+        else:
+            # The multi-rank step (bucketed RCCL all-reduce on a side stream under the backward) is an untimed extra of this
+            # line: neither an exception nor a stuck collective in it may take the headline measurement with it.  A watchdog
+            # ends every rank after TRAIN_LEG_TIMEOUT_S; rank 0 first prints the line it has (train fields null, train_error set).
+            import threading
+            emergency = {"line": None}
+
+            def bail():
+                if rank == 0 and emergency["line"] is not None:
+                    print(json.dumps(dict(emergency["line"], train_error=f"multi-rank training leg exceeded {TRAIN_LEG_TIMEOUT_S} s")), flush=True)
+                os._exit(0 if rank != 0 or emergency["line"] is not None else 1)
+
+            if rank == 0:
+                emergency["line"] = headline_line(None)
+            dog = threading.Timer(TRAIN_LEG_TIMEOUT_S, bail)
+            dog.daemon = True
+            dog.start()
+            try:
+                train_ms, train_prof = train_leg()
+            except Exception as e:      # noqa: BLE001  (reported in the line; the sampler measurement stands)
+                train_error = f"{type(e).__name__}: {str(e)[:300]}"
+            dog.cancel()
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    states = B * world * args.steps
-    value = states / elapsed
-    line = {
-        "metric": "denoised_states_per_sec_18step_edm_heun", "value": value, "unit": "states/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl["name"], "states_per_gpu": B, "global_batch": B * world, "H": H, "W": W,
-                   "sampler": (f"EDM Heun + RePaint, 18 steps x {wl['n_repeat']} resampling loops, {run.nfe} NFE/state, S_churn=0, "
-                               "re-noising draws generated on the device (Philox), fp64 state / fp32 net") if repaint else
-                              "EDM Heun, 18 steps, 35 NFE/state, S_churn=0, w=0, fp64 state / fp32 net",
-                   "parallelism": f"batch-sharded x{world}, no data-path collective",
-                   "launch": "eager" if args.no_graph else "one HIP graph per sampler call"},
-        "timed_with_profiler": False, "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B, "train_step_ms": train_ms,
-        "train_samples_per_sec": (B * world / (train_ms * 1e-3)) if train_ms else None,
-        "roofline": roofline_of(prof), "kernels": kernel_table(prof)[:8], "csrc_digest": csrc_digest(),
-    }
+    line = headline_line(train_ms)
+    if train_error:
+        line["train_error"] = train_error
     if train_ms and train_prof:
         tflops = sum(r["flops"] for r in train_prof)           # forward + data-gradient + weight-gradient GEMM flops
         dom = sorted(train_prof, key=lambda r: -r["total_ms"])[:3]
@@ -564,7 +597,7 @@ def main():
         args.no_cpu_baseline = True      # the CPU leg is defined on the headline workloads
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(wl, {k: v.cpu() for k, v in run.params.items()})
-        line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
