@@ -208,6 +208,56 @@ class FlatTrainState:
         g.replay()
         return loss
 
+    # ---- checkpoint / resume (configs/callbacks/callbacks_ddim.yaml:1-10, run.py:68-72): the optimiser half -------------
+    def optimizer_state_dict(self) -> dict:
+        """The Adam state in ``torch.optim.Adam.state_dict()`` form -- what Lightning stores as
+        ``checkpoint['optimizer_states'][0]`` for ``configure_optimizers`` (models/mcedm.py:139-161): per-parameter ``step``,
+        ``exp_avg``, ``exp_avg_sq`` in ``model.parameters()`` order (= the plan's parameter table) and one param group.  A run
+        of the fused trainer can therefore be resumed by the reference's Lightning loop and vice versa."""
+        names = self.plan.param_names
+        shapes = [self.pviews[n] for n in names]
+        state = {}
+        if self.step_count > 0:
+            for i, (m, v) in enumerate(zip(views_like(self.flat_m, shapes), views_like(self.flat_v, shapes))):
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+        hp = self.hp
+        group = {"lr": hp["lr"], "betas": (hp["beta1"], hp["beta2"]), "eps": hp["eps"], "weight_decay": hp["weight_decay"],
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        """Inverse of optimizer_state_dict: accepts the ``optimizer_states[0]`` entry of a reference checkpoint (one param
+        group over ``model.parameters()``, no amsgrad).  Hyper-parameters of the group (lr, betas, eps, weight decay) are taken
+        over; an empty state resets the moments."""
+        names = self.plan.param_names
+        groups = sd["param_groups"]
+        if len(groups) != 1 or list(groups[0]["params"]) != list(range(len(names))):
+            raise RuntimeError("optimizer state: expected one param group over model.parameters() in registration order")
+        g = groups[0]
+        if g.get("amsgrad", False):
+            raise NotImplementedError("amsgrad state (the reference configures amsgrad=False, configs/model/*.yaml)")
+        self.hp.update(lr=float(g["lr"]), beta1=float(g["betas"][0]), beta2=float(g["betas"][1]), eps=float(g["eps"]),
+                       weight_decay=float(g["weight_decay"]))
+        state = sd["state"]
+        if not state:
+            self.flat_m.zero_(); self.flat_v.zero_(); self.step_count = 0
+            return
+        if sorted(int(k) for k in state) != list(range(len(names))):
+            raise RuntimeError("optimizer state: every parameter needs an entry")
+        shapes = [self.pviews[n] for n in names]
+        steps = set()
+        with torch.no_grad():
+            for i, (m, v) in enumerate(zip(views_like(self.flat_m, shapes), views_like(self.flat_v, shapes))):
+                e = state[i] if i in state else state[str(i)]
+                if tuple(e["exp_avg"].shape) != tuple(m.shape):
+                    raise RuntimeError(f"optimizer state of parameter {names[i]}: shape {tuple(e['exp_avg'].shape)} != {tuple(m.shape)}")
+                m.copy_(e["exp_avg"]); v.copy_(e["exp_avg_sq"])
+                steps.add(int(float(e["step"])))
+        if len(steps) != 1:
+            raise RuntimeError(f"optimizer state: parameters disagree on the step count ({sorted(steps)})")
+        self.step_count = steps.pop()
+
     def step(self, x, cond_in, mask, noise, rnd_normal):
         """One optimisation step on this rank's shard (all tensors NCHW fp32 on the device). Returns the local loss (a
         tensor that the next step overwrites when the step is graph-replayed)."""

@@ -134,3 +134,37 @@ def test_training_step_autograd_and_fused_trainer(module, golden, monkeypatch):
         F1 = m.model(x, torch.tensor([0.3]).cuda(), cond)
         Pn = {k: v.detach().cpu() for k, v in new_p.items()}
         close(F1, orc.unet_forward(Pn, fx.CFG_P, x.cpu(), torch.tensor([0.3]), cond.cpu()))
+
+
+def test_fused_trainer_resumes_bit_for_bit_from_a_checkpoint(module):
+    """Checkpoint / resume (configs/callbacks/callbacks_ddim.yaml:1-10, run.py:68-72) for the fused trainer: module
+    state_dict (weights + EMA copy) and the Adam state in torch.optim.Adam form after step 1, loaded into a FRESH module and
+    trainer; step 2 from there equals step 2 of the uninterrupted run bit for bit (the step is bitwise reproducible)."""
+    import copy
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd.mcedm import PlMcedm
+    from mcedm_amd.train import EdmTrainer
+    m, _ = module
+    h, u, mask, cond_noise, noise, rnd_normal = fx.training_inputs()
+    xc, cond_in, mc = (t.cuda() for t in fx.training_nchw(h, u, mask, cond_noise))
+    nz, rn = noise.cuda(), rnd_normal.cuda()
+    tr = EdmTrainer(m)
+    tr.step(xc, cond_in, mc, nz, rn)
+    ckpt = {"state_dict": copy.deepcopy(m.state_dict()), "optimizer_states": [copy.deepcopy(tr.optimizer_state_dict())]}
+    tr.step(xc, cond_in, mc, nz * 0.5, rn)
+    want = {k: v.clone() for k, v in m.state_dict().items()}
+    # resume
+    m2 = PlMcedm(hparams(fx.CFG_P)).cuda()
+    m2.load_state_dict(ckpt["state_dict"], strict=True)
+    tr2 = EdmTrainer(m2)
+    tr2.load_optimizer_state_dict(ckpt["optimizer_states"][0])
+    assert tr2.step_count == 1
+    tr2.step(xc, cond_in, mc, nz * 0.5, rn)
+    got = m2.state_dict()
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    # the exported state is what torch's own Adam accepts for the same parameter list
+    opt = torch.optim.Adam(m2.model.parameters(), lr=1.0)
+    opt.load_state_dict(tr2.optimizer_state_dict())
+    assert float(opt.state[next(iter(m2.model.parameters()))]["step"]) == 2

@@ -108,3 +108,50 @@ def test_two_rank_bucketed_allreduce_clip_adam_equals_full_batch_step():
     assert len(firsts) >= 2 and firsts[-1] == 0 and all(a > b for a, b in zip(firsts, firsts[1:])), firsts
     assert clip_ref < 0.9 and abs(clip - clip_ref) < 1e-5 * clip_ref, (clip, clip_ref)     # the clip really was active
     assert err_p < 5e-7 and err_e < 5e-9, (err_p, err_e)       # one fp32 ulp of O(1) parameters
+
+
+def test_fused_trainer_optimizer_state_round_trips_through_torch_adam():
+    """Checkpoint / resume of the fused trainer: its Adam state exports as a torch.optim.Adam state_dict
+    (what Lightning stores as checkpoint['optimizer_states'][0] for models/mcedm.py:139-161) that torch's own Adam loads, and
+    the state of a torch Adam that has taken steps loads back into the flat buffers, hyper-parameters included."""
+    sys.path.insert(0, ROOT)
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd import lib as L
+    from mcedm_amd.train import FlatTrainState
+    from oracle import mcedm_oracle as orc
+    cfg = orc.UNetConfig(ch=32, ch_mult=(1, 1), attn_resolutions=(), resolution=16)
+    P = orc.make_params(cfg, 3)
+    plan = L.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks, cfg.attn_resolutions,
+                  cfg.resolution)
+    ts = FlatTrainState(plan, P, lr=3e-4, beta1=0.8, eps=1e-7)
+    assert ts.optimizer_state_dict()["state"] == {}                       # a fresh optimiser has no state yet
+    g = torch.Generator().manual_seed(0)
+    ts.flat_m.copy_(torch.randn(ts.flat_m.shape, generator=g))
+    ts.flat_v.copy_(torch.rand(ts.flat_v.shape, generator=g))
+    ts.step_count = 7
+    sd = ts.optimizer_state_dict()
+    params = [torch.nn.Parameter(P[n].clone()) for n in plan.param_names]
+    opt = torch.optim.Adam(params, lr=1.0)
+    opt.load_state_dict(sd)                                               # torch accepts it as its own
+    grp = opt.param_groups[0]
+    assert (grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"]) == (3e-4, (0.8, 0.999), 1e-7, 0.0)
+    off = 0
+    for i, p in enumerate(params):
+        st = opt.state[p]
+        assert float(st["step"]) == 7
+        torch.testing.assert_close(st["exp_avg"].reshape(-1), ts.flat_m[off:off + p.numel()], rtol=0, atol=0)
+        torch.testing.assert_close(st["exp_avg_sq"].reshape(-1), ts.flat_v[off:off + p.numel()], rtol=0, atol=0)
+        off += p.numel()
+    # a torch Adam that has stepped -> the fused trainer
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g)
+    opt.step()
+    t2 = FlatTrainState(plan, P)
+    t2.load_optimizer_state_dict(opt.state_dict())
+    assert t2.step_count == 8 and t2.hp["lr"] == 3e-4 and t2.hp["beta1"] == 0.8
+    torch.testing.assert_close(t2.flat_m, torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in params]), rtol=0, atol=0)
+    torch.testing.assert_close(t2.flat_v, torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in params]), rtol=0, atol=0)
+    bad = opt.state_dict()
+    bad["state"][3]["step"] = torch.tensor(5.0)
+    with pytest.raises(RuntimeError, match="disagree on the step"):
+        t2.load_optimizer_state_dict(bad)
