@@ -158,17 +158,19 @@ class FlatTrainState:
         self.use_graph = os.environ.get("MCEDM_TRAIN_GRAPH", "1") != "0"
         self._graph = None
 
-    def _forward_backward(self, x, cond_in, mask, noise, rnd_normal):
-        """pack -> noise -> denoise(training) -> loss -> backward into the flat gradient buffer; returns the loss tensor."""
+    def _forward_backward(self, x, cond_in, mask, noise, rnd_normal, dx_fn=None):
+        """pack -> noise -> denoise(training) -> loss -> backward into the flat gradient buffer; returns the loss tensor.
+        dx_fn (dx_cond models, models/ddim.py:1672-1681): callable (cond_in, x_noise) -> the network's dx input (no gradient)."""
         plan = self.plan
         self.packed = plan.pack(self.pviews, self.packed)
         x_noise, sigma = _lib.edm_noise_inputs(x, mask, noise, rnd_normal.reshape(-1).contiguous(), self.P_mean, self.P_std)
-        D = plan.denoise(self.packed, x_noise, sigma, cond=cond_in, ws=self.ws, training=True, sigma_data=self.sigma_data)
+        dx = dx_fn(cond_in, x_noise) if dx_fn is not None else None
+        D = plan.denoise(self.packed, x_noise, sigma, cond=cond_in, ws=self.ws, training=True, sigma_data=self.sigma_data, dx=dx)
         loss, dD = _lib.edm_loss(D, x, mask, sigma, sigma_data=self.sigma_data, want_grad=True)
         multi = self.world > 1             # bucket events only where a side stream waits for them
         plan.denoise_backward(self.packed, self.pviews, x_noise, sigma, cond_in, dD, self.grad_views, self.ws,
                               sigma_data=self.sigma_data, bucket_first=self.sync.bucket_first if multi else None,
-                              bucket_events=self.sync.events if multi else None)
+                              bucket_events=self.sync.events if multi else None, dx=dx)
         return loss
 
     def _graphed_forward_backward(self, x, cond_in, mask, noise, rnd_normal):
@@ -258,13 +260,14 @@ class FlatTrainState:
             raise RuntimeError(f"optimizer state: parameters disagree on the step count ({sorted(steps)})")
         self.step_count = steps.pop()
 
-    def step(self, x, cond_in, mask, noise, rnd_normal):
+    def step(self, x, cond_in, mask, noise, rnd_normal, dx_fn=None):
         """One optimisation step on this rank's shard (all tensors NCHW fp32 on the device). Returns the local loss (a
-        tensor that the next step overwrites when the step is graph-replayed)."""
-        if self.use_graph and self.world == 1 and x.is_cuda:
+        tensor that the next step overwrites when the step is graph-replayed).  dx_fn: see _forward_backward (such steps are
+        launched eagerly: the callable is the caller's code)."""
+        if self.use_graph and self.world == 1 and x.is_cuda and dx_fn is None:
             loss = self._graphed_forward_backward(x, cond_in, mask, noise, rnd_normal)
         else:
-            loss = self._forward_backward(x, cond_in, mask, noise, rnd_normal)
+            loss = self._forward_backward(x, cond_in, mask, noise, rnd_normal, dx_fn)
         self.sync.launch()                 # bucketed sum all-reduce, overlapping the tail of the backward
         self.sync.join()
         self.step_count += 1
@@ -295,8 +298,8 @@ class EdmTrainer(FlatTrainState):
                 for p, v in zip(ema.values(), views_like(self.flat_ema, list(ema.values()))):
                     p.data = v
 
-    def step(self, x, cond_in, mask, noise, rnd_normal):
-        loss = super().step(x, cond_in, mask, noise, rnd_normal)
+    def step(self, x, cond_in, mask, noise, rnd_normal, dx_fn=None):
+        loss = super().step(x, cond_in, mask, noise, rnd_normal, dx_fn)
         # the kernel wrote parameters (and the EMA copy) in place behind autograd's back: drop the modules' packed copies
         self.net.invalidate_packed()
         if self.flat_ema is not None:

@@ -165,3 +165,39 @@ def test_dx_cond_and_guided_sampler_replay_from_a_graph_bit_identically(golden, 
     monkeypatch.setenv("MCEDM_HIP_GRAPH", "0")
     c = m.sample_edm(h.cuda(), u_noise.cuda(), m.sparams, return_last=True, guide_dx=True)
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_trainer_step_with_dx_equals_autograd_plus_adam(golden, monkeypatch, mode):
+    """The fused data-parallel step (mcedm_amd.train.EdmTrainer: flat buffers, fused clip + Adam + EMA) of a dx_cond model:
+    same batch and dx as PlCondEdm.training_step + clip_grad_norm_(1.0) + torch.optim.Adam -> the same parameters."""
+    from mcedm_amd.train import EdmTrainer
+    h, u, noise, rnd_normal = fx.cond_training_inputs()
+    st = fx.TRAIN_NORM_STATS
+
+    def prepared():
+        m, _ = make_module(mode, golden)
+        m.normalizer_input.set_stats(torch.tensor(st[0]), torch.tensor(st[1]))
+        m.normalizer_target.set_stats(torch.tensor(st[2]), torch.tensor(st[3]))
+        m.set_pde_loss_function("swe_per", False)
+        return m
+
+    a = prepared()
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: noise.cuda())
+    monkeypatch.setattr(torch, "randn", lambda *a_, **k: rnd_normal)
+    monkeypatch.setattr(torch, "rand", lambda *a_, **k: torch.tensor([0.5]))
+    loss = a.training_step((h.cuda(), None, None, u.cuda()), 0)
+    monkeypatch.undo()
+    loss.backward()
+    opt = torch.optim.Adam(a.model.parameters(), lr=2e-4)
+    torch.nn.utils.clip_grad_norm_(a.model.parameters(), 1.0)
+    opt.step()
+    b = prepared()
+    tr = EdmTrainer(b)
+    hn = ((h - st[0]) / st[1]).permute(0, 3, 1, 2).contiguous().cuda()
+    un = ((u - st[2]) / st[3]).permute(0, 3, 1, 2).contiguous().cuda()
+    l2 = tr.step(un, hn, None, noise.cuda(), rnd_normal.cuda(), dx_fn=lambda c, xn: b.get_dx_input(c[:, 0:1], xn))
+    close(l2.reshape(()), loss.detach().reshape(()).cpu(), rtol=1e-5, atol=1e-5)
+    pa, pb = dict(a.model.named_parameters()), dict(b.model.named_parameters())
+    for n in pa:
+        close(pb[n], pa[n].detach().cpu(), rtol=1e-4, atol=2e-6)
