@@ -201,3 +201,21 @@ def test_fused_trainer_step_with_dx_equals_autograd_plus_adam(golden, monkeypatc
     pa, pb = dict(a.model.named_parameters()), dict(b.model.named_parameters())
     for n in pa:
         close(pb[n], pa[n].detach().cpu(), rtol=1e-4, atol=2e-6)
+
+
+def test_dx_cond_sampler_on_a_rectangular_grid_against_the_oracle(golden):
+    """T != X (the SWE residual runs along W, its time axis along H): a 4-step dx-conditioned sampler on 2 x 64 x 32 states
+    against the oracle's (no reference golden at this shape; the oracle is pinned on the square cases above)."""
+    m, P = make_module("enc", golden, timesteps=4)
+    st = fx.STEP_NORM_STATS
+    m.normalizer_input.set_stats(torch.tensor(st[0]), torch.tensor(st[1]))
+    m.normalizer_target.set_stats(torch.tensor(st[2]), torch.tensor(st[3]))
+    m.set_pde_loss_function("swe_per", False)
+    B, T, X = 2, 64, 32
+    h, u_noise = fx.randn("dxcond/rect/h", B, T, X, 1), fx.randn("dxcond/rect/u", B, T, X, 1)
+    xs = m.sample_edm(h.cuda(), u_noise.cuda(), m.sparams, return_last=False)
+    with torch.no_grad():
+        xo = orc.sample_edm_cond(P, cfg_of("enc"), h.permute(0, 3, 1, 2), orc.SamplerParams(timesteps=4), u_noise.permute(0, 3, 1, 2),
+                                 None, return_last=False, dx_input=lambda hh, d: orc.guidance_dx_cond("swe_per", hh, d, st))
+    assert tuple(xs.shape) == (B, 5, T, X, 1)
+    close(xs, xo, rtol=1e-4, atol=1e-5 * float(xo.abs().max()))
