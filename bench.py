@@ -398,6 +398,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MCEDM_BENCH_ONE_CARD=1: rehearsal of the N > 1 control flow on a one-GPU box -- every rank on cuda:0, process group over
+    # gloo (RCCL refuses two ranks per device).  Not a measurement: the ranks share the card.
+    one_card = os.environ.get("MCEDM_BENCH_ONE_CARD") == "1"
+    if one_card:
+        local_rank = 0
 
     import torch
     torch.cuda.set_device(local_rank)
@@ -405,7 +410,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI; used only for the barrier / max-reduce
+        if one_card:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)   # RCCL over xGMI; used only for the barrier / max-reduce
 
     import mcedm_amd  # noqa: F401
     from mcedm_amd import lib
