@@ -43,6 +43,7 @@ class UNetDesc(C.Structure):
 
 
 DX_NONE, DX_CAT, DX_ENC = 0, 1, 2      # MCEDM_DX_* (include/mcedm_hip.h)
+ABI_VERSION = 2                        # MCEDM_ABI_VERSION
 
 
 class SamplerDesc(C.Structure):
@@ -92,6 +93,9 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     vp, i32, f32p, f64p, sz = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t
     lib.mcedm_version.restype = C.c_int
+    if lib.mcedm_version() != ABI_VERSION:           # struct layouts below are those of include/mcedm_hip.h at this version
+        raise RuntimeError(f"{LIB_PATH} implements ABI {lib.mcedm_version()}, this binding ABI {ABI_VERSION}: rebuild it with "
+                           "`python m-cedm_amd/build.py`")
     lib.mcedm_last_error.restype = C.c_char_p
     lib.mcedm_unet_plan_create.argtypes = [C.POINTER(UNetDesc), C.POINTER(vp)]
     lib.mcedm_unet_plan_destroy.argtypes = [vp]
