@@ -45,7 +45,7 @@ struct WinoCfg {
   static constexpr int SC = MB_ == 4 ? 2 : 1;          // chunks per stage of the K loop (one barrier per stage)
   static constexpr int CPW = WKC / NW;                  // channels of a chunk that one wave stages: 1 or 2
   static constexpr int TI = 4 / MB_;                    // patch rows (of the four) per thread in the input transform
-  static constexpr int VBUF = SC * 16 * 288, RBUF = SC * WKC * 200;      // floats per stage (VPOS, RPLANE below)
+  static constexpr int VBUF = SC * 16 * 288, RBUF = SC * WKC * 196;      // floats per stage (VPOS, RPLANE below)
   static constexpr int LDS_ROWS_OFF = 2 * VBUF + 2 * RBUF;              // transform rows start here (floats; 16-byte aligned)
   static constexpr int XCH_FLOATS = NW * 16 * 64;                       // epilogue exchange: one round of 16 registers x 64 lanes per wave
   static constexpr int RED_FLOATS = 2 * (MT / 2) * 3 + MT;              // statistics records of the two halves (pairs at most) + the bias row
@@ -53,16 +53,17 @@ struct WinoCfg {
   static_assert(LDS_ROWS_OFF % 4 == 0, "LDS layout");
 };
 constexpr int RROWS = WPH + 2, RPITCH = WPW + 2; // raw tile with halo: 10 x 18
-constexpr int RPLANE = 200;                      // floats between channels of the raw tile (180 used); = 8 mod 64: the eight channels of a
-                                                 // 32-lane group of the transform's ds_read_b64 (bank = dword mod 64) start 8 banks apart
+constexpr int RPLANE = 196;                      // floats between channels of the raw tile (180 used); = 4 mod 32: hipcc merges the transform's two
+                                                 // adjacent 8-byte reads into ds_read2_b64, which banks at dword mod 32 over 16-lane groups = eight
+                                                 // channels x two patch columns x two dwords: channels 4 banks apart cover the 32 banks once
 constexpr int RSUB = (RROWS * RPITCH + 63) / 64; // raw elements per lane and channel: 3
 // V tile of one (chunk, position): [k parity h][patch 32][k-step 4]; the h = 1 block starts at float 144 = 16 mod 32: the
 // transform's dword writes bank at dword mod 32 per 32-lane group (four patch columns x eight channels: 4 ttx + (k >> 1) + 16 (k & 1)
 // covers the 32 banks once); the 16-byte B-fragment reads (dword mod 64, 16-lane groups inside one h half) only need it 16-byte
-// aligned.  (160 and RPLANE 208, the first layout, were 2-way on those writes and on the transform's reads:
+// aligned.  (160 and RPLANE 208, the first layout, were 2-way on those writes and 4-way on the transform's reads:
 // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.48, profiles/r3_s128_mfma_lds_counters.json.)
 constexpr int VH1 = 144, VPOS = 288;
-static_assert(RPLANE % 64 == 8 && VH1 % 32 == 16 && VH1 >= 128 && VPOS >= VH1 + 128 && RPLANE >= RROWS * RPITCH && RPLANE % 2 == 0 && VPOS % 4 == 0 && VH1 % 4 == 0, "LDS layout");
+static_assert(RPLANE % 32 == 4 && VH1 % 32 == 16 && VH1 >= 128 && VPOS >= VH1 + 128 && RPLANE >= RROWS * RPITCH && RPLANE % 2 == 0 && VPOS % 4 == 0 && VH1 % 4 == 0, "LDS layout");
 
 
 // U = G g G^T for one (cout, cin): G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
