@@ -404,6 +404,19 @@ __device__ __forceinline__ void conv_init_acc(const ConvArgs& p, f32x16 (&acc)[C
   }
 }
 
+// Sum over the 32 lanes of a half-wave, result in every lane: four DPP steps inside the 16-lane rows (vector-ALU moves) and ONE
+// cross-row exchange, instead of five __shfl_xor = five ds_bpermute_b32 (LDS-pipe round trips, ~80 per tile and wave in the
+// statistics of the epilogue).  A fixed order like the butterfly it replaces: deterministic, independent of the batch.
+__device__ __forceinline__ float half_sum32(float v) {
+#define MCEDM_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  v += MCEDM_DPP(v, 0xB1);       // quad_perm [1, 0, 3, 2]
+  v += MCEDM_DPP(v, 0x4E);       // quad_perm [2, 3, 0, 1]
+  v += MCEDM_DPP(v, 0x141);      // row_half_mirror: lane i <-> 7 - i of its eight
+  v += MCEDM_DPP(v, 0x140);      // row_mirror: lane i <-> 15 - i of its row
+#undef MCEDM_DPP
+  return v + __shfl_xor(v, 16);
+}
+
 // FULL: every output channel of the tile exists (m0 + MT <= Cout).  Store-only: nothing here waits on memory.
 // STATS (0 / 4 / 2): fused GroupNorm statistics of what is stored, one record per wave and STATS-channel block (4: the
 // four accumulator registers of a lane that are consecutive channels; 2: their two halves -- GroupNorm(32) over 64

@@ -459,9 +459,7 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
         float a[2], b[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          a[e] = (v0[4 * gq + 2 * e] + v1[4 * gq + 2 * e]) + (v0[4 * gq + 2 * e + 1] + v1[4 * gq + 2 * e + 1]);
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) a[e] += __shfl_xor(a[e], off);
+          a[e] = half_sum32((v0[4 * gq + 2 * e] + v1[4 * gq + 2 * e]) + (v0[4 * gq + 2 * e + 1] + v1[4 * gq + 2 * e + 1]));
         }
         const float cnt = pairs ? 128.f : 256.f;
         const float mean0 = pairs ? a[0] * (1.0f / 128.0f) : (a[0] + a[1]) * (1.0f / 256.0f);
@@ -472,9 +470,7 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
           float q = 0.f;
 #pragma unroll
           for (int r = 4 * gq + 2 * e; r < 4 * gq + 2 * e + 2; ++r) { const float d0 = v0[r] - mean, d1 = v1[r] - mean; q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); }
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off);
-          b[e] = q;
+          b[e] = half_sum32(q);
         }
         if ((lane & 31) == 0) {
           const int quad = 8 * mb + 2 * gq + (lane >> 5);
