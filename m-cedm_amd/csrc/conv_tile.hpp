@@ -460,8 +460,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
       float mean[NR];
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) { gs1[q] += __shfl_xor(gs1[q], off); cnt[q] += __shfl_xor(cnt[q], off); }
+        gs1[q] = half_sum32(gs1[q]); cnt[q] = half_sum32(cnt[q]);
         mean[q] = cnt[q] > 0.f ? gs1[q] / cnt[q] : 0.f;
       }
       float gm2[NR];
@@ -482,9 +481,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[C
       }
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
-        float b = gm2[q];
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) b += __shfl_xor(b, off);
+        const float b = half_sum32(gm2[q]);
         if ((lane & 31) == 0) {
           const int quad = (wm * C::TM + i) * 8 + 2 * (STATS == 2 ? q >> 1 : q) + (lane >> 5);
           const int gl = STATS == 2 ? 2 * quad + (q & 1) : quad;
