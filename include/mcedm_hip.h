@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define MCEDM_ABI_VERSION 2
+#define MCEDM_ABI_VERSION 3   /* 3: mcedm_edm_loss / mcedm_sqnorm take caller-owned reduction scratch; mcedm_ddim_timesteps */
+/* Device scratch of one grid-wide fixed-order reduction (mcedm_edm_loss, mcedm_sqnorm): 8-byte aligned, contents
+ * irrelevant on entry, private to the call until it has completed on its stream.  Two calls that may run concurrently (two
+ * plans on two streams of one device) need two scratch areas; calls ordered on one stream can share one. */
+#define MCEDM_REDUCE_SCRATCH_BYTES (4096 * 8 + 64)
 #define MCEDM_MAX_LEVELS 8
 
 typedef enum {
@@ -186,9 +190,12 @@ int mcedm_edm_t_steps(const mcedm_sampler_desc* sp, double* t_steps);
 /* Masked, weighted EDM loss of training_step (models/mcedm.py:266-278, models/losses.py:48-59)
  * and its gradient w.r.t. D:  loss = mean_b sum_chw w_b (D*m - x*m)^2,  w_b = (s^2+sd^2)/(s*sd)^2.
  *  loss_out: 1 fp32 (device), accumulated from zero by this call;  dD_out [B,C,H,W] or NULL.
- *  mask == NULL: unmasked loss of PlCondEdm.training_step (models/ddim.py:1727). */
+ *  mask == NULL: unmasked loss of PlCondEdm.training_step (models/ddim.py:1727).
+ *  scratch: MCEDM_REDUCE_SCRATCH_BYTES of device memory (the per-block partial sums and the ticket of the fixed-order,
+ *  atomic-free sum that makes the loss bitwise reproducible): the library keeps no device state of its own. */
 int mcedm_edm_loss(const float* D, const float* x, const float* mask, const float* sigma, int B, int C,
-                   int H, int W, double sigma_data, float* loss_out, float* dD_out, void* stream);
+                   int H, int W, double sigma_data, float* loss_out, float* dD_out, void* scratch, size_t scratch_bytes,
+                   void* stream);
 
 /* x_noise = x + mask*noise*sigma (mcedm.py:216; mask == NULL: x + noise*sigma, :218), sigma = exp(rnd_normal*P_std + P_mean)
  * (mcedm.py:271). */
@@ -222,8 +229,9 @@ int mcedm_edm_denoise_backward_bucketed(const mcedm_plan* plan, const void* pack
                                         int n_buckets, const int32_t* bucket_first_param,
                                         void* const* bucket_events, void* stream);
 
-/* Squared L2 norm of a flat fp32 buffer, accumulated in fp64 into *sqnorm_out (device, overwritten). */
-int mcedm_sqnorm(const float* g, size_t n, double* sqnorm_out, void* stream);
+/* Squared L2 norm of a flat fp32 buffer, accumulated in fp64 into *sqnorm_out (device, overwritten); fixed summation
+ * order (bitwise reproducible).  scratch: MCEDM_REDUCE_SCRATCH_BYTES of device memory, as for mcedm_edm_loss. */
+int mcedm_sqnorm(const float* g, size_t n, double* sqnorm_out, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Fused grad-clip + Adam + EMA on flat fp32 buffers (models/mcedm.py:139-168,
  * models/ddim_blocks.py:44-54, configs/trainer/trainer_ddim.yaml:8-9).
@@ -432,6 +440,11 @@ typedef struct mcedm_ddim_desc {
   const float* alphas_cumprod_ext;
 } mcedm_ddim_desc;
 int mcedm_ddim_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* bytes);
+/* Host helper: the timestep sequence the sampler walks (models/ddim.py:823-830), exactly as the reference builds it --
+ * range(0, n, n // timesteps) for uniform, [int(s) for s in np.linspace(0, sqrt(0.8 n), timesteps) ** 2] for quad, with
+ * numpy.linspace's own arithmetic (arange * step, last sample pinned to the stop value).  *count = entries (uniform may
+ * exceed `timesteps`); seq may be NULL to query the count, else capacity >= *count. */
+int mcedm_ddim_timesteps(int num_diffusion_timesteps, int timesteps, int skip_type, int* seq, int capacity, int* count);
 int mcedm_ddim_repaint_sample(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_ddim_desc* sp, const float* hu,
                               const float* init_noise, const float* eta_noise, float* xs_out, float* x0_out, int return_last,
                               void* workspace, size_t workspace_bytes, int B, void* stream);

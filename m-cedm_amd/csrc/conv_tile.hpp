@@ -38,6 +38,15 @@ struct ConvCfg {
 // 1e-4 parity bar, and a third of the VALU work of expf() + IEEE division in the staging path.
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
+// two elements at a time (v_pk_mul_f32 / v_pk_add_f32 around the two transcendentals each): the same operations as silu_f
+__device__ __forceinline__ f32x2 silu_f2(f32x2 v) {
+  const f32x2 a = v * -1.44269504088896340736f;
+  f32x2 d = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  d = d + 1.0f;
+  const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  return v * r;
+}
+
 __device__ __forceinline__ float apply_coef(float v, const Coef& c, int act) {
   float t = (v - c.mean) * c.scale + c.offset;
   return act ? silu_f(t) : t;

@@ -57,6 +57,7 @@ constexpr int RPLANE = 196;                      // floats between channels of t
                                                  // adjacent 8-byte reads into ds_read2_b64, which banks at dword mod 32 over 16-lane groups = eight
                                                  // channels x two patch columns x two dwords: channels 4 banks apart cover the 32 banks once
 constexpr int RSUB = (RROWS * RPITCH + 63) / 64; // raw elements per lane and channel: 3
+constexpr int WINO_IL_K = 5;                     // side-work instructions the K loop's recipe admits behind each MFMA
 // V tile of one (chunk, position): [k parity h][patch 32][k-step 4]; the h = 1 block starts at float 144 = 16 mod 32: the
 // transform's dword writes bank at dword mod 32 per 32-lane group (four patch columns x eight channels: 4 ttx + (k >> 1) + 16 (k & 1)
 // covers the 32 banks once); the 16-byte B-fragment reads (dword mod 64, 16-lane groups inside one h half) only need it 16-byte
@@ -93,7 +94,9 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
   const int chunk = ci / WKC, k = ci % WKC, mb = co / 32, lane = (co & 31) + 32 * (k & 1), s = k >> 1;
 #pragma unroll
   for (int xi = 0; xi < 4; ++xi) {
-    const float u[4] = {t[xi][0], 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), t[xi][2]};
+    // column nu = 2 is stored NEGATED: the kernel's input transform produces -V[xi][2] (t1 - t2 instead of t2 - t1, which lets
+    // the four outputs of a row come out of two packed additions), and (-U) * (-V) = U * V bit for bit
+    const float u[4] = {t[xi][0], 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), -(0.5f * (t[xi][0] - t[xi][1] + t[xi][2])), t[xi][2]};
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
       dst[((((size_t)chunk * (coutp / 32) + mb) * 16 + 4 * xi + nu) * 64 + lane) * 4 + s] = u[nu];
@@ -185,13 +188,21 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
       }
     }
   };
+  auto raw_load_next = [&]() { if (++ld_st == nst) { ld_st = 0; ++ld_tile; set_geom(ld_tile < tiles_img ? ld_tile : tiles_img - 1); } };
+  auto raw_load_done = [&]() {                                     // all chunks of the stage requested: on to the next stage
+#pragma unroll
+    for (int i = 0; i < NG; ++i) rkeepC[i] = rkeepL[i];            // these registers are committed one trip from now
+  };
   auto raw_load = [&]() {                                          // the next stage of the stream
 #pragma unroll
     for (int sc = 0; sc < WSC; ++sc) raw_load1(sc);
-#pragma unroll
-    for (int i = 0; i < NG; ++i) rkeepC[i] = rkeepL[i];            // these registers are committed one trip from now
-    if (++ld_st == nst) { ld_st = 0; ++ld_tile; set_geom(ld_tile < tiles_img ? ld_tile : tiles_img - 1); }
+    raw_load_done();
+    raw_load_next();
   };
+  // The transform of a lane's four elements is written on PAIRS (v_pk_add / v_pk_fma / v_pk_mul_f32: two elements per vector
+  // instruction) and the zero padding is folded into the lane's copy of the row -- (v - mean) * 0 + 0 --: vector instructions
+  // do not overlap with the fp32 MFMAs of either wave of the SIMD, so every one removed from this loop is
+  // matrix time.  Same operations in the same order as apply_coef(): bit-identical values.
   auto raw_commit1 = [&](int sc, float* rb) {
 #pragma unroll
     for (int cw = 0; cw < C::CPW; ++cw) {
@@ -199,12 +210,28 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
       const bool ok = ci < Cin && (ci < p.Ca ? p.xa : p.xb) != nullptr;
       const Coef cf = cfl[ci < Cin ? ci : Cin - 1];
       const unsigned ck = ok ? 0xffffffffu : 0u;
+      if (UP) {
 #pragma unroll
-      for (int i = 0; i < NR; ++i) {
-        float v = apply_coef(raw[sc][cw][i], cf, p.act);
-        v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeepC[UP ? i : 0] & ck));
-        if (UP) { if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + kl) * RPLANE + lane + 64 * i] = v; }
-        else rb[(sc * WKC + kl) * RPLANE + lofs[i]] = v;
+        for (int i = 0; i < NR; ++i) {
+          float v = apply_coef(raw[sc][cw][i], cf, p.act);
+          v = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & (rkeepC[i] & ck));
+          if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + kl) * RPLANE + lane + 64 * i] = v;
+        }
+      } else {
+        const unsigned mk = rkeepC[0] & ck;
+        const float scm = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cf.scale) & mk);
+        const float ofm = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cf.offset) & mk);
+        f32x2 t[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 v = {raw[sc][cw][2 * h], raw[sc][cw][2 * h + 1]};
+          t[h] = (v - cf.mean) * scm + ofm;
+        }
+        // no branch (a slot must stay ONE basic block, see the K loop): SiLU is evaluated and selected
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const f32x2 a = silu_f2(t[h]); t[h] = p.act ? a : t[h]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[(sc * WKC + kl) * RPLANE + lofs[i]] = t[i >> 1][i & 1];
       }
     }
   };
@@ -212,39 +239,48 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   // ---- input transform: thread = (channel k, patch (ty, tx), row half hf): V[xi][nu] for xi in {2 hf, 2 hf + 1}.
   // In two halves (LDS reads / arithmetic + LDS writes) per chunk of the stage, so that the K loop can spread them out.
   // patch rows ty = mb + MB ti, ti < TI
+  // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] down the rows r0 .. r3 of the 4 x 4 patch.  Both halves evaluate ONE
+  // formula, t0 = Y - X, t1 = X + s Z (no per-half selects): hf = 0: (Y, Z, X, s) = (r0, r1, r2, +1) gives (r0 - r2, r1 + r2),
+  // hf = 1: (r2, r3, r1, -1) gives (r2 - r1, r1 - r3); the halves differ in two LDS row offsets and a sign.  Along the columns
+  // (o0, o3) = (c0, c1) - (c2, c3) and (o1, -o2) = (c1, c1) + (c2, -c2): two packed additions per row; nu = 2 is stored negated
+  // and the packed weights carry the same sign (wino_pack_kernel).  8 packed vector instructions per chunk and thread.
   const int tk = lane & 7, ttx = lane >> 3, tty = mb;
-  const int tr_src = tk * RPLANE + (2 * tty + hf) * RPITCH + 2 * ttx;
+  const int tr_yz = tk * RPLANE + (2 * tty + 2 * hf) * RPITCH + 2 * ttx;
+  const int tr_x = tk * RPLANE + (2 * tty + 2 - hf) * RPITCH + 2 * ttx;
+  const float tsgn = hf ? -1.f : 1.f;
+  const f32x2 tpm = {1.f, -1.f};
   const int tr_dst = (8 * hf) * VPOS + (tk & 1) * VH1 + (tty * WTX + ttx) * 4 + (tk >> 1);
-  float2 td[WSC][C::TI][3][2];
+  f32x2 td[WSC][C::TI][3][2];                         // rows Y, Z, X; column pairs (c0, c1), (c2, c3)
   auto transform_read1 = [&](int sc, const float* rb) {
 #pragma unroll
     for (int ti = 0; ti < C::TI; ++ti)
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        td[sc][ti][a][0] = *reinterpret_cast<const float2*>(rb + sc * WKC * RPLANE + tr_src + (2 * MB * ti + a) * RPITCH);
-        td[sc][ti][a][1] = *reinterpret_cast<const float2*>(rb + sc * WKC * RPLANE + tr_src + (2 * MB * ti + a) * RPITCH + 2);
+      for (int j = 0; j < 2; ++j) {
+        const float* b = rb + sc * WKC * RPLANE + 2 * MB * ti * RPITCH + 2 * j;
+        td[sc][ti][0][j] = *reinterpret_cast<const f32x2*>(b + tr_yz);
+        td[sc][ti][1][j] = *reinterpret_cast<const f32x2*>(b + tr_yz + RPITCH);
+        td[sc][ti][2][j] = *reinterpret_cast<const f32x2*>(b + tr_x);
       }
   };
   auto transform_finish1 = [&](int sc, float* vb) {
 #pragma unroll
     for (int ti = 0; ti < C::TI; ++ti) {
-      float d[3][4];
+      f32x2 t[2][2];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) { d[a][0] = td[sc][ti][a][0].x; d[a][1] = td[sc][ti][a][0].y; d[a][2] = td[sc][ti][a][1].x; d[a][3] = td[sc][ti][a][1].y; }
-      // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; rows held: hf = 0: d0 d1 d2, hf = 1: d1 d2 d3
-      float t[2][4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (hf == 0) { t[0][b] = d[0][b] - d[2][b]; t[1][b] = d[1][b] + d[2][b]; }
-        else         { t[0][b] = d[1][b] - d[0][b]; t[1][b] = d[0][b] - d[2][b]; }
+      for (int j = 0; j < 2; ++j) {
+        t[0][j] = td[sc][ti][0][j] - td[sc][ti][2][j];
+        t[1][j] = td[sc][ti][2][j] + tsgn * td[sc][ti][1][j];
       }
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
+        const f32x2 o03 = t[x][0] - t[x][1];
+        const f32x2 c11 = {t[x][0].y, t[x][0].y}, c22 = {t[x][1].x, t[x][1].x};
+        const f32x2 o12 = c11 + tpm * c22;
         float* o = vb + sc * 16 * VPOS + tr_dst + MB * ti * WTX * 4 + 4 * x * VPOS;
-        o[0 * VPOS] = t[x][0] - t[x][2];
-        o[1 * VPOS] = t[x][1] + t[x][2];
-        o[2 * VPOS] = t[x][2] - t[x][1];
-        o[3 * VPOS] = t[x][1] - t[x][3];
+        o[0 * VPOS] = o03.x;
+        o[1 * VPOS] = o12.x;
+        o[2 * VPOS] = o12.y;
+        o[3 * VPOS] = o03.y;
       }
     }
   };
@@ -271,12 +307,18 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   transform_finish(vbuf);
   // Accumulators start at zero, except Winograd position (xi, nu) = (1, 1) -- block 5 of the hf = 0 waves --, which starts at
   // the bias: A^T has ones in column 1 of both rows, so a constant there comes out as that constant in all four pixels.
+  // Zeroing is done by the matrix pipe itself -- D = 0 * 0 + 0 with the inline constant as C: eight instructions (512 cycles)
+  // instead of 128 v_mov: the in-kernel stamps put the v_mov version at 3500 cycles per tile with both waves of a SIMD in it
+  // (a wave issues a vector instruction every ~7 cycles at best here).
   f32x16 acc[8];
   auto init_acc = [&]() {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float z = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int q = 0; q < 8; ++q) {
+      asm volatile("" : "+v"(z));                          // an opaque zero per block: eight matrix instructions, not one + 112 copies
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, z, zero16, 0, 0, 0);
+    }
     if (hf == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[5][r] = bias_l[32 * mb + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2)];
@@ -291,10 +333,18 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
 #ifdef MCEDM_WINO_TIMELINE      // cycle sums of waves 0 and MB (lane 0): MFMA stream, barrier, epilogue -> dbg[8..12] / dbg[13..15, 7] (diagnostic builds only)
   unsigned long long ph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #define WINO_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tlast; tlast = t_; }
-  const bool no_u = mode & 2, no_t = mode & 4, no_r = mode & 8;   // drop the weight reloads / the transform / the raw tile path (wrong results)
+  unsigned long long sl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, slast = 0;      // mode bit 16: cycles per slot of the stage (wave 0) -> dbg[8..15]
+#define WINO_SLOT(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sl[(i) & 7] += t_ - slast; slast = t_; }
+#define WINO_SLOT0 { slast = __builtin_amdgcn_s_memtime(); }
+  unsigned long long ep[6] = {0, 0, 0, 0, 0, 0}, elast = 0;          // mode bit 32: cycles per phase of the epilogue (wave 0) -> dbg[8..13]
+#define WINO_EP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (i) ep[(i) - 1] += t_ - elast; elast = t_; __builtin_amdgcn_sched_barrier(0); }
+  const bool no_u = mode & 2;                                       // drop the weight reloads (wrong results; ablation)
 #else
 #define WINO_STAMP(i)
-  constexpr bool no_u = false, no_t = false, no_r = false;
+#define WINO_SLOT(i)
+#define WINO_SLOT0
+#define WINO_EP(i)
+  constexpr bool no_u = false;
 #endif
   // One trip = one stage: WSC x 4 slots of [two B-fragment reads for the next slot | eight MFMAs | two weight reloads] and,
   // behind each slot's MFMAs, one slice of the side work that prepares later stages -- the transform of stage g + 1 (LDS
@@ -304,20 +354,24 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   // (before or after the MFMAs, or ping-ponged between the two waves of a SIMD) it cost its latencies: 2400 cycles per chunk
   // and wave against 2048 of MFMAs.  Every slice touches buffers no MFMA of this trip reads: one barrier per trip.
   auto side_slice = [&](int slot, int g, int cur) {
-    const bool more = g + 1 < G && !no_t, c2 = g + 2 < G && !no_r, l3 = g + 3 < G && !no_r;
+    // Every slice runs in every trip (past the end of the stream it works on stale registers and writes LDS buffers nobody
+    // reads; the loads stay inside this sample's planes): a slot is then ONE basic block, and the scheduler can place the
+    // slice's instructions between the slot's MFMAs (the recipe in the K loop).
     if (WSC == 2) {        // the two chunks' transforms one after the other: their 12 + 12 staging registers are never live together
-      if (slot == 0 && more) transform_read1(0, rbuf + (cur ^ 1) * RBUF);
-      if (slot == 1 && c2) raw_commit1(0, rbuf + cur * RBUF);
-      if (slot == 2 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
-      if (slot == 3 && more) transform_read1(WSC - 1, rbuf + (cur ^ 1) * RBUF);
-      if (slot == 4 && c2) { raw_commit1(WSC - 1, rbuf + cur * RBUF); commit_done(); }
-      if (slot == 5 && more) transform_finish1(WSC - 1, vbuf + (cur ^ 1) * VBUF);
-      if (slot == 6 && l3) raw_load();
+      // a chunk's raw registers are requested again in the slot right behind their commit: the tile data (HBM) then has seven
+      // slots = 7 / 8 of a stage to arrive (both chunks requested together in slot 6 left the first one three slots, ~1.5 us,
+      // and its commit waited ~800 cycles for it: in-kernel slot stamps)
+      if (slot == 0) transform_read1(0, rbuf + (cur ^ 1) * RBUF);
+      if (slot == 1) raw_commit1(0, rbuf + cur * RBUF);
+      if (slot == 2) { transform_finish1(0, vbuf + (cur ^ 1) * VBUF); raw_load1(0); }
+      if (slot == 3) transform_read1(WSC - 1, rbuf + (cur ^ 1) * RBUF);
+      if (slot == 4) { raw_commit1(WSC - 1, rbuf + cur * RBUF); commit_done(); }
+      if (slot == 5) { transform_finish1(WSC - 1, vbuf + (cur ^ 1) * VBUF); raw_load1(WSC - 1); raw_load_done(); }
     } else {
-      if (slot == 0 && more) transform_read(rbuf + (cur ^ 1) * RBUF);
-      if (slot == 1 && c2) { raw_commit1(0, rbuf + cur * RBUF); commit_done(); }
-      if (slot == 2 && l3) raw_load();
-      if (slot == 3 && more) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
+      if (slot == 0) transform_read(rbuf + (cur ^ 1) * RBUF);
+      if (slot == 1) { raw_commit1(0, rbuf + cur * RBUF); commit_done(); }
+      if (slot == 2) { raw_load1(0); raw_load_done(); }
+      if (slot == 3) transform_finish1(0, vbuf + (cur ^ 1) * VBUF);
     }
   };
   (void)mode;
@@ -325,6 +379,7 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   for (int g = 0; g < G; ++g) {
     const int cur = g & 1;
     WINO_STAMP(0)
+    WINO_SLOT0
 #pragma unroll
     for (int sc = 0; sc < WSC; ++sc) {
       const int c = st * WSC + sc;
@@ -353,13 +408,21 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
           ua[2 * qp] = un[(2 * qp) * 64];
           ua[2 * qp + 1] = un[(2 * qp + 1) * 64];
         }
-        // pin the order: the next pair's two LDS reads, this pair's eight MFMAs, this pair's two reloads, the slice
-        if (qp < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        // The slice's instructions go BETWEEN the slot's MFMAs, up to WINO_IL_K behind each: its dependent chains (LDS read ->
+        // arithmetic -> transcendental -> LDS write) then wait under matrix instructions instead of in front of the next slot
+        // (as a block of its own behind the eight MFMAs a commit slice cost +900 cycles for ~25 vector instructions).
         side_slice(sc * 4 + qp, g, cur);
+        if (qp < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x486, WINO_IL_K, 0);           // VALU | SALU | DS | transcendental
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (sc * 4 + qp == (WSC == 2 ? 5 : 2)) raw_load_next();                 // the one conditional piece (tile geometry): a block of its own
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_SLOT(sc * 4 + qp + (WSC == 1 ? 0 : 0))
       }
     }
     WINO_STAMP(1)
@@ -370,6 +433,7 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
 
     // ---- a tile is complete: output transform, bias, residual, stores, statistics; then the accumulators start over.
     // (The stream's LDS buffers already hold the first stages of the next tile: the exchange area is a region of its own.)
+    WINO_EP(0)
     const int y0 = (tile / tiles_x) * WPH, x0 = (tile % tiles_x) * WPW;
     const int pt = lane & 31;                             // this wave stores row hf of every patch: pixels
     const int oy = y0 + 2 * (pt >> 3) + hf, ox = x0 + 2 * (pt & 7);   // (y0 + 2 ty + hf, x0 + 2 tx + {0, 1}), patch = lane & 31
@@ -429,6 +493,7 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
         }
       }
     }
+    WINO_EP(1)                                            // 1: output transform over nu, weight + residual requests
     const int pw = wave ^ MB;
     float v0[16], v1[16];
 #pragma unroll
@@ -444,10 +509,12 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
       }
       if (j == 0) __syncthreads();
     }
+    WINO_EP(2)                                            // 2: the two exchange rounds (incl. the wait for the residual)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, make_float2(v0[r], v1[r])), rs_out, voff,
                                             4u * (unsigned)((r & 3) + 8 * (r >> 2)) * HWu, 0);
+    WINO_EP(3)                                            // 3: the 16 stores
     if (p.gsum) {
       // fused GroupNorm statistics of what was stored (conv_tile.hpp conv_epilogue): one record per 4-channel block =
       // registers 4 g .. 4 g + 3 of the 32 lanes that share lane >> 5 (or per 2-channel block, gsum_rc == 2: their two
@@ -490,9 +557,11 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
       conv_stats_store<C, 2>(p, red, n, m0, tile, tiles_img, tid);
       // the next epilogue writes `red` only after a whole tile of barriers
     }
+    WINO_EP(4)                                            // 4: statistics
     __builtin_amdgcn_sched_barrier(0);
     init_acc();
     ++tile;
+    WINO_EP(5)                                            // 5: accumulator initialisation
     WINO_STAMP(3)
   }
   if (p.dbg && tid == 0) {
@@ -502,7 +571,9 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   }
 #ifdef MCEDM_WINO_TIMELINE
   if (p.dbg && tid == 0) for (int i = 0; i < 5; ++i) p.dbg[blockIdx.x * 16 + 8 + i] = ph[i];
-  if (p.dbg && tid == 64 * MB) { p.dbg[blockIdx.x * 16 + 13] = ph[1]; p.dbg[blockIdx.x * 16 + 14] = ph[2]; p.dbg[blockIdx.x * 16 + 15] = ph[3]; p.dbg[blockIdx.x * 16 + 7] = ph[0]; }
+  if (p.dbg && tid == 0 && (mode & 16)) for (int i = 0; i < 8; ++i) p.dbg[blockIdx.x * 16 + 8 + i] = sl[i];
+  if (p.dbg && tid == 0 && (mode & 32)) for (int i = 0; i < 6; ++i) p.dbg[blockIdx.x * 16 + 8 + i] = ep[i];
+  if (p.dbg && tid == 64 * MB && !(mode & 48)) { p.dbg[blockIdx.x * 16 + 13] = ph[1]; p.dbg[blockIdx.x * 16 + 14] = ph[2]; p.dbg[blockIdx.x * 16 + 15] = ph[3]; p.dbg[blockIdx.x * 16 + 7] = ph[0]; }
 #endif
 }
 

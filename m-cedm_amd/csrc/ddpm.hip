@@ -936,6 +936,41 @@ extern "C" int mcedm_ddim_workspace_bytes(const mcedm_ddpm_plan* plan, int B, si
   return MCEDM_OK;
 }
 
+// The DDIM timestep sequence of PlDdim.sample_with_repeat (models/ddim.py:823-830).
+//  uniform: range(0, n, n // N) -- may hold more than N entries;
+//  quad:    [int(s) for s in np.linspace(0, sqrt(0.8 n), N) ** 2].  numpy.linspace evaluates arange(N) * step with
+//           step = stop / (N - 1) and then PINS the last sample to `stop` itself; hi * i / (N - 1) is a different rounding
+//           and lands on the other side of an integer for 85 of ~1200 (n, N) pairs (n = 1000, N = 100: first sampled step
+//           799 instead of 800), so the two operations are reproduced in numpy's order.
+static std::vector<int> ddim_timestep_seq(int n, int N, int skip_type) {
+  std::vector<int> seq;
+  if (skip_type == 0) {
+    const int skip = n / N;
+    for (int v = 0; v < n; v += skip) seq.push_back(v);
+  } else {
+    const double hi = std::sqrt(n * 0.8);
+    const double step = N > 1 ? hi / (double)(N - 1) : 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double v = (N > 1 && i == N - 1) ? hi : (double)i * step;
+      seq.push_back((int)(v * v));
+    }
+  }
+  return seq;
+}
+
+extern "C" int mcedm_ddim_timesteps(int num_diffusion_timesteps, int timesteps, int skip_type, int* seq, int capacity, int* count) {
+  MCEDM_REQUIRE(count && num_diffusion_timesteps >= 2 && timesteps >= 1 && timesteps <= num_diffusion_timesteps,
+                "ddim_timesteps: bad schedule (timesteps=%d of %d)", timesteps, num_diffusion_timesteps);
+  MCEDM_REQUIRE(skip_type == 0 || skip_type == 1, "ddim_timesteps: skip_type must be 0 (uniform) or 1 (quad)");
+  const std::vector<int> s = ddim_timestep_seq(num_diffusion_timesteps, timesteps, skip_type);
+  *count = (int)s.size();
+  if (seq) {
+    MCEDM_REQUIRE(capacity >= (int)s.size(), "ddim_timesteps: capacity %d < %d entries", capacity, (int)s.size());
+    for (size_t i = 0; i < s.size(); ++i) seq[i] = s[i];
+  }
+  return MCEDM_OK;
+}
+
 extern "C" int mcedm_ddim_repaint_sample(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_ddim_desc* sp,
                                          const float* hu, const float* init_noise, const float* eta_noise, float* xs_out,
                                          float* x0_out, int return_last, void* workspace, size_t workspace_bytes, int B,
@@ -951,14 +986,7 @@ extern "C" int mcedm_ddim_repaint_sample(const mcedm_ddpm_plan* plan, const void
   const bool stochastic = std::fabs(sp->eta) > 1e-10;                   // ddim.py:884
   MCEDM_REQUIRE(!stochastic || eta_noise != nullptr, "ddim_repaint_sample: eta != 0 needs eta_noise");
   // the timestep sequence (ddim.py:823-830) and its predecessor list (:845)
-  std::vector<int> seq;
-  if (sp->skip_type == 0) {
-    const int skip = n / N;
-    for (int v = 0; v < n; v += skip) seq.push_back(v);                 // range(0, num_timesteps, skip): may hold more than N entries
-  } else {
-    const double hi = std::sqrt(n * 0.8);
-    for (int i = 0; i < N; ++i) { const double v = (N > 1 ? hi * i / (N - 1) : 0.0); seq.push_back((int)(v * v)); }
-  }
+  std::vector<int> seq = ddim_timestep_seq(n, N, sp->skip_type);
   const int S = (int)seq.size();
   DHeader hd; size_t act = 0;
   int rc;

@@ -377,38 +377,42 @@ __global__ void noise_inputs_kernel(const float* __restrict__ x, const float* __
 }
 
 // ---- deterministic grid-wide sums (loss, gradient norm) ---------------------------------------------------------
-// Every block stores its partial sum (fp64) in a slot of a library-owned device array, takes a ticket, and the block that
-// draws the LAST ticket adds the slots in index order: the value does not depend on the order the blocks ran in (an
-// atomicAdd of the partials would make the loss, the clip factor and with them the whole training run differ in the last
-// bits from run to run).  One array per kernel; calls on ONE stream at a time per device (the library's contract:
-// one process per GPU, one stream), the ticket is back at zero when the kernel ends.
+// Every block stores its partial sum (fp64) in a slot of a scratch array, takes a ticket, and the block that draws the LAST
+// ticket adds the slots in index order: the value does not depend on the order the blocks ran in (an atomicAdd of the
+// partials would make the loss, the clip factor and with them the whole training run differ in the last bits from run to
+// run).  The array and the ticket live in CALLER-owned scratch (ABI 3: MCEDM_REDUCE_SCRATCH_BYTES per concurrent call), so
+// two plans on two streams of one device never share state; the entry point zeroes the ticket on the stream in front of
+// the kernel.  Layout: [RED_MAX] fp64 partials, then the 32-bit ticket.
 constexpr int RED_MAX = 4096;
-__device__ double g_red_part[2][RED_MAX];
-__device__ unsigned g_red_ticket[2];
+static_assert(MCEDM_REDUCE_SCRATCH_BYTES >= RED_MAX * 8 + 4, "mcedm_hip.h: MCEDM_REDUCE_SCRATCH_BYTES too small for the reduction");
+struct RedScratch { double* part; unsigned* ticket; };
+static inline RedScratch red_scratch(void* scratch) {
+  return RedScratch{reinterpret_cast<double*>(scratch), reinterpret_cast<unsigned*>(reinterpret_cast<char*>(scratch) + (size_t)RED_MAX * 8)};
+}
 
 // block_sum: this block's partial in thread 0.  Returns true in every thread of the LAST block, with the total in *total
 // (thread 0 only).
-__device__ __forceinline__ bool grid_sum_fixed_order(int which, double block_sum, unsigned bid, unsigned nblocks, double* total) {
+__device__ __forceinline__ bool grid_sum_fixed_order(RedScratch rs, double block_sum, unsigned bid, unsigned nblocks, double* total) {
   __shared__ unsigned s_last;
   __shared__ double s_red[4];
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&g_red_part[which][bid], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&rs.part[bid], block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
-    s_last = (atomicAdd(&g_red_ticket[which], 1u) == nblocks - 1) ? 1u : 0u;
+    s_last = (atomicAdd(rs.ticket, 1u) == nblocks - 1) ? 1u : 0u;
   }
   __syncthreads();
   if (!s_last) return false;
   __threadfence();
   double t = 0.0;
   for (unsigned i = threadIdx.x; i < nblocks; i += blockDim.x)      // fixed assignment of slots to threads
-    t += __hip_atomic_load(&g_red_part[which][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t += __hip_atomic_load(&rs.part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
     *total = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    g_red_ticket[which] = 0u;
+    *rs.ticket = 0u;
   }
   return true;
 }
@@ -417,7 +421,7 @@ __device__ __forceinline__ bool grid_sum_fixed_order(int which, double block_sum
 __global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__ D, const float* __restrict__ x,
                                                        const float* __restrict__ mask, const float* __restrict__ sigma,
                                                        float sigma_data, int B, size_t per_sample,
-                                                       float* __restrict__ loss, float* __restrict__ dD) {
+                                                       float* __restrict__ loss, float* __restrict__ dD, RedScratch rs) {
   const int b = blockIdx.y;
   const float s = sigma[b];
   const float wgt = (s * s + sigma_data * sigma_data) / ((s * sigma_data) * (s * sigma_data));
@@ -436,12 +440,12 @@ __global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
   __syncthreads();
   double total;
-  if (grid_sum_fixed_order(0, (red[0] + red[1]) + (red[2] + red[3]), blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, &total) &&
+  if (grid_sum_fixed_order(rs, (red[0] + red[1]) + (red[2] + red[3]), blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, &total) &&
       threadIdx.x == 0)
     *loss = (float)(total / (double)B);
 }
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, double* __restrict__ out, RedScratch rs) {
   float a0 = 0.f, a1 = 0.f;
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
   __syncthreads();
   double total;
-  if (grid_sum_fixed_order(1, (red[0] + red[1]) + (red[2] + red[3]), blockIdx.x, gridDim.x, &total) && threadIdx.x == 0) *out = total;
+  if (grid_sum_fixed_order(rs, (red[0] + red[1]) + (red[2] + red[3]), blockIdx.x, gridDim.x, &total) && threadIdx.x == 0) *out = total;
 }
 
 // torch.optim.Adam (no amsgrad) on clipped grads, then EmaModel.update (ddim_blocks.py:44-54).
@@ -504,26 +508,35 @@ extern "C" int mcedm_edm_noise_inputs(const float* x, const float* mask, const f
 }
 
 extern "C" int mcedm_edm_loss(const float* D, const float* x, const float* mask, const float* sigma, int B, int C, int H,
-                              int W, double sigma_data, float* loss_out, float* dD_out, void* stream) {
+                              int W, double sigma_data, float* loss_out, float* dD_out, void* scratch, size_t scratch_bytes,
+                              void* stream) {
   MCEDM_REQUIRE(D && x && sigma && loss_out, "edm_loss: null pointer");
+  MCEDM_REQUIRE(scratch && scratch_bytes >= MCEDM_REDUCE_SCRATCH_BYTES && ((size_t)scratch & 7) == 0,
+                "edm_loss: needs %d bytes of 8-byte aligned device scratch (MCEDM_REDUCE_SCRATCH_BYTES)", MCEDM_REDUCE_SCRATCH_BYTES);
   MCEDM_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0, "edm_loss: bad shape");
   const size_t per = (size_t)C * H * W;
   MCEDM_REQUIRE(B <= RED_MAX, "edm_loss: batch %d exceeds the reduction table (%d)", B, RED_MAX);
   int gx = (int)((per + 255) / 256);
   if (gx > 64) gx = 64;
   if (gx > RED_MAX / B) gx = RED_MAX / B;            // one slot of the fixed-order reduction per block
+  const RedScratch rs = red_scratch(scratch);
+  MCEDM_HIP_TRY(hipMemsetAsync(rs.ticket, 0, sizeof(unsigned), (hipStream_t)stream));
   hipLaunchKernelGGL(edm_loss_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, D, x, mask, sigma,
-                     (float)sigma_data, B, per, loss_out, dD_out);
+                     (float)sigma_data, B, per, loss_out, dD_out, rs);
   MCEDM_LAUNCH_CHECK("edm_loss_kernel");
   return MCEDM_OK;
 }
 
-extern "C" int mcedm_sqnorm(const float* g, size_t n, double* sqnorm_out, void* stream) {
+extern "C" int mcedm_sqnorm(const float* g, size_t n, double* sqnorm_out, void* scratch, size_t scratch_bytes, void* stream) {
   MCEDM_REQUIRE(g && sqnorm_out, "sqnorm: null pointer");
+  MCEDM_REQUIRE(scratch && scratch_bytes >= MCEDM_REDUCE_SCRATCH_BYTES && ((size_t)scratch & 7) == 0,
+                "sqnorm: needs %d bytes of 8-byte aligned device scratch (MCEDM_REDUCE_SCRATCH_BYTES)", MCEDM_REDUCE_SCRATCH_BYTES);
   if (n == 0) { MCEDM_HIP_TRY(hipMemsetAsync(sqnorm_out, 0, sizeof(double), (hipStream_t)stream)); return MCEDM_OK; }
   int blocks = grid_for(n);
   if (blocks > RED_MAX) blocks = RED_MAX;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm_out);
+  const RedScratch rs = red_scratch(scratch);
+  MCEDM_HIP_TRY(hipMemsetAsync(rs.ticket, 0, sizeof(unsigned), (hipStream_t)stream));
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm_out, rs);
   MCEDM_LAUNCH_CHECK("sqnorm_kernel");
   return MCEDM_OK;
 }

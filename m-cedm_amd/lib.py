@@ -29,7 +29,7 @@ EXPORTS = [
     "mcedm_ddpm_packed_bytes", "mcedm_ddpm_pack_weights", "mcedm_ddpm_workspace_bytes", "mcedm_ddpm_forward",
     "mcedm_ddpm_denoise", "mcedm_repaint_schedule", "mcedm_repaint_workspace_bytes", "mcedm_repaint_sample",
     "mcedm_repaint_sample_rng", "mcedm_normal_fill", "mcedm_ddpm_forward_sc", "mcedm_ddim_workspace_bytes",
-    "mcedm_ddim_repaint_sample",
+    "mcedm_ddim_repaint_sample", "mcedm_ddim_timesteps",
     "mcedm_unet_forward_dx", "mcedm_edm_denoise_dx", "mcedm_edm_denoise_backward_dx", "mcedm_heun_sample_dxcond",
 ]
 
@@ -43,7 +43,8 @@ class UNetDesc(C.Structure):
 
 
 DX_NONE, DX_CAT, DX_ENC = 0, 1, 2      # MCEDM_DX_* (include/mcedm_hip.h)
-ABI_VERSION = 2                        # MCEDM_ABI_VERSION
+ABI_VERSION = 3                        # MCEDM_ABI_VERSION
+REDUCE_SCRATCH_BYTES = 4096 * 8 + 64   # MCEDM_REDUCE_SCRATCH_BYTES
 
 
 class SamplerDesc(C.Structure):
@@ -113,7 +114,7 @@ def load() -> C.CDLL:
     lib.mcedm_heun_sample.argtypes = [vp, vp, C.POINTER(SamplerDesc), f32p, f32p, f32p, f64p, f64p, i32, vp, sz,
                                       i32, i32, i32, vp]
     lib.mcedm_edm_t_steps.argtypes = [C.POINTER(SamplerDesc), C.POINTER(C.c_double)]
-    lib.mcedm_edm_loss.argtypes = [f32p, f32p, f32p, f32p, i32, i32, i32, i32, C.c_double, f32p, f32p, vp]
+    lib.mcedm_edm_loss.argtypes = [f32p, f32p, f32p, f32p, i32, i32, i32, i32, C.c_double, f32p, f32p, vp, sz, vp]
     lib.mcedm_edm_noise_inputs.argtypes = [f32p, f32p, f32p, f32p, i32, i32, i32, i32, C.c_double, C.c_double, f32p,
                                            f32p, vp]
     lib.mcedm_edm_denoise_backward.argtypes = [vp, vp, C.POINTER(vp), f32p, f32p, i32, f32p, f32p, C.POINTER(vp), vp,
@@ -130,7 +131,7 @@ def load() -> C.CDLL:
                                                   C.POINTER(vp), vp]
     lib.mcedm_heun_sample_dxcond.argtypes = [vp, vp, C.POINTER(SamplerDesc), C.POINTER(GuidanceDesc), C.POINTER(GuidanceDesc),
                                              f32p, f32p, f64p, f64p, i32, vp, sz, i32, i32, i32, vp]
-    lib.mcedm_sqnorm.argtypes = [f32p, sz, f64p, vp]
+    lib.mcedm_sqnorm.argtypes = [f32p, sz, f64p, vp, sz, vp]
     lib.mcedm_adam_ema_step.argtypes = [f32p, f32p, f32p, f32p, f32p, sz, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_double, f64p, C.c_double, C.c_double, C.c_double, C.c_int64, vp]
     lib.mcedm_swe_fv_step.argtypes = [f32p, f32p, i32, i32, i32, C.c_float, C.c_float, vp]
@@ -160,6 +161,7 @@ def load() -> C.CDLL:
     lib.mcedm_ddpm_forward_sc.argtypes = [vp, vp, f32p, f32p, C.c_float, f32p, vp, sz, i32, vp]
     lib.mcedm_ddim_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]
     lib.mcedm_ddim_repaint_sample.argtypes = [vp, vp, C.POINTER(DdimDesc), f32p, f32p, f32p, f32p, f32p, i32, vp, sz, i32, vp]
+    lib.mcedm_ddim_timesteps.argtypes = [i32, i32, i32, C.POINTER(C.c_int), i32, C.POINTER(C.c_int)]
     for name in EXPORTS:
         fn = getattr(lib, name)          # AttributeError here == header/library drift
         if name not in ("mcedm_last_error", "mcedm_unet_plan_destroy", "mcedm_ddpm_plan_destroy"):
@@ -422,6 +424,18 @@ def ddim_desc(sp, alphas_ext: torch.Tensor, h_ch: int, u_ch: int, self_cond: boo
     return d, ae
 
 
+def ddim_timesteps(num_diffusion_timesteps: int, timesteps: int, skip_type) -> List[int]:
+    """The timestep sequence of PlDdim.sample_with_repeat (models/ddim.py:823-830) as the device sampler walks it."""
+    skip = {"uniform": 0, "quad": 1, 0: 0, 1: 1}.get(skip_type)
+    if skip is None:
+        raise NotImplementedError(f"skip_type {skip_type}")
+    cnt = C.c_int()
+    check(load().mcedm_ddim_timesteps(num_diffusion_timesteps, timesteps, skip, None, 0, C.byref(cnt)), "ddim_timesteps")
+    arr = (C.c_int * cnt.value)()
+    check(load().mcedm_ddim_timesteps(num_diffusion_timesteps, timesteps, skip, arr, cnt.value, C.byref(cnt)), "ddim_timesteps")
+    return list(arr)
+
+
 def repaint_schedule(rd: RepaintDesc) -> List[float]:
     arr = (C.c_double * (rd.timesteps + 1))()
     check(load().mcedm_repaint_schedule(C.byref(rd), arr), "repaint_schedule")
@@ -526,7 +540,7 @@ class DdpmPlan:
         ws = ws or Workspace()
         buf = ws.get(self.ddim_workspace_bytes(B), hu.device)
         n = dd.num_diffusion_timesteps
-        S = len(range(0, n, n // dd.timesteps)) if dd.skip_type == 0 else dd.timesteps
+        S = len(ddim_timesteps(n, dd.timesteps, dd.skip_type))
         R = self.resolution
         xs = torch.empty((B, 1 if return_last else S + 1, R, R, self.in_channels), dtype=torch.float32, device=hu.device)
         x0 = torch.empty((B, 1 if return_last else S, R, R, self.in_channels), dtype=torch.float32, device=hu.device)
@@ -716,12 +730,28 @@ def edm_noise_inputs(x, mask, noise, rnd_normal, P_mean=-1.2, P_std=1.2):
     return x_noise, sigma
 
 
-def edm_loss(D, x, mask, sigma, sigma_data=1.0, want_grad=True):
+_RED_SCRATCH = {}
+
+
+def reduce_scratch(device, stream=None) -> torch.Tensor:
+    """MCEDM_REDUCE_SCRATCH_BYTES of device memory for the fixed-order sums of edm_loss / sqnorm, one area per (device, stream):
+    the library owns no device state (ABI 3), and calls on different streams must not share an area."""
+    if torch.cuda.is_current_stream_capturing():      # belongs to the graph being captured (its private pool), never cached
+        return torch.empty(REDUCE_SCRATCH_BYTES, dtype=torch.uint8, device=device)
+    key = (torch.device(device).index, int(_stream() or 0) if stream is None else int(stream))
+    buf = _RED_SCRATCH.get(key)
+    if buf is None:
+        buf = _RED_SCRATCH[key] = torch.empty(REDUCE_SCRATCH_BYTES, dtype=torch.uint8, device=device)
+    return buf
+
+
+def edm_loss(D, x, mask, sigma, sigma_data=1.0, want_grad=True, scratch: Optional[torch.Tensor] = None):
     B, Cc, H, W = D.shape
     loss = torch.empty(1, dtype=torch.float32, device=D.device)
     dD = torch.empty_like(D) if want_grad else None
+    scratch = reduce_scratch(D.device) if scratch is None else scratch
     check(load().mcedm_edm_loss(_ptr(D), _ptr(x), _ptr(mask), _ptr(sigma), B, Cc, H, W, float(sigma_data), _ptr(loss),
-                                _ptr(dD), _stream()), "edm_loss")
+                                _ptr(dD), scratch.data_ptr(), scratch.numel() * scratch.element_size(), _stream()), "edm_loss")
     return loss, dD
 
 
@@ -767,10 +797,12 @@ def darcy_residual(pred, two_dx: float, denom: float, clamp: bool) -> torch.Tens
     return out
 
 
-def sqnorm(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def sqnorm(g: torch.Tensor, out: Optional[torch.Tensor] = None, scratch: Optional[torch.Tensor] = None) -> torch.Tensor:
     if out is None:
         out = torch.empty(1, dtype=torch.float64, device=g.device)
-    check(load().mcedm_sqnorm(_ptr(g), g.numel(), _ptr(out, torch.float64), _stream()), "sqnorm")
+    scratch = reduce_scratch(g.device) if scratch is None else scratch
+    check(load().mcedm_sqnorm(_ptr(g), g.numel(), _ptr(out, torch.float64), scratch.data_ptr(),
+                              scratch.numel() * scratch.element_size(), _stream()), "sqnorm")
     return out
 
 

@@ -150,6 +150,10 @@ class FlatTrainState:
             self.flat_ema = torch.cat([ema[n].detach().reshape(-1) for n in names]).contiguous()
         self.grad_views = views_like(self.flat_g, tens)
         self.sq = torch.zeros(1, dtype=torch.float64, device=self.flat_p.device)
+        # scratch of the two fixed-order reductions (loss, gradient norm): owned by this state, so two trainers on two streams
+        # of one device never share any (ABI 3; the calls of one step are ordered on its stream and may share one area)
+        self.red_scratch = (torch.empty(_lib.REDUCE_SCRATCH_BYTES, dtype=torch.uint8, device=self.flat_p.device)
+                            if self.flat_p.is_cuda else None)
         self.step_count = 0
         self.ws = _lib.Workspace()
         self.packed = packed
@@ -166,7 +170,7 @@ class FlatTrainState:
         x_noise, sigma = _lib.edm_noise_inputs(x, mask, noise, rnd_normal.reshape(-1).contiguous(), self.P_mean, self.P_std)
         dx = dx_fn(cond_in, x_noise) if dx_fn is not None else None
         D = plan.denoise(self.packed, x_noise, sigma, cond=cond_in, ws=self.ws, training=True, sigma_data=self.sigma_data, dx=dx)
-        loss, dD = _lib.edm_loss(D, x, mask, sigma, sigma_data=self.sigma_data, want_grad=True)
+        loss, dD = _lib.edm_loss(D, x, mask, sigma, sigma_data=self.sigma_data, want_grad=True, scratch=self.red_scratch)
         multi = self.world > 1             # bucket events only where a side stream waits for them
         plan.denoise_backward(self.packed, self.pviews, x_noise, sigma, cond_in, dD, self.grad_views, self.ws,
                               sigma_data=self.sigma_data, bucket_first=self.sync.bucket_first if multi else None,
@@ -271,8 +275,9 @@ class FlatTrainState:
         self.sync.launch()                 # bucketed sum all-reduce, overlapping the tail of the backward
         self.sync.join()
         self.step_count += 1
+        sqn = _lib.sqnorm if self.red_scratch is None else (lambda g, out: _lib.sqnorm(g, out, scratch=self.red_scratch))
         clip_adam_ema_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.flat_ema, self.step_count, self.world, self.hp,
-                       self.sq)
+                       self.sq, sqnorm_fn=sqn)
         return loss
 
 

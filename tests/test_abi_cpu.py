@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     exported = sorted(set(re.findall(r"\bT (mcedm_[a-z0-9_]+)$", nm, flags=re.M)))
     assert exported == names, (set(exported) ^ set(names))
     assert sorted(set(L.EXPORTS + L.OP_EXPORTS)) == names, set(L.EXPORTS + L.OP_EXPORTS) ^ set(names)
-    assert lib.mcedm_version() == 2
+    assert lib.mcedm_version() == 3
 
 
 def test_plan_parameter_table_matches_state_dict_order():
@@ -140,3 +140,24 @@ def test_repaint_schedule_and_ddpm_plan_host_side():
         L.DdpmPlan(2, 2, 64, (1, 2), 1, (), 32)
     with pytest.raises(RuntimeError, match="multiple of 32"):
         L.DdpmPlan(2, 2, 48, (1,), 1, (), 32)
+
+
+def test_ddim_timestep_sequence_equals_numpy_linspace():
+    """the quad sequence is [int(s) for s in np.linspace(0, sqrt(0.8 n), N) ** 2] (models/ddim.py:826-828).
+    numpy computes arange(N) * (stop / (N - 1)) and pins the last sample to stop; hi * i / (N - 1) truncates to a different
+    timestep for 85 of ~1200 (n, N) pairs (n = 1000, N = 100: 799 instead of 800).  Host helper vs numpy on a sweep."""
+    import numpy as np
+    bad = []
+    for n in (100, 250, 500, 1000, 2000, 4000):
+        for N in list(range(1, 260)) + [n]:
+            if N > n:
+                continue
+            ref = [int(s) for s in list(np.linspace(0, np.sqrt(n * 0.8), N) ** 2)]
+            got = L.ddim_timesteps(n, N, "quad")
+            if got != ref:
+                bad.append((n, N))
+            assert L.ddim_timesteps(n, N, "uniform") == list(range(0, n, n // N))
+    assert not bad, bad[:10]
+    assert L.ddim_timesteps(1000, 100, "quad")[-1] == 800 and L.ddim_timesteps(1000, 16, "quad")[1:4] == [3, 14, 31]
+    with pytest.raises(RuntimeError, match="bad schedule"):
+        L.ddim_timesteps(10, 11, "quad")

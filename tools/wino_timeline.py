@@ -44,5 +44,12 @@ nch = cin // 8
 print(f"B={B} {cin}->{cout} {hw}x{hw}: {us:.1f} us/launch ({flops / us / 1e6:.1f} algorithmic TFLOP/s), {len(d)} workgroups x {per} tiles, "
       f"span {end.max():.1f} us | prologue {np.mean(pro - st):.2f} us | {np.mean(loop - pro) / per:.2f} us per tile (K loop + epilogue)")
 print(f"   {cyc:.0f} cycles per tile = {cyc / nch:.0f} per chunk incl. the epilogue (matrix floor 4096 per chunk and SIMD), clock {clk:.2f} GHz")
-if d[:, 8:13].max() > 0:
+if int(os.environ.get("MCEDM_WINO_MODE", "0")) & 16:
+    nst = nch // 2
+    print("   wave 0 cycles per slot of a stage (2 chunks = 8 slots of 8 MFMAs; floor 512 alone / 1024 with the SIMD's other wave): "
+          + "  ".join(f"s{j} {np.mean(d[:, 8 + j]) / nst / per:.0f}" for j in range(8)))
+elif int(os.environ.get("MCEDM_WINO_MODE", "0")) & 32:
+    print("   wave 0 cycles per TILE in the epilogue: " + "  ".join(f"{nm} {np.mean(d[:, 8 + j]) / per:.0f}" for j, nm in enumerate(
+        ["nu-transform + requests", "exchange rounds", "stores", "statistics", "accumulator init"])))
+elif d[:, 8:13].max() > 0:
     print("   wave 0 cycles per chunk: " + "  ".join(f"{nm} {np.mean(d[:, 8 + j]) / nch / per:.0f}" for j, nm in enumerate(["top", "mfma stream", "barrier", "epilogue"])))
