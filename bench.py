@@ -64,6 +64,13 @@ WORKLOADS = {
 REPAINT = dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32, n_repeat=32, n_time_h=0, n_time_u=64,
                name="SWE dam-break 128x128 RePaint (n_time_h=0, n_time_u=64, 32 resample loops/step), DDPM U-Net ch=64 "
                     "(BASELINE config 5)")
+# Algorithmic cost of ONE U-Net forward per sample (2 x MAC of conv / linear / attention; bytes of the fused
+# schedule): (GFLOP, MB).  darcy128 is the s128 network with 1-channel input / output (the difference is < 0.1 %).
+ALGORITHMIC = {"s32": (1.1115, 20.3), "ref128": (18.787, 230.0), "s128l3": (70.759, 452.5), "s128": (70.843, 463.9),
+               "darcy128": (70.843, 463.9)}
+# kernels bound by HBM rather than by the matrix pipe (their `gbps` against the 8 TB/s roofline is the number that matters)
+HBM_BOUND_KERNELS = ("gn_bwd_kernel", "conv_small_cout_kernel", "act_materialize_kernel", "gn_coef_kernel", "wgrad_reduce_kernel",
+                     "adam_ema_kernel", "heun", "edm_loss_kernel", "sqnorm_kernel", "gelu", "pack_conv_kernel", "wino_pack_kernel")
 TRAIN_LEG_TIMEOUT_S = 300      # watchdog of the multi-rank training leg (an untimed extra of the line)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
@@ -360,6 +367,28 @@ def kernel_table(prof):
     return rows
 
 
+def hbm_bound_rows(prof):
+    """The HBM-bound kernels of a profile with their achieved fraction of the 8 TB/s roofline on ALGORITHMIC bytes."""
+    rows = [r for r in kernel_table(prof) if any(k in r["name"] for k in HBM_BOUND_KERNELS)]
+    return [dict(r, hbm_frac=round(r["gbps"] / PEAK_HBM_GBPS, 3)) for r in rows]
+
+
+def fractions(key, states_per_s, fwd_ms, B):
+    """Both roofline fractions SURVEY.md 8(d) asks for next to every number, on the algorithmic cost of the workload:
+    per U-Net forward (batch B in fwd_ms) and per denoised state (35 forwards) at the measured whole-job rate."""
+    if key not in ALGORITHMIC:
+        return {}
+    gf, mb = ALGORITHMIC[key]
+    nfe = 2 * STEPS - 1
+    return {"forward_fp32_frac_algorithmic": gf * 1e9 * B / (fwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "forward_hbm_frac": mb * 1e6 * B / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            "per_state": {"gflop": gf * nfe, "gbyte": mb * nfe / 1e3,
+                          "fp32_frac": states_per_s * gf * nfe * 1e9 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                          "hbm_frac": states_per_s * mb * nfe * 1e6 / 1e9 / PEAK_HBM_GBPS,
+                          "note": "fp32 MFMA binds (ridge 19.7 flop/B, the network's AI is 55-156): at the fp32 peak the HBM "
+                                  "fraction cannot exceed 0.13 (ch=128) / 0.24 (ch=64, 128^2) / 0.36 (32^2)"}}
+
+
 def roofline_of(prof):
     if not prof:
         return None
@@ -461,30 +490,45 @@ def main():
                        "launch": "eager" if args.no_graph else "one HIP graph per sampler call"},
             "timed_with_profiler": False, "unet_fwd_ms": fwd_ms, "unet_fwd_batch": B, "train_step_ms": train_ms_,
             "train_samples_per_sec": (B * world / (train_ms_ * 1e-3)) if train_ms_ else None,
-            "roofline": roofline_of(prof), "kernels": kernel_table(prof)[:8], "csrc_digest": csrc_digest(),
+            "roofline": roofline_of(prof), "kernels": kernel_table(prof)[:8], "hbm_bound_kernels": hbm_bound_rows(prof),
+            "csrc_digest": csrc_digest(),
+            **(fractions(args.workload, states / elapsed / world, fwd_ms, B) if not repaint else {}),
         }
 
     # one data-parallel training step (models/mcedm.py:254-281 + clip/Adam/EMA), outside the timed region:
     # noise -> denoise(training) -> loss -> backward -> gradient all-reduce -> fused clip+Adam+EMA
     train_ms, train_prof, train_error = None, None, None
 
+    train_multi, phase = None, {"name": "not started"}
+
     def train_leg():
         from mcedm_amd.train import FlatTrainState
-        ts = FlatTrainState(run.plan, run.params, packed=run.packed)
         gen = torch.Generator(device="cpu").manual_seed(7 + rank)
         xs = torch.randn(B, 2, H, W, generator=gen).to(device)
         nz = torch.randn(B, 2, H, W, generator=gen).to(device)
         rn = torch.randn(B, generator=gen).to(device)
-        ts.step(xs, run.cond, run.mask, nz, rn)
-        barrier()
-        t1 = time.perf_counter()
-        nt = 3
-        for _ in range(nt):
-            loss = ts.step(xs, run.cond, run.mask, nz, rn)
-        barrier()
-        ms = (time.perf_counter() - t1) / nt * 1e3
-        assert torch.isfinite(loss).all()
-        tp = None
+
+        def timed(ts, what, nt=3, **kw):
+            """1 warm-up + nt steps between barrier + synchronize brackets; MAX over ranks."""
+            phase["name"] = what
+            ts.step(xs, run.cond, run.mask, nz, rn, **kw)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(nt):
+                loss = ts.step(xs, run.cond, run.mask, nz, rn, **kw)
+            barrier()
+            ms_ = (time.perf_counter() - t1) / nt * 1e3
+            assert torch.isfinite(loss).all()
+            if world > 1:
+                t = torch.tensor([ms_], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms_ = float(t)
+            return ms_
+
+        ts = FlatTrainState(run.plan, run.params, packed=run.packed)          # up to 4 buckets (the default of the trainer)
+        nb = len(ts.sync.ranges)
+        ms = timed(ts, f"step, {nb} bucket(s)")
+        tp, multi = None, None
         if world == 1:            # one more step, launched eagerly with HIP event pairs around every kernel (single rank
                                   # only: a step contains the gradient all-reduce, which every rank must enter)
             ts.use_graph = False
@@ -495,12 +539,30 @@ def main():
             torch.cuda.synchronize()
             lib.prof_enable(False)
             tp = lib.prof_report()
+        else:
+            # What the first multi-GPU record needs to separate compute, exchange and overlap: the same
+            # step WITHOUT the gradient exchange (backward + clip + Adam + EMA only), and with ONE bucket (the whole flat
+            # gradient in one all-reduce behind the backward: no overlap) next to the bucketed, overlapped step above.
+            ms_noex = timed(ts, "step without the exchange", exchange=False)
+            nbytes = ts.flat_g.numel() * ts.flat_g.element_size()
+            bucket_bytes = [(hi - lo) * 4 for lo, hi in ts.sync.ranges]
+            del ts
+            ts1 = FlatTrainState(run.plan, run.params, packed=run.packed, max_buckets=1)
+            ms1 = timed(ts1, "step, 1 bucket")
+            ts = ts1
+            multi = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "allreduce_bytes_per_step": nbytes,
+                     "bucket_bytes": bucket_bytes, "step_ms": {f"buckets_{nb}": ms, "buckets_1": ms1},
+                     "step_ms_no_exchange": ms_noex,
+                     "exchange_exposed_ms": {f"buckets_{nb}": ms - ms_noex, "buckets_1": ms1 - ms_noex},
+                     "note": "MAX over ranks, 1 warm-up + 3 steps each; exposed = step - step without the all-reduce; "
+                             "buckets_1 = no overlap with the backward (one all-reduce of the whole flat gradient after it)"}
         del ts
-        return ms, tp
+        phase["name"] = "done"
+        return ms, tp, multi
 
     if not args.no_train:
         if world == 1:
-            train_ms, train_prof = train_leg()
+            train_ms, train_prof, train_multi = train_leg()
         else:
             # The multi-rank step (bucketed RCCL all-reduce on a side stream under the backward) is an untimed extra of this
             # line: neither an exception nor a stuck collective in it may take the headline measurement with it.  A watchdog
@@ -509,9 +571,15 @@ def main():
             emergency = {"line": None}
 
             def bail():
+                # the headline line still goes out (the sampler measurement stands), but the process ends NON-ZERO: a stuck
+                # collective or backward must not read as success to torchrun / the driver
                 if rank == 0 and emergency["line"] is not None:
-                    print(json.dumps(dict(emergency["line"], train_error=f"multi-rank training leg exceeded {TRAIN_LEG_TIMEOUT_S} s")), flush=True)
-                os._exit(0 if rank != 0 or emergency["line"] is not None else 1)
+                    print(json.dumps(dict(emergency["line"], status="train_leg_timeout",
+                                          train_error=f"multi-rank training leg exceeded {TRAIN_LEG_TIMEOUT_S} s in phase "
+                                                      f"'{phase['name']}' (rank 0's view)")), flush=True)
+                sys.stderr.write(f"[bench rank {rank}] training-leg watchdog fired in phase '{phase['name']}'\n")
+                sys.stderr.flush()
+                os._exit(3)
 
             if rank == 0:
                 emergency["line"] = headline_line(None)
@@ -519,9 +587,9 @@ def main():
             dog.daemon = True
             dog.start()
             try:
-                train_ms, train_prof = train_leg()
+                train_ms, train_prof, train_multi = train_leg()
             except Exception as e:      # noqa: BLE001  (reported in the line; the sampler measurement stands)
-                train_error = f"{type(e).__name__}: {str(e)[:300]}"
+                train_error = f"{type(e).__name__} in phase '{phase['name']}': {str(e)[:300]}"
             dog.cancel()
 
     if rank != 0:
@@ -530,8 +598,12 @@ def main():
         return
 
     line = headline_line(train_ms)
+    line["status"] = "ok"
     if train_error:
         line["train_error"] = train_error
+        line["status"] = "train_leg_failed"
+    if train_multi:
+        line["train_multi_gpu"] = train_multi
     if train_ms and train_prof:
         tflops = sum(r["flops"] for r in train_prof)           # forward + data-gradient + weight-gradient GEMM flops
         dom = sorted(train_prof, key=lambda r: -r["total_ms"])[:3]
@@ -543,7 +615,8 @@ def main():
                     "step timed over 3 graph-replayed steps, per-kernel rows from one extra eager step with event pairs",
             "kernels": [{"name": r["name"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
                          "tflops": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12, 1),
-                         "frac": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)} for r in dom]}
+                         "frac": round(r["flops"] / (r["total_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)} for r in dom],
+            "hbm_bound_kernels": hbm_bound_rows(train_prof)}
     if prof and args.profile_steps > 0:
         flops_state = sum(r["flops"] for r in prof) / (args.profile_steps * B)
         line["forward_fp32_frac"] = flops_state * B * world * args.steps / elapsed / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world)
@@ -570,6 +643,7 @@ def main():
                                       "fp32_frac_whole_sampler": sum(r["flops"] for r in p2) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                       "dominant_kernel": ro["kernel"], "dominant_kernel_tflops": ro["achieved"],
                                       "dominant_kernel_frac": ro["frac"], "dominant_kernel_share": ro["share_of_kernel_time"]}
+            line["secondary"][key].update(fractions(key, r2.B / dt, line["secondary"][key]["unet_fwd_ms"], r2.B))
             del r2
             torch.cuda.empty_cache()
 

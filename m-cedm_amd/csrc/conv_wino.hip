@@ -609,8 +609,10 @@ int launch_pack_conv_wino(const float* w, float* dst, int Cout, int Cin, int tra
 }
 
 bool conv_wino_applicable(const ConvArgs& a, int taps) {
-  return taps == 9 && a.wino && (a.resample == RS_NONE || a.resample == RS_UP) && a.Cout % 64 == 0 && a.H % WPH == 0 &&
-         a.W % WPW == 0 && (a.Ca + a.Cb) % WKC == 0 && a.Ca % WKC == 0 && !a.sk_wpk &&
+  // the plain variant stages its input with 16-byte loads (raw_load1): misaligned views take the direct kernel
+  const bool aligned = a.resample != RS_NONE || (((size_t)a.xa | (size_t)a.xb) & 15) == 0;
+  return taps == 9 && a.wino && (a.resample == RS_NONE || a.resample == RS_UP) && a.Cout % 64 == 0 && a.H % WPH == 0 && aligned &&
+         a.W % WPW == 0 && (a.Ca + a.Cb) % WKC == 0 && a.Ca % WKC == 0 && !a.sk_wpk && ((size_t)a.wino & 15) == 0 &&
          (!a.res || a.res_mode == RS_NONE || a.res_mode == RS_UP || a.res_mode == RS_DOWN) && (a.Ca + a.Cb) <= 1024;
 }
 

@@ -68,7 +68,7 @@ extern "C" int mcedm_op_conv_wino(const float* xa, const float* xb, int Ca, int 
   a.Hs = resample == RS_UP ? H / 2 : H; a.Ws = resample == RS_UP ? W / 2 : W;
   a.wino = wino; a.bias = bias; a.res = res; a.res_mode = res_mode;
   a.out = out; a.Cout = Cout; a.B = B;
-  MCEDM_REQUIRE(conv_wino_applicable(a, 9), "op_conv_wino: needs Cout %% 128 == 0, H %% 8 == 0, W %% 16 == 0, Cin %% 8 == 0");
+  MCEDM_REQUIRE(conv_wino_applicable(a, 9), "op_conv_wino: needs Cout %% 64 == 0, H %% 8 == 0, W %% 16 == 0, Cin %% 8 == 0 and 16-byte aligned inputs / weight table");
   return launch_conv_wino(a, (hipStream_t)stream);
 }
 

@@ -306,7 +306,8 @@ class PlCondEdm(_EvalMetrics, _Base):
         dx = None
         if self.dx_cond and torch.rand(1) > 0.1:                 # models/ddim.py:1672-1677: dx off with a small probability
             dx = self.get_dx_input(cond_in[:, 0:self.h_ch], u_noise)     # on the NOISED target; carries no gradient
-        torch.rand(1)                                            # the cond_p draw of models/ddim.py:1683 (cond_p = 1)
+        if torch.rand(1) >= self.cond_p:                         # models/ddim.py:1683-1684: conditioning off for this batch
+            cond_in = None                                       # (the network then reads zeros, adm_blocks.py:328-331)
         loss = _EdmTrainLoss.apply(self, u, u_noise, sigma, cond_in, None, dx, *self.model.parameters())
         self.log("train_loss", loss, prog_bar=True, on_epoch=True, on_step=False, sync_dist=True)
         return loss

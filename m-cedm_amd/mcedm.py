@@ -125,12 +125,20 @@ class PlMcedm(_Base):
         self.save_hyperparameters()
         m, o, d = hparams.model, hparams.optimization, hparams.data
         self.cond_p = 1.0
-        for flag in ("dx_cond", "add_cond_mask", "add_xt"):
-            if getattr(m, flag, False) if hasattr(m, flag) else False:
-                raise NotImplementedError(f"hparams.model.{flag}=True is outside the MI355X hot path (SURVEY.md 8a)")
+        if getattr(m, "dx_cond", False) if hasattr(m, "dx_cond") else False:
+            raise NotImplementedError("hparams.model.dx_cond=True cannot run for the joint model in the reference either "
+                                      "(PlMcedm.get_dx_pde slices the wrong axis, models/mcedm.py:500-518); see DESIGN.md")
         if not str(hparams.name).startswith("adm"):
             raise NotImplementedError("only the ADM/EDM U-Net (hparams.name = 'adm*') is on the hot path")
-        self.dx_cond = self.add_cond_mask = self.add_xt = False
+        self.dx_cond = False
+        # models/mcedm.py:25-34: the two optional widenings of the conditioning input.  Like the reference, the constructor
+        # rewrites hparams.model.cond_channels before the network is built (the C ABI takes any cond_channels).
+        self.add_cond_mask = bool(m.add_cond_mask) if hasattr(m, "add_cond_mask") else False
+        self.add_xt = bool(m.add_xt) if hasattr(m, "add_xt") else False
+        if self.add_cond_mask:
+            m.cond_channels = m.cond_channels + m.in_channels          # the observation mask rides along (SSSD-S4 style)
+        if self.add_xt:
+            m.cond_channels = m.cond_channels + 2                      # the grid coordinates dx, dt
         self.model = DhariwalUNet(hparams)
         self.ema_model = EmaModel(self.model, beta=m.ema_rate) if m.ema else None
         # EDM preconditioning constants (mcedm.py:45-50)
@@ -227,7 +235,15 @@ class PlMcedm(_Base):
         return (sigma ** 2 + self.sigma_data ** 2) / (sigma * self.sigma_data) ** 2
 
     def get_cond_in(self, x, mask, dx=None, dt=None):
-        return x * (1 - mask) + torch.randn_like(x) * mask
+        """models/mcedm.py:241-252 ('b h w c' tensors): observed values, noise where the state is missing -- or, with
+        add_cond_mask, zeros there plus the observation mask as extra channels; add_xt appends the batch's dx / dt fields."""
+        if self.add_cond_mask:
+            cond_in = torch.cat([x * (1 - mask), (1. - mask)], dim=-1)
+        else:
+            cond_in = x * (1 - mask) + torch.randn_like(x) * mask
+        if self.add_xt:
+            cond_in = torch.cat([cond_in, dx, dt], dim=-1)
+        return cond_in
 
     # ---- preconditioned network (HIP) ------------------------------------------------------------------
     def _net(self, model):

@@ -264,16 +264,18 @@ class FlatTrainState:
             raise RuntimeError(f"optimizer state: parameters disagree on the step count ({sorted(steps)})")
         self.step_count = steps.pop()
 
-    def step(self, x, cond_in, mask, noise, rnd_normal, dx_fn=None):
+    def step(self, x, cond_in, mask, noise, rnd_normal, dx_fn=None, exchange: bool = True):
         """One optimisation step on this rank's shard (all tensors NCHW fp32 on the device). Returns the local loss (a
         tensor that the next step overwrites when the step is graph-replayed).  dx_fn: see _forward_backward (such steps are
-        launched eagerly: the callable is the caller's code)."""
+        launched eagerly: the callable is the caller's code).  exchange=False skips the gradient all-reduce (measurement
+        only -- bench.py separates compute from exchange with it; the replicas then drift apart)."""
         if self.use_graph and self.world == 1 and x.is_cuda and dx_fn is None:
             loss = self._graphed_forward_backward(x, cond_in, mask, noise, rnd_normal)
         else:
             loss = self._forward_backward(x, cond_in, mask, noise, rnd_normal, dx_fn)
-        self.sync.launch()                 # bucketed sum all-reduce, overlapping the tail of the backward
-        self.sync.join()
+        if exchange:
+            self.sync.launch()             # bucketed sum all-reduce, overlapping the tail of the backward
+            self.sync.join()
         self.step_count += 1
         sqn = _lib.sqnorm if self.red_scratch is None else (lambda g, out: _lib.sqnorm(g, out, scratch=self.red_scratch))
         clip_adam_ema_(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.flat_ema, self.step_count, self.world, self.hp,

@@ -142,6 +142,32 @@ def training_nchw(h, u, mask, cond_noise):
     return x.permute(0, 3, 1, 2).contiguous(), cond_in, mask.permute(0, 3, 1, 2).contiguous()
 
 
+# ---- the optional widenings of the joint model's conditioning input (models/mcedm.py:25-34, 241-252) ---------------------
+# tag -> (add_cond_mask, add_xt): the observation mask as extra channels (+ in_channels), the dx / dt fields (+ 2)
+COND_IN_CASES = {"mask": (True, False), "xt": (False, True), "mask_xt": (True, True)}
+
+
+def cond_in_cfg(tag: str) -> "orc.UNetConfig":
+    add_mask, add_xt = COND_IN_CASES[tag]
+    return orc.UNetConfig(cond_channels=2 + (2 if add_mask else 0) + (2 if add_xt else 0))
+
+
+def cond_in_xt(B: int = 4, T: int = 32, X: int = 32):
+    """dx, dt of the 5-tuple batch as fields 'b h w 1' (what get_cond_in concatenates when add_xt is set)."""
+    return randn("condin/dx", B, T, X, 1) * 0.1 + 0.5, randn("condin/dt", B, T, X, 1) * 0.1 + 0.3
+
+
+def cond_in_nchw(tag, h, u, mask, cond_noise, dx, dt):
+    """data_transform + get_cond_in of models/mcedm.py:241-252 restated -> (x, cond_in, mask) in NCHW."""
+    add_mask, add_xt = COND_IN_CASES[tag]
+    st = TRAIN_NORM_STATS
+    x = torch.cat([(h - st[0]) / st[1], (u - st[2]) / st[3]], dim=-1)
+    cond = torch.cat([x * (1 - mask), 1.0 - mask], dim=-1) if add_mask else orc.cond_input(x, mask, cond_noise)
+    if add_xt:
+        cond = torch.cat([cond, dx, dt], dim=-1)
+    return x.permute(0, 3, 1, 2).contiguous(), cond.permute(0, 3, 1, 2).contiguous(), mask.permute(0, 3, 1, 2).contiguous()
+
+
 # ---- single-task conditional EDM (PlCondEdm, configs/model/adm_edm_cond_h_res32.yaml): h -> u, 1 + 1 -> 1 channels
 CFG_C = orc.UNetConfig(in_channels=1, cond_channels=1, out_ch=1)
 COND_SAMPLER_CASES = {"det": 0.0, "churn": 15.0}
@@ -353,7 +379,9 @@ def eval_cond_inputs(tag: str):
 
 # ---- DDIM sampler with RePaint loops (PlDdim.sample_with_repeat, models/ddim.py:808-913) on the res-32 DDPM U-Net -------------
 # tag -> (timesteps, skip_type, eta, n_repeat, n_time_h, n_time_u)
-DDIM_CASES = {"uni_r2": (5, "uniform", 0.0, 2, 0, 16), "quad_eta_r3": (4, "quad", 0.01, 3, 8, 0)}
+# quad16 (round 4): 16 quad steps of 1000 -- int(np.linspace(0, sqrt(800), 16) ** 2) = 0, 3, 14, 31, 56 ...; the
+# hi * i / (N - 1) evaluation order lands on 32 / 128 / 288 instead of 31 / 127 / 287
+DDIM_CASES = {"uni_r2": (5, "uniform", 0.0, 2, 0, 16), "quad_eta_r3": (4, "quad", 0.01, 3, 8, 0), "quad16": (16, "quad", 0.0, 1, 0, 16)}
 EVAL_DDIM = ("swe_per", 2, 4, "uniform", 0.0, 2, 0, 16)          # system, n_samples, then as above: PlDdim.test_step with type 'ddim'
 
 

@@ -96,16 +96,26 @@ def test_sample_edm_dx_cond_golden(golden, mode, system, guided):
     if system == "darcy":
         # The Darcy log-probability gradient is a step-like function of the residual (zero or O(1e5), 1e-5 wide transition,
         # see tests/test_hip_cond_edm.py): which grid cells sit inside the transition is decided by the last bits of the
-        # residual, and a flipped cell changes the network INPUT there by O(1e5).  Observed on the device: the trajectory
-        # agrees to 3e-8 through step 6, then one cell flips and its receptive field (26 of 3072 values in the enc case)
-        # moves by up to 2e-3 relative; the cat case happens to agree to 7e-7 throughout.  So: the early trajectory at the
-        # bar, the final state at the bar outside the few flipped receptive fields, everything finite.  The op itself is
-        # pinned at 1e-6 (tests/test_pde.py), the dx path end to end by the SWE cases.
+        # residual, and a flipped cell changes the network INPUT there by O(1e5).  How much of that the REFERENCE ITSELF shows is
+        # measured, not asserted (round 4, oracle/make_golden_dxcond_stability.py -> tests/golden/dxcond_stability.npz): the
+        # reference run on 1 thread instead of 8, or with one input moved by one unit in the last place, differs from its own
+        # 8-thread trajectory in 0.23-0.78 % of the final state's entries of the enc case (first at sampled step 12, never by
+        # step 6) and in none of the cat case.  The device is held to that: the cat case at the bar throughout; the enc case at
+        # the bar through step 6 and, in the final state, at most 4x the reference's own worst self-disagreement outside it
+        # (the device differs from the reference in the summation order of every convolution, not of one).
+        stab = golden("dxcond_stability.npz")
+        ref_self = float(stab[f"{mode}_darcy::final_bad_frac"].max())
+        assert int(stab[f"{mode}_darcy::first_bad_step"][stab[f"{mode}_darcy::first_bad_step"] >= 0].min(initial=99)) > 6
         close(xs[:, 0:7:6], traj[:, :2], rtol=1e-4, atol=1e-5 * scale)
         bad = (xs[:, -1:].cpu() - ref).abs() > 1e-5 * scale + 1e-4 * ref.abs()
-        # each flipped cell moves its receptive field, ~26 of the 3072 values (0.85 %); which and how many cells flip changes with any
-        # last-bit change of the network (one or three observed): allow six
-        assert float(bad.double().mean()) < 0.05 and bool(torch.isfinite(xs).all())
+        frac = float(bad.double().mean())
+        print(f"   entries of the final state outside the bar: {frac * 100:.3f} % (reference vs itself: up to {ref_self * 100:.3f} %)")
+        assert bool(torch.isfinite(xs).all())
+        if ref_self == 0.0:
+            close(xs[:, -1:], ref, rtol=1e-4, atol=1e-5 * scale)
+            close(xs[:, ::6], traj, rtol=1e-4, atol=1e-5 * scale)
+        else:
+            assert frac <= 4.0 * ref_self, (frac, ref_self)
         return
     close(xs[:, -1:], ref, rtol=1e-4, atol=1e-5 * scale)
     close(xs[:, ::6], traj, rtol=1e-4, atol=1e-5 * scale)

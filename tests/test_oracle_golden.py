@@ -364,3 +364,44 @@ def test_dx_cond_network_and_sampler(golden, mode):
                                      dx_input=lambda hh, d: orc.guidance_dx_cond("swe_per", hh, d, st))
             ref = torch.as_tensor(g["enc_swe_per_xs_last"])
             torch.testing.assert_close(xs, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("tag", list(fx.COND_IN_CASES))
+def test_cond_in_variants(golden, tag):
+    """models/mcedm.py:25-34, 241-252 (round 4): add_cond_mask / add_xt widen the conditioning input; get_cond_in, the training
+    loss with its gradients and the sampler of the reference, reproduced by the oracle on the widened network."""
+    g = golden("cond_in.npz")
+    cfg = fx.cond_in_cfg(tag)
+    P = orc.make_params(cfg, int(g["seed"]))
+    h, u, mask, cond_noise, noise, rnd_normal = fx.training_inputs()
+    dx, dt = fx.cond_in_xt()
+    xc, cond_in, mc = fx.cond_in_nchw(tag, h, u, mask, cond_noise, dx, dt)
+    close(cond_in.permute(0, 2, 3, 1).contiguous(), g[f"{tag}::cond_in"], rtol=0, atol=0)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss = orc.training_loss(Pg, cfg, xc, cond_in, mc, noise, rnd_normal)
+    loss.backward()
+    close(loss.detach(), g[f"{tag}::loss"], rtol=1e-5, atol=1e-6)
+    for n in fx.TRAIN_GRAD_NAMES:
+        ref = torch.as_tensor(g[f"{tag}::grad::{n}"])
+        close(Pg[n].grad, ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
+    init = fx.randn(f"condin/{tag}/init", 4, 2, 32, 32)
+    with torch.no_grad():
+        xs = orc.sample_edm(P, cfg, cond_in, mc, orc.SamplerParams(timesteps=18), init)
+    close(xs, g[f"{tag}::xs_last"], rtol=1e-3, atol=1e-4)
+
+
+def test_cond_edm_training_with_the_conditioning_dropped(golden):
+    """models/ddim.py:1683-1684 with cond_p = 0: the batch trains with cond = None, i.e. zeros (adm_blocks.py:328-331)."""
+    g = golden("cond_in.npz")
+    cfg = fx.CFG_C
+    P = orc.make_params(cfg, 13)
+    h, u, noise, rnd_normal = fx.cond_training_inputs()
+    st = fx.TRAIN_NORM_STATS
+    hn, un = ((h - st[0]) / st[1]).permute(0, 3, 1, 2), ((u - st[2]) / st[3]).permute(0, 3, 1, 2)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss = orc.training_loss_cond(Pg, cfg, un, torch.zeros_like(hn), noise, rnd_normal)
+    loss.backward()
+    close(loss.detach(), g["cond_drop::loss"], rtol=1e-5, atol=1e-6)
+    for n in fx.COND_GRAD_NAMES:
+        ref = torch.as_tensor(g[f"cond_drop::grad::{n}"])
+        close(Pg[n].grad, ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
