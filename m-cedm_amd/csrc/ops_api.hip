@@ -1,5 +1,6 @@
 // ops_api.hip -- kernel-level C entry points (tests, per-kernel timing).
 #include "common.hpp"
+#include "conv_wino.hpp"
 #include "bwd.hpp"
 
 using namespace mcedm;
@@ -144,6 +145,11 @@ extern "C" int mcedm_op_set_conv8(int enable) {
 
 extern "C" int mcedm_op_set_conv_wino(int enable) {
   set_conv_wino(enable);
+  return MCEDM_OK;
+}
+
+extern "C" int mcedm_op_set_conv_wino1(int enable) {
+  set_conv_wino1(enable);
   return MCEDM_OK;
 }
 

@@ -125,3 +125,40 @@ def test_conv_wino_rejects_unserved_shapes(lib):
     w = lib.op_pack_conv_wino(dev(fx.randn("wino/rej/w", 128, 8, 3, 3)))
     with pytest.raises(RuntimeError):
         lib.op_conv_wino(dev(torch.zeros(1, 8, 12, 16)), None, w, None, 128)
+
+
+@pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,up,res_mode", [
+    (2, 128, 0, 128, 32, 32, 0, 0),       # plain, residual at the same size
+    (1, 64, 64, 128, 16, 32, 0, -1),      # channel concat, no residual
+    (2, 128, 128, 256, 16, 16, 0, 0),     # two 128-channel output blocks, 32 chunks
+    (2, 128, 0, 128, 32, 32, 1, 1),       # up-sampled input, residual at half size (the up blocks' conv0 + skip)
+    (2, 128, 0, 128, 16, 32, 0, 2),       # residual = 2 x 2 mean of a double-size source (the down blocks' conv1)
+    (3, 24, 0, 128, 24, 16, 0, 0),        # odd chunk count, three tiles per sample
+])
+def test_one_wave_per_simd_kernel_is_bit_identical(lib, B, Ca, Cb, Cout, H, W, up, res_mode):
+    """conv_wino1_kernel (round 4: one wave per SIMD, all sixteen positions of a 32-channel block in one wave's AccVGPRs,
+    register-local output transform) against conv_wino_kernel<WinoCfg<4>> (two waves per SIMD, LDS exchange): same tile, same
+    order of every sum -- the outputs must be equal bit for bit, in every resampling / residual mode."""
+    tag = f"wino1/{B}{Ca}{Cb}{Cout}{H}{W}{up}{res_mode}"
+    Cin = Ca + Cb
+    hs, wsz = (H // 2, W // 2) if up else (H, W)
+    xa = dev(fx.randn(tag + "/xa", B, Ca, hs, wsz))
+    xb = dev(fx.randn(tag + "/xb", B, Cb, hs, wsz)) if Cb else None
+    w = dev(fx.randn(tag + "/w", Cout, Cin, 3, 3) / (Cin * 9) ** 0.5)
+    b = dev(fx.randn(tag + "/b", Cout) * 0.1)
+    res = None
+    if res_mode >= 0:
+        rh, rw = (H // 2, W // 2) if res_mode == 1 else (2 * H, 2 * W) if res_mode == 2 else (H, W)
+        res = dev(fx.randn(tag + "/res", B, Cout, rh, rw))
+    coef = dev(coef_table(tag, B, Cin))
+    wino = lib.op_pack_conv_wino(w)
+    outs = []
+    for which in (0, 1):
+        lib.set_conv_wino1(which)
+        try:
+            outs.append(lib.op_conv_wino(xa, xb, wino, b, Cout, coef=coef, act=1, resample=1 if up else 0, res=res,
+                                         res_mode=max(res_mode, 0)).clone())
+        finally:
+            lib.set_conv_wino1(-1)
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1])

@@ -44,7 +44,10 @@ nch = cin // 8
 print(f"B={B} {cin}->{cout} {hw}x{hw}: {us:.1f} us/launch ({flops / us / 1e6:.1f} algorithmic TFLOP/s), {len(d)} workgroups x {per} tiles, "
       f"span {end.max():.1f} us | prologue {np.mean(pro - st):.2f} us | {np.mean(loop - pro) / per:.2f} us per tile (K loop + epilogue)")
 print(f"   {cyc:.0f} cycles per tile = {cyc / nch:.0f} per chunk incl. the epilogue (matrix floor 4096 per chunk and SIMD), clock {clk:.2f} GHz")
-if int(os.environ.get("MCEDM_WINO_MODE", "0")) & 16:
+if os.environ.get("MCEDM_WINO1", "1") != "0" and cout % 128 == 0:
+    print(f"   one wave per SIMD: K loop {np.mean(d[:, 8]) / per / nch:.0f} cycles per chunk, epilogue + accumulator init {np.mean(d[:, 9]) / per:.0f} cycles per tile "
+          f"(= {np.mean(d[:, 9]) / per / nch:.0f} per chunk)")
+elif int(os.environ.get("MCEDM_WINO_MODE", "0")) & 16:
     nst = nch // 2
     print("   wave 0 cycles per slot of a stage (2 chunks = 8 slots of 8 MFMAs; floor 512 alone / 1024 with the SIMD's other wave): "
           + "  ".join(f"s{j} {np.mean(d[:, 8 + j]) / nst / per:.0f}" for j in range(8)))
