@@ -25,6 +25,7 @@
 
 #include "common.hpp"
 #include "conv_tile.hpp"
+#include "pack.hpp"
 #include "prof.hpp"
 
 namespace mcedm {
@@ -559,41 +560,11 @@ size_t conv_packed_floats(int Cout, int Cin, int taps) {
   return (size_t)ceil_div(Cin, KC) * taps * KC * cout_padded(Cout);
 }
 
-// dst[((chunk*taps + tap)*KC + cil) * CoutP + co]; zero-padded in ci and co.
+// dst[((chunk*taps + tap)*KC + cil) * CoutP + co]; zero-padded in ci and co (pack.hpp pack_conv_value).
 __global__ void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int taps,
                                  int KC, int coutp, int qkv_heads, int transpose_flip, size_t total) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int co = (int)(i % coutp);
-    size_t t = i / coutp;
-    const int cil = (int)(t % KC); t /= KC;
-    const int tap = (int)(t % taps);
-    const int chunk = (int)(t / taps);
-    const int ci = chunk * KC + cil;
-    float v = 0.f;
-    if (co < Cout && ci < Cin) {
-      if (!transpose_flip) {
-        int cs = co;
-        if (qkv_heads > 0) {  // packed row (head, which, c) <- reference row (head, c, which), adm_blocks.py:175
-          const int per = Cout / qkv_heads, d = per / 3;
-          const int h = co / per, rr = co % per, which = rr / d, c = rr % d;
-          cs = h * per + c * 3 + which;
-        }
-        v = w[((size_t)cs * Cin + ci) * taps + tap];
-      } else {
-        // dgrad: the GEMM's output channels are the conv's input channels and its K index runs over the conv's
-        // output channels; w is stored [K = Cin][Cout][taps], taps mirrored.  For the qkv conv the incoming
-        // gradient rows are in packed (head, which, c) order, so K index ci reads reference row (head, c, which).
-        int kk = ci;
-        if (qkv_heads > 0) {
-          const int per = Cin / qkv_heads, d = per / 3;
-          const int h = ci / per, rr = ci % per, which = rr / d, c = rr % d;
-          kk = h * per + c * 3 + which;
-        }
-        v = w[((size_t)kk * Cout + co) * taps + (taps - 1 - tap)];
-      }
-    }
-    dst[i] = v;
-  }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = pack_conv_value(w, i, Cout, Cin, taps, KC, coutp, qkv_heads, transpose_flip);
 }
 
 int launch_pack_conv(const float* w, float* dst, int Cout, int Cin, int taps, int qkv_heads, int transpose_flip,

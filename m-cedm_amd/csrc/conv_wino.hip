@@ -29,44 +29,17 @@
 #include <cstdlib>
 
 #include "conv_wino.hpp"
+#include "pack.hpp"
 #include "prof.hpp"
 
 namespace mcedm {
 
-// U = G g G^T for one (cout, cin): G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-// tflip: the data-gradient weights, w'[co][ci][a][b] = w[ci][co][2 - a][2 - b] (w is then [Cin][Cout][3][3])
+// U = G g G^T for every (cout, cin) of one weight tensor (pack.hpp wino_pack_elem)
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int coutp, int nch,
                                  int tflip) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= coutp * nch * WKC) return;
-  const int co = idx % coutp, ci = idx / coutp;
-  float g[3][3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      float v = 0.f;
-      if (co < Cout && ci < Cin) v = tflip ? w[((size_t)ci * Cout + co) * 9 + (2 - a) * 3 + (2 - b)] : w[((size_t)co * Cin + ci) * 9 + a * 3 + b];
-      g[a][b] = v;
-    }
-  float t[4][3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    t[0][b] = g[0][b];
-    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-    t[3][b] = g[2][b];
-  }
-  const int chunk = ci / WKC, k = ci % WKC, mb = co / 32, lane = (co & 31) + 32 * (k & 1), s = k >> 1;
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi) {
-    // column nu = 2 is stored NEGATED: the kernel's input transform produces -V[xi][2] (t1 - t2 instead of t2 - t1, which lets
-    // the four outputs of a row come out of two packed additions), and (-U) * (-V) = U * V bit for bit
-    const float u[4] = {t[xi][0], 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), -(0.5f * (t[xi][0] - t[xi][1] + t[xi][2])), t[xi][2]};
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
-      dst[((((size_t)chunk * (coutp / 32) + mb) * 16 + 4 * xi + nu) * 64 + lane) * 4 + s] = u[nu];
-  }
+  wino_pack_elem(w, dst, idx, Cout, Cin, coutp, tflip);
 }
 
 // UP: the conv input is the nearest-neighbour 2x up-sampling of the (activated) source (adm_blocks.py:69-73)

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "edm.hpp"
+#include "pack.hpp"
 #include "plan.hpp"
 #include "bwd.hpp"
 
@@ -264,6 +265,54 @@ __global__ void freqs_kernel(float* f, int half) {
   if (k < half) f[k] = powf(1.0f / 10000.0f, (float)k / (float)half);
 }
 
+// Every conv weight of a plan is re-laid per optimisation step (direct form, its data-gradient mirror, both again in
+// Winograd form): as one launch per table that was ~140 kernels of 4-5 us per training step (profiles/r3_train_kernel_stats.csv:
+// 805 + 560 calls in six steps).  The jobs are batched instead: one launch packs up to PACK_MAX tables, a fixed number of
+// workgroups per table walking its elements (pack.hpp holds the per-element bodies, shared with the one-table kernels).
+constexpr int PACK_MAX = 48;
+struct PackJob {
+  const float* w; float* dst;
+  int Cout, Cin, taps, KC, coutp, qkv_heads, tflip;
+  int kind;                     // 0: direct form (pack_conv_value), 1: Winograd F(2x2, 3x3) form (wino_pack_elem)
+  unsigned total;               // elements to walk: packed floats (direct) or coutp * nch * WKC (Winograd)
+};
+struct PackBatch { PackJob j[PACK_MAX]; };
+static_assert(sizeof(PackBatch) <= 4000, "kernel argument budget");
+
+__global__ void pack_batch_kernel(PackBatch b) {
+  const PackJob& J = b.j[blockIdx.y];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < J.total; i += gridDim.x * blockDim.x) {
+    if (J.kind == 0) J.dst[i] = pack_conv_value(J.w, i, J.Cout, J.Cin, J.taps, J.KC, J.coutp, J.qkv_heads, J.tflip);
+    else wino_pack_elem(J.w, J.dst, (int)i, J.Cout, J.Cin, J.coutp, J.tflip);
+  }
+}
+
+struct Packer {
+  PackBatch b;
+  int count = 0;
+  hipStream_t s;
+  int status = MCEDM_OK;
+  void flush() {
+    if (count == 0 || status != MCEDM_OK) { count = 0; return; }
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(48, count), dim3(256), 0, s, b);
+    if (hipGetLastError() != hipSuccess) { set_error("pack_batch_kernel launch failed"); status = MCEDM_ERR_HIP; }
+    count = 0;
+  }
+  void add(const PackJob& j) {
+    b.j[count] = j;
+    if (++count == PACK_MAX) flush();
+  }
+  void conv(const float* w, float* dst, int Cout, int Cin, int taps, int qkv_heads, int tflip) {
+    const size_t total = conv_packed_floats(Cout, Cin, taps);
+    if (total >= (1ull << 32)) { set_error("pack: table too large"); status = MCEDM_ERR_INVALID; return; }
+    add(PackJob{w, dst, Cout, Cin, taps, conv_kc_for(taps), cout_padded(Cout), qkv_heads, tflip, 0, (unsigned)total});
+  }
+  void wino(const float* w, float* dst, int Cout, int Cin, int tflip) {
+    const int coutp = cout_padded(Cout), nch = ceil_div(Cin, WKC);
+    add(PackJob{w, dst, Cout, Cin, 9, WKC, coutp, 0, tflip, 1, (unsigned)(coutp * nch * WKC)});
+  }
+};
+
 struct Copier {
   CopyBatch b;
   int count = 0;
@@ -281,20 +330,18 @@ struct Copier {
   }
 };
 
-static int pack_conv(const ConvP& c, const float* const* params, float* pk, Copier& cp, hipStream_t s) {
-  int rc = launch_pack_conv(params[c.w], pk + c.wpk, c.cout, c.cin, c.taps, c.qkv_heads, 0, s);
-  if (rc) return rc;
+static int pack_conv(const ConvP& c, const float* const* params, float* pk, Copier& cp, Packer& pp, hipStream_t s) {
+  pp.conv(params[c.w], pk + c.wpk, c.cout, c.cin, c.taps, c.qkv_heads, 0);
+  int rc = MCEDM_OK;
   if (c.qkv_heads > 0) rc = launch_pack_bias(params[c.b], pk + c.bias, c.cout, c.qkv_heads, s);
   else cp.add(params[c.b], pk + c.bias, c.cout);
   if (rc) return rc;
-  if (c.wpk_dgrad != NONE) {
-    // data-gradient GEMM: output channels = conv input channels; for the qkv conv the K index follows the packed
-    // (head, which, c) order of the incoming gradient rows
-    rc = launch_pack_conv(params[c.w], pk + c.wpk_dgrad, c.cin, c.cout, c.taps, c.qkv_heads, 1, s);
-  }
-  if (!rc && c.wino != NONE) rc = launch_pack_conv_wino(params[c.w], pk + c.wino, c.cout, c.cin, 0, s);
-  if (!rc && c.wino_dgrad != NONE) rc = launch_pack_conv_wino(params[c.w], pk + c.wino_dgrad, c.cin, c.cout, 1, s);
-  return rc;
+  // data-gradient GEMM: output channels = conv input channels; for the qkv conv the K index follows the packed
+  // (head, which, c) order of the incoming gradient rows
+  if (c.wpk_dgrad != NONE) pp.conv(params[c.w], pk + c.wpk_dgrad, c.cin, c.cout, c.taps, c.qkv_heads, 1);
+  if (c.wino != NONE) pp.wino(params[c.w], pk + c.wino, c.cout, c.cin, 0);
+  if (c.wino_dgrad != NONE) pp.wino(params[c.w], pk + c.wino_dgrad, c.cin, c.cout, 1);
+  return pp.status;
 }
 
 static void pack_norm(const NormP& n, const float* const* params, float* pk, Copier& cp) {
@@ -316,14 +363,16 @@ extern "C" int mcedm_unet_pack_weights(const mcedm_plan* plan, const float* cons
   MCEDM_LAUNCH_CHECK("freqs_kernel");
   Copier cp;
   cp.s = s;
+  Packer pp;
+  pp.s = s;
   cp.add(params[P.map0_w], pk + P.w0, (size_t)ch * ch); cp.add(params[P.map0_b], pk + P.b0, ch);
   cp.add(params[P.map1_w], pk + P.w1, (size_t)ch * ch); cp.add(params[P.map1_b], pk + P.b1, ch);
-  int rc = pack_conv(P.conv_in, params, pk, cp, s);
+  int rc = pack_conv(P.conv_in, params, pk, cp, pp, s);
   if (rc) return rc;
   if (P.desc.dx_mode == MCEDM_DX_ENC) {
-    if ((rc = pack_conv(P.dx_enc0, params, pk, cp, s))) return rc;
-    if ((rc = pack_conv(P.dx_enc2, params, pk, cp, s))) return rc;
-    if ((rc = pack_conv(P.combine, params, pk, cp, s))) return rc;
+    if ((rc = pack_conv(P.dx_enc0, params, pk, cp, pp, s))) return rc;
+    if ((rc = pack_conv(P.dx_enc2, params, pk, cp, pp, s))) return rc;
+    if ((rc = pack_conv(P.combine, params, pk, cp, pp, s))) return rc;
   }
   for (auto* v : {&P.enc, &P.dec})
     for (const BlockP& b : *v) {
@@ -331,19 +380,20 @@ extern "C" int mcedm_unet_pack_weights(const mcedm_plan* plan, const float* cons
       cp.add(params[b.aff_b], pk + P.baff + b.film_row0, (size_t)2 * b.cout);
       pack_norm(b.norm0, params, pk, cp);
       pack_norm(b.norm1, params, pk, cp);
-      if ((rc = pack_conv(b.conv0, params, pk, cp, s))) return rc;
-      if ((rc = pack_conv(b.conv1, params, pk, cp, s))) return rc;
-      if (b.skip_kernel == 1 && (rc = pack_conv(b.skip, params, pk, cp, s))) return rc;
+      if ((rc = pack_conv(b.conv0, params, pk, cp, pp, s))) return rc;
+      if ((rc = pack_conv(b.conv1, params, pk, cp, pp, s))) return rc;
+      if (b.skip_kernel == 1 && (rc = pack_conv(b.skip, params, pk, cp, pp, s))) return rc;
       if (b.attn) {
         pack_norm(b.norm2, params, pk, cp);
-        if ((rc = pack_conv(b.qkv, params, pk, cp, s))) return rc;
-        if ((rc = pack_conv(b.proj, params, pk, cp, s))) return rc;
+        if ((rc = pack_conv(b.qkv, params, pk, cp, pp, s))) return rc;
+        if ((rc = pack_conv(b.proj, params, pk, cp, pp, s))) return rc;
       }
     }
   pack_norm(P.out_norm, params, pk, cp);
-  if ((rc = pack_conv(P.conv_out, params, pk, cp, s))) return rc;
+  if ((rc = pack_conv(P.conv_out, params, pk, cp, pp, s))) return rc;
   cp.flush();
-  return cp.status;
+  pp.flush();
+  return cp.status != MCEDM_OK ? cp.status : pp.status;
 }
 
 // ------------------------------------------------------------------------------------------
