@@ -308,50 +308,31 @@ __global__ __launch_bounds__(Wino1Cfg::NT, 1) void conv_wino1_kernel(const ConvA
     const unsigned rvoff = 4u * ((unsigned)cbase * (HWu >> 2) + (unsigned)(oy >> 1) * (p.W >> 1) + (ox >> 1));
     const unsigned dvoff = 4u * ((unsigned)cbase * (HWu << 2) + (unsigned)(2 * oy) * (unsigned)(2 * p.W) + (unsigned)(2 * ox));
     const bool pairs = p.gsum_rc == 2;
-    // A^T = [[1,1,1,0],[0,1,-1,-1]] over nu, then over xi, in conv_wino.hip's order of operations, on whole accumulator blocks
-    // (a block leaves the AccVGPRs as one 16-register copy; at most four are in flight, the fences keep it that way):
+    // A^T = [[1,1,1,0],[0,1,-1,-1]] over nu, then over xi, in conv_wino.hip's order of operations, one accumulator REGISTER at a
+    // time (16 AccVGPR reads, 16 additions over nu, then the two pixel rows as packed pairs (column 0, column 1) -- which is also
+    // the operand of the 8-byte store and the shape of the residual):
     //   T_xi[0] = (M[xi][0] + M[xi][1]) + M[xi][2], T_xi[1] = (M[xi][1] - M[xi][2]) - M[xi][3];
     //   row 0 = ((T0 + T1) + T2) + residual, row 1 = ((-T2 - T3) + T1) + residual
-    // A^T = [[1,1,1,0],[0,1,-1,-1]] over nu, then over xi, in conv_wino.hip's order of operations, on whole accumulator blocks
-    // (a block leaves the AccVGPRs as one 16-register copy; at most four are in flight, the fences keep it that way):
-    //   T_xi[0] = (M[xi][0] + M[xi][1]) + M[xi][2], T_xi[1] = (M[xi][1] - M[xi][2]) - M[xi][3];
-    //   row 0 = ((T0 + T1) + T2) + residual, row 1 = ((-T2 - T3) + T1) + residual
-    f32x16 row0[2], row1[2];
-    auto out_transform = [&]() {
-      f32x16 t1k[2];
-      {
-        const f32x16 a0 = (acc[0] + acc[1]) + acc[2], b0 = (acc[1] - acc[2]) - acc[3];
-        __builtin_amdgcn_sched_barrier(0);
-        t1k[0] = (acc[4] + acc[5]) + acc[6]; t1k[1] = (acc[5] - acc[6]) - acc[7];
-        row0[0] = a0 + t1k[0]; row0[1] = b0 + t1k[1];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      {
-        const f32x16 a2 = (acc[8] + acc[9]) + acc[10], b2 = (acc[9] - acc[10]) - acc[11];
-        row0[0] = row0[0] + a2; row0[1] = row0[1] + b2;
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x16 a3 = (acc[12] + acc[13]) + acc[14], b3 = (acc[13] - acc[14]) - acc[15];
-        row1[0] = (-a2 - a3) + t1k[0]; row1[1] = (-b2 - b3) + t1k[1];
-        __builtin_amdgcn_sched_barrier(0);                // the accumulators are dead from here to the end of the epilogue
-      }
-    };
-    // registers 4 gq .. 4 gq + 3 (channels cbase + 8 gq + {0 .. 3}) of both pixel rows: residual, stores, statistics
-    auto finish_group = [&](int gq, const float2 (&rv)[2][4]) {
-      float v[2][2][4];                                               // [pixel row][pixel column j][k]
+    // registers 4 gq .. 4 gq + 3 (channels cbase + 8 gq + {0 .. 3}) of both pixel rows: transform, residual, stores, statistics
+    auto finish_group = [&](int gq, const f32x2 (&rv)[2][4]) {
+      f32x2 v[2][4];                                                  // [pixel row][k] = (column 0, column 1)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int r = 4 * gq + k;
+        f32x2 T[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          v[0][j][k] = row0[j][r] + (j ? rv[0][k].y : rv[0][k].x);
-          v[1][j][k] = row1[j][r] + (j ? rv[1][k].y : rv[1][k].x);
+        for (int xi = 0; xi < 4; ++xi) {
+          T[xi].x = (acc[4 * xi][r] + acc[4 * xi + 1][r]) + acc[4 * xi + 2][r];
+          T[xi].y = (acc[4 * xi + 1][r] - acc[4 * xi + 2][r]) - acc[4 * xi + 3][r];
         }
+        v[0][k] = ((T[0] + T[1]) + T[2]) + rv[0][k];
+        v[1][k] = ((-T[2] - T[3]) + T[1]) + rv[1][k];
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int row = 0; row < 2; ++row)
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, make_float2(v[row][0][k], v[row][1][k])),
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v[row][k]),
                                                 rs_out, voff + (unsigned)row * Wb, 4u * (unsigned)(k + 8 * gq) * HWu, 0);
       if (p.gsum) {
         // fused GroupNorm statistics: per pixel row the records conv_wino.hip's two half-waves write (count, sum, M2 about the
@@ -361,7 +342,7 @@ __global__ __launch_bounds__(Wino1Cfg::NT, 1) void conv_wino1_kernel(const ConvA
           float a[2], b[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e)
-            a[e] = half_sum32((v[row][0][2 * e] + v[row][1][2 * e]) + (v[row][0][2 * e + 1] + v[row][1][2 * e + 1]));
+            a[e] = half_sum32((v[row][2 * e].x + v[row][2 * e].y) + (v[row][2 * e + 1].x + v[row][2 * e + 1].y));
           const float cnt = pairs ? 128.f : 256.f;
           const float mean0 = pairs ? a[0] * (1.0f / 128.0f) : (a[0] + a[1]) * (1.0f / 256.0f);
           const float mean1 = pairs ? a[1] * (1.0f / 128.0f) : mean0;
@@ -370,7 +351,7 @@ __global__ __launch_bounds__(Wino1Cfg::NT, 1) void conv_wino1_kernel(const ConvA
             const float mean = e ? mean1 : mean0;
             float q = 0.f;
 #pragma unroll
-            for (int k = 2 * e; k < 2 * e + 2; ++k) { const float d0 = v[row][0][k] - mean, d1 = v[row][1][k] - mean; q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); }
+            for (int k = 2 * e; k < 2 * e + 2; ++k) { const float d0 = v[row][k].x - mean, d1 = v[row][k].y - mean; q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); }
             b[e] = half_sum32(q);
           }
           if ((lane & 31) == 0) {
@@ -390,46 +371,31 @@ __global__ __launch_bounds__(Wino1Cfg::NT, 1) void conv_wino1_kernel(const ConvA
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    if (p.res && p.res_mode == RS_DOWN) {
-      // residual at double resolution, 2 x 2 mean (adm_blocks.py:75-77): four 16-byte loads per channel, fetched per group
-      out_transform();
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        float2 rv[2][4];
+    for (int gq = 0; gq < 4; ++gq) {
+      f32x2 rv[2][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned so = 4u * (unsigned)(k + 8 * gq) * (HWu << 2);
+      for (int k = 0; k < 4; ++k) {
+        const int dr = k + 8 * gq;
+        if (p.res && p.res_mode == RS_DOWN) {      // residual at double resolution, 2 x 2 mean (adm_blocks.py:75-77)
+          const unsigned so = 4u * (unsigned)dr * (HWu << 2);
 #pragma unroll
           for (int row = 0; row < 2; ++row) {
             const f32x4 ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, dvoff + (unsigned)(2 * row) * 8u * (unsigned)p.W, so, 0));
             const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, dvoff + (unsigned)(2 * row + 1) * 8u * (unsigned)p.W, so, 0));
-            rv[row][k] = make_float2(0.25f * ((ta[0] + ta[1]) + (tb[0] + tb[1])), 0.25f * ((ta[2] + ta[3]) + (tb[2] + tb[3])));
+            rv[row][k] = f32x2{0.25f * ((ta[0] + ta[1]) + (tb[0] + tb[1])), 0.25f * ((ta[2] + ta[3]) + (tb[2] + tb[3]))};
           }
+        } else if (p.res && p.res_mode == RS_UP) { // half resolution: the four pixels of the patch share one source pixel
+          const float q = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, rvoff, 4u * (unsigned)dr * (HWu >> 2), 0));
+          rv[0][k] = rv[1][k] = f32x2{q, q};
+        } else {                                   // no residual: a zero-sized descriptor reads zeros
+          rv[0][k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff, 4u * (unsigned)dr * HWu, 0));
+          rv[1][k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff + Wb, 4u * (unsigned)dr * HWu, 0));
         }
-        finish_group(gq, rv);
       }
-    } else {
-      // (All 64 residual registers requested in front of the transform -- the one-wave kernel has the registers -- measured
-      // slower: the allocator then spills loop-invariant address registers and reloads them inside the K loop, each reload
-      // behind an s_waitcnt vmcnt(0) that drains the weight prefetch: K loop 5890 -> 6950 cycles per chunk.)
-      out_transform();
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        float2 rv[2][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int dr = k + 8 * gq;
-          if (p.res && p.res_mode == RS_UP) {      // half resolution: the four pixels of the patch share one source pixel
-            const float q = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, rvoff, 4u * (unsigned)dr * (HWu >> 2), 0));
-            rv[0][k] = rv[1][k] = make_float2(q, q);
-          } else {                                 // no residual: a zero-sized descriptor reads zeros
-            rv[0][k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff, 4u * (unsigned)dr * HWu, 0));
-            rv[1][k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, voff + Wb, 4u * (unsigned)dr * HWu, 0));
-          }
-        }
-        finish_group(gq, rv);
-      }
+      finish_group(gq, rv);
     }
+    __builtin_amdgcn_sched_barrier(0);                    // the accumulators are dead from here
     if (p.gsum) {
       __syncthreads();
       conv_stats_store<C, 2>(p, red, n, m0, tile, tiles_img, tid);
