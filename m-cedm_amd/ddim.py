@@ -12,8 +12,8 @@ It runs on the same HIP path as ``PlMcedm``: the same ``DhariwalUNet`` (``in_cha
 ``out_ch`` 1 in ``configs/model/adm_edm_cond_h_res32.yaml``), the same EDM preconditioning, and the UNMASKED variants of
 the loss and of the Heun sampler (``mask = NULL`` in the C ABI).  Constructor, attributes, state_dict keys (incl. the
 DDPM-schedule buffers ``betas`` / ``logvar`` that ``PlDdim.__init__`` registers, models/ddim.py:22-30) and method
-signatures follow the reference; DDIM sampling, PDE guidance, self-conditioning and the ``node_type`` channel are outside
-the hot path and raise.
+signatures follow the reference (incl. PDE guidance, ``dx_cond``, the ``node_type`` channel and the ``cond_p`` drop); DDIM
+sampling of the single-task model and self-conditioning are outside the hot path and raise.
 """
 from __future__ import annotations
 
@@ -132,9 +132,12 @@ class PlCondEdm(_EvalMetrics, _Base):
         super().__init__()
         self.save_hyperparameters()
         m, o, d, df = hparams.model, hparams.optimization, hparams.data, hparams.diffusion
-        for flag in ("node_type", "self_cond"):
-            if hasattr(m, flag) and getattr(m, flag):
-                raise NotImplementedError(f"hparams.model.{flag}=True is outside the MI355X hot path")
+        if hasattr(m, "self_cond") and m.self_cond:
+            raise NotImplementedError("hparams.model.self_cond=True is outside the MI355X hot path")
+        # models/ddim.py:36-38: a boundary / interior flag per grid point rides along as one more conditioning channel
+        self.node_type = bool(m.node_type) if hasattr(m, "node_type") else False
+        if self.node_type:
+            m.cond_channels = m.cond_channels + 1
         # dx_cond (models/ddim.py:33-35): the network also sees the PDE-residual gradient at its input state.  For the
         # single-task model only dx_norm == 'prob' can run in the reference -- get_dx_pde (:1424-1450) returns a 3-D tensor
         # with calc_prob=False and get_dx_input (:601-639) fails to unpack it (pinned: tests/golden/dxcond.npz
@@ -159,7 +162,6 @@ class PlCondEdm(_EvalMetrics, _Base):
         elif m.var_type == "fixedsmall":
             self.register_buffer("logvar", post_var.clamp(min=1e-20).log())
         self.cond_p = m.cond_p if hasattr(m, "cond_p") else 0.8
-        self.node_type = False
         self.model = DhariwalUNet(hparams)
         self.ema_model = EmaModel(self.model, beta=m.ema_rate) if m.ema else None
         self.normalization, self.rescaled = d.normalization, d.rescaled
@@ -226,18 +228,29 @@ class PlCondEdm(_EvalMetrics, _Base):
         return self.normalizer_target(u, inverse=True)
 
     def get_cond_in(self, h, u, dx, dt):
-        """models/ddim.py:1081-1116 (node_type False)."""
-        cc = self.model.cond_channels
+        """models/ddim.py:1081-1116: h alone, h + the initial condition of u, h + the (t, x) grids, or all of them, by the
+        network's conditioning width; node_type appends a channel that is 1 on the boundary of the (t, x) grid and 0 inside."""
+        cc = self.model.cond_channels - 1 if self.node_type else self.model.cond_channels
+        u_ic = u[:, 0:1].repeat(1, u.shape[1], 1, 1) if u is not None else None
         if cc == self.h_ch:
-            return h
-        u_ic = u[:, 0:1].repeat(1, u.shape[1], 1, 1)
-        if cc == self.h_ch + self.u_ch:
-            return torch.cat([h, u_ic], dim=-1)
-        if cc == self.h_ch + 2:
-            return torch.cat([h, dt, dx], dim=-1)
-        if cc == self.h_ch + self.u_ch + 2:
-            return torch.cat([h, u_ic, dt, dx], dim=-1)
-        raise RuntimeError(f"Number of conditional channels {cc} does not match the known state channels {self.h_ch}")
+            cond_in = h
+        elif cc == self.h_ch + self.u_ch:
+            cond_in = torch.cat([h, u_ic], dim=-1)
+        elif cc == self.h_ch + 2:
+            cond_in = torch.cat([h, dt, dx], dim=-1)
+        elif cc == self.h_ch + self.u_ch + 2:
+            cond_in = torch.cat([h, u_ic, dt, dx], dim=-1)
+        else:
+            raise RuntimeError(f"Number of conditional channels {cc} does not match the known state channels {self.h_ch}")
+        if self.node_type:
+            b, hc, wc, _ = h.shape
+            node = torch.zeros((b, hc, wc, 1), dtype=h.dtype, device=h.device)
+            node[:, 0] = 1
+            node[:, -1] = 1
+            node[:, :, 0] = 1
+            node[:, :, -1] = 1
+            cond_in = torch.cat([cond_in, node], dim=-1)
+        return cond_in
 
     def get_loss_weight(self, sigma):
         return (sigma ** 2 + self.sigma_data ** 2) / (sigma * self.sigma_data) ** 2

@@ -168,6 +168,20 @@ def cond_in_nchw(tag, h, u, mask, cond_noise, dx, dt):
     return x.permute(0, 3, 1, 2).contiguous(), cond.permute(0, 3, 1, 2).contiguous(), mask.permute(0, 3, 1, 2).contiguous()
 
 
+# PlCondEdm with hparams.model.node_type (models/ddim.py:36-38, 1105-1114): the conditioning gains a boundary-flag channel
+CFG_NODE = orc.UNetConfig(in_channels=1, cond_channels=2, out_ch=1)
+
+
+def node_cond(h: torch.Tensor) -> torch.Tensor:
+    """get_cond_in of the node_type model restated: cat(h, node) 'b t x 2', node = 1 on the border of the (t, x) grid."""
+    node = torch.zeros_like(h[..., :1])
+    node[:, 0] = 1
+    node[:, -1] = 1
+    node[:, :, 0] = 1
+    node[:, :, -1] = 1
+    return torch.cat([h, node], dim=-1)
+
+
 # ---- single-task conditional EDM (PlCondEdm, configs/model/adm_edm_cond_h_res32.yaml): h -> u, 1 + 1 -> 1 channels
 CFG_C = orc.UNetConfig(in_channels=1, cond_channels=1, out_ch=1)
 COND_SAMPLER_CASES = {"det": 0.0, "churn": 15.0}

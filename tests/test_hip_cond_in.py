@@ -104,3 +104,41 @@ def test_cond_edm_training_step_drops_the_conditioning(golden, monkeypatch):
         for n in fx.COND_GRAD_NAMES:
             ref = torch.as_tensor(gg[f"{key}grad::{n}"])
             close(grads[n].grad, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_cond_edm_node_type_channel_golden(golden, monkeypatch):
+    """PlCondEdm with hparams.model.node_type (models/ddim.py:36-38, 1105-1114): the constructor widens cond_channels by one,
+    get_cond_in appends the boundary flag; training step and sampler against the reference's outputs."""
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd.ddim import PlCondEdm
+    g = golden("cond_in.npz")
+    hp = cond_hparams()
+    hp.model.node_type = True
+    m = PlCondEdm(hp).cuda()
+    assert hp.model.cond_channels == fx.CFG_NODE.cond_channels
+    P = orc.make_params(fx.CFG_NODE, 31)
+    with torch.no_grad():
+        for n, p in m.model.named_parameters():
+            p.copy_(P[n])
+        for n, p in m.ema_model.ma_model.named_parameters():
+            p.copy_(P[n])
+    h, u, noise, rnd_normal = fx.cond_training_inputs()
+    st = fx.TRAIN_NORM_STATS
+    m.normalizer_input.set_stats(torch.tensor(st[0]), torch.tensor(st[1]))
+    m.normalizer_target.set_stats(torch.tensor(st[2]), torch.tensor(st[3]))
+    m.h_ch = m.u_ch = 1
+    hn4 = ((h - st[0]) / st[1]).cuda()
+    close(m.get_cond_in(hn4, ((u - st[2]) / st[3]).cuda(), None, None), g["node::cond_in"], rtol=0, atol=0)
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: noise.cuda())
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: rnd_normal)
+    loss = m.training_step((h.cuda(), None, None, u.cuda()), 0)
+    monkeypatch.undo()
+    close(loss, torch.as_tensor(g["node::loss"]), rtol=1e-4, atol=1e-4)
+    loss.backward()
+    grads = dict(m.model.named_parameters())
+    for n in fx.COND_GRAD_NAMES:
+        ref = torch.as_tensor(g[f"node::grad::{n}"])
+        close(grads[n].grad, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+    hs, u_noise, _ = fx.cond_sampler_inputs("det")
+    xs = m.sample_edm(fx.node_cond(hs).cuda(), u_noise.cuda(), cond_hparams().sampler, return_last=True)
+    close(xs, g["node::xs_last"], rtol=1e-4, atol=1e-5)

@@ -405,3 +405,27 @@ def test_cond_edm_training_with_the_conditioning_dropped(golden):
     for n in fx.COND_GRAD_NAMES:
         ref = torch.as_tensor(g[f"cond_drop::grad::{n}"])
         close(Pg[n].grad, ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_cond_edm_node_type_channel(golden):
+    """models/ddim.py:36-38, 1105-1114 (round 4): node_type adds a boundary-flag conditioning channel to the single-task model."""
+    g = golden("cond_in.npz")
+    cfg = fx.CFG_NODE
+    P = orc.make_params(cfg, 31)
+    h, u, noise, rnd_normal = fx.cond_training_inputs()
+    st = fx.TRAIN_NORM_STATS
+    hn4 = (h - st[0]) / st[1]
+    cond = fx.node_cond(hn4)
+    close(cond, g["node::cond_in"], rtol=0, atol=0)
+    un = ((u - st[2]) / st[3]).permute(0, 3, 1, 2)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss = orc.training_loss_cond(Pg, cfg, un, cond.permute(0, 3, 1, 2).contiguous(), noise, rnd_normal)
+    loss.backward()
+    close(loss.detach(), g["node::loss"], rtol=1e-5, atol=1e-6)
+    for n in fx.COND_GRAD_NAMES:
+        ref = torch.as_tensor(g[f"node::grad::{n}"])
+        close(Pg[n].grad, ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
+    hs, u_noise, steps = fx.cond_sampler_inputs("det")
+    with torch.no_grad():
+        xs = orc.sample_edm_cond(P, cfg, fx.node_cond(hs).permute(0, 3, 1, 2), orc.SamplerParams(), u_noise.permute(0, 3, 1, 2), steps)
+    close(xs, g["node::xs_last"], rtol=1e-3, atol=1e-4)
