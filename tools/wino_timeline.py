@@ -56,3 +56,5 @@ elif int(os.environ.get("MCEDM_WINO_MODE", "0")) & 32:
         ["nu-transform + requests", "exchange rounds", "stores", "statistics", "accumulator init"])))
 elif d[:, 8:13].max() > 0:
     print("   wave 0 cycles per chunk: " + "  ".join(f"{nm} {np.mean(d[:, 8 + j]) / nch / per:.0f}" for j, nm in enumerate(["top", "mfma stream", "barrier", "epilogue"])))
+    if d[:, 13:16].max() > 0:      # the SIMD partner of wave 0 (wave MB: the same channel block, the other row half)
+        print("   its SIMD partner:        " + "  ".join(f"{nm} {np.mean(d[:, c]) / nch / per:.0f}" for nm, c in (("top", 7), ("mfma stream", 13), ("barrier", 14), ("epilogue", 15))))
