@@ -161,3 +161,21 @@ def test_ddim_timestep_sequence_equals_numpy_linspace():
     assert L.ddim_timesteps(1000, 100, "quad")[-1] == 800 and L.ddim_timesteps(1000, 16, "quad")[1:4] == [3, 14, 31]
     with pytest.raises(RuntimeError, match="bad schedule"):
         L.ddim_timesteps(10, 11, "quad")
+
+
+def test_bench_roofline_helpers():
+    """bench.py's host-side arithmetic (no GPU): both roofline fractions of SURVEY.md 8(d) per forward and per state, and the
+    HBM-bound kernel rows."""
+    import bench
+    f = bench.fractions("s128", 76.0, 12.0, 32)
+    gf, mb = bench.ALGORITHMIC["s128"]
+    assert abs(f["forward_hbm_frac"] - mb * 1e6 * 32 / 12.0e-3 / 8e12) < 1e-12
+    assert abs(f["forward_fp32_frac_algorithmic"] - gf * 1e9 * 32 / 12.0e-3 / 157.3e12) < 1e-12
+    assert abs(f["per_state"]["gflop"] - 35 * gf) < 1e-9 and abs(f["per_state"]["hbm_frac"] - 76.0 * 35 * mb * 1e6 / 8e12) < 1e-12
+    assert bench.fractions("repaint128", 1.0, 1.0, 1) == {}
+    prof = [{"name": "gn_bwd_kernel", "launches": 45, "total_ms": 5.5, "flops": 2e10, "bytes": 1.2e10},
+            {"name": "conv_wino_kernel<WinoCfg<4>, false>", "launches": 53, "total_ms": 18.0, "flops": 4e12, "bytes": 1e10}]
+    rows = bench.hbm_bound_rows(prof)
+    assert [r["name"] for r in rows] == ["gn_bwd_kernel"] and abs(rows[0]["hbm_frac"] - round(1.2e10 / 5.5e-3 / 1e9, 1) / 8000.0) < 1e-3
+    ro = bench.roofline_of(prof)
+    assert ro["kernel"].startswith("conv_wino") and abs(ro["executed_over_algorithmic"] - 4 / 9) < 1e-12 and ro["frac"] < ro["direct_equivalent_frac"]
