@@ -332,8 +332,13 @@ int mcedm_op_set_conv_resident(int enable);
 int mcedm_op_set_conv_wino(int enable);
 /* Which of the two Winograd kernels serves the 128-channel shapes: 1 = the one-wave-per-SIMD kernel (conv_wino1.hip: all 16
  * positions of a 32-channel block in one wave's AccVGPRs), 0 = the two-waves-per-SIMD kernel (conv_wino.hip), -1 = the default
- * (env MCEDM_WINO1, else 1).  The two are bit-identical (statistics included).  Read at every launch.  Process-global. */
+ * (env MCEDM_WINO1, else 0: the one-wave kernel measured 6-9 % slower and stays off).  The two are bit-identical (statistics
+ * included).  Read at every launch.  Process-global. */
 int mcedm_op_set_conv_wino1(int enable);
+/* The Winograd F(3x3, 2x2) weight-gradient kernel (wgrad_wino.hip) for the un-resampled 3x3 convs whose channel counts are
+ * multiples of 128 on images with W % 32 == 0: 1 on, 0 off (the direct split-K kernel everywhere), -1 back to the default (env
+ * MCEDM_WGRAD_WINO, else on).  Read at every launch; the scratch size does not depend on it.  Process-global. */
+int mcedm_op_set_wgrad_wino(int enable);
 /* The single-launch attention part of a UNetBlock at 8 x 8 x 64 channels (attn_fused.hip; inference only): 1 on, 0 off
  * (qkv conv + attention kernel + proj conv), -1 back to the default (env MCEDM_ATTN_FUSED, else on).  Process-global. */
 int mcedm_op_set_attn_fused(int enable);

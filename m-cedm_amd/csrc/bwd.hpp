@@ -16,10 +16,17 @@ struct WgradArgs {
 };
 size_t wgrad_scratch_floats(int Cout, int Cin, int taps);
 // dw [Cout][Cin][kh][kw], db [Cout] (may be null).  qkv_heads > 0: dy rows are in packed qkv order.
-// act_tmp: scratch of B * (Ca+Cb) * H * W floats for the materialised conv input; have_act: act_tmp already holds it (written
+// act_tmp: scratch of B * (Ca+Cb) * H * W floats for the materialised conv input, NOT the first bytes of an allocation (see
+// wgrad_wino.hip); have_act: act_tmp already holds it (written
 // by the GroupNorm backward of the same input, GnBwdArgs::xact: one pass over x less)
 int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s,
                  bool have_act = false);
+// wgrad_wino.hip: the un-resampled 3x3 weight gradient in Winograd F(3x3, 2x2) form (Cout, Cin multiples of 128, W % 32 == 0).
+// x: the materialised conv input [B][Cin][H][W]; the 16 bytes in FRONT of it must be readable (launch_wgrad passes act_tmp).
+bool wgrad_wino_applicable(const WgradArgs& a, int taps, int qkv_heads);
+size_t wgrad_wino_scratch_floats(int Cout, int Cin, int taps);     // 0 when the channel counts are not served
+int launch_wgrad_wino(const WgradArgs& a, const float* x, float* dw, float* db, hipStream_t s);
+void set_wgrad_wino(int enable);                                   // 1 / 0, -1: default (env MCEDM_WGRAD_WINO, else on)
 // the materialisation step alone: out[B, Ca+Cb, H, W] = resample(act(coef(cat(xa, xb)))); dy / Cout / dwp are not read
 int launch_act_materialize(const WgradArgs& a, float* out, hipStream_t s);
 

@@ -622,7 +622,7 @@ int launch_conv_wino(const ConvArgs& a_in, hipStream_t stream) {
                 "conv_wino: one sample of the output / residual exceeds the 4 GiB buffer range");
   { const int rc = conv_resolve_identity(a); if (rc != MCEDM_OK) return rc; }
   // 128 output channels per workgroup where they divide (fewer passes over the input), else 64; the 128-channel shape runs on
-  // the one-wave-per-SIMD kernel (conv_wino1.hip) unless that is switched off
+  // the one-wave-per-SIMD kernel (conv_wino1.hip) only when that is switched on (MCEDM_WINO1=1; off by default)
   if (a.Cout % 128 == 0) {
     const int rc = try_launch_conv_wino1(a, stream);
     if (rc != -1) return rc;

@@ -42,7 +42,7 @@ static_assert(RPLANE % 32 == 4 && VH1 % 32 == 16 && VH1 >= 128 && VPOS >= VH1 + 
 
 // conv_wino1.hip: the 128-channel shape with ONE wave per SIMD (see there); -1: not served (shape / switch), else the launch status
 int try_launch_conv_wino1(const ConvArgs& a, hipStream_t stream);
-void set_conv_wino1(int enable);                 // 1 / 0, -1: default (env MCEDM_WINO1, else on)
+void set_conv_wino1(int enable);                 // 1 / 0, -1: default (env MCEDM_WINO1, else off: measured 6-9 % slower)
 // tiles per persistent workgroup (a divisor of the tiles per image; conv_wino.hip)
 int wino_tiles_per_wg(long long total, int tiles_img, int slots);
 

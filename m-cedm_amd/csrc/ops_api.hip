@@ -153,6 +153,11 @@ extern "C" int mcedm_op_set_conv_wino1(int enable) {
   return MCEDM_OK;
 }
 
+extern "C" int mcedm_op_set_wgrad_wino(int enable) {
+  set_wgrad_wino(enable);
+  return MCEDM_OK;
+}
+
 extern "C" int mcedm_op_set_conv_resident(int enable) {
   set_conv_resident(enable);
   return MCEDM_OK;

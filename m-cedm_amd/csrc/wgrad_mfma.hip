@@ -349,7 +349,9 @@ static int wgrad_nsplit_max(int Cout, int Cin) {
 }
 size_t wgrad_scratch_floats(int Cout, int Cin, int taps) {
   const size_t cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
-  return (size_t)wgrad_nsplit_max(Cout, Cin) * (taps * cop * cip + cop);
+  const size_t direct = (size_t)wgrad_nsplit_max(Cout, Cin) * (taps * cop * cip + cop);
+  const size_t wino = wgrad_wino_scratch_floats(Cout, Cin, taps);          // wgrad_wino.hip: the Winograd-domain partial blocks
+  return direct > wino ? direct : wino;
 }
 
 template <class C>
@@ -401,10 +403,14 @@ int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_hea
   WgradArgs b = a;
   b.dbp = a.dwp + (size_t)wgrad_nsplit_max(a.Cout, Cin) * taps * cop * cip;      // [split][CoP] bias partials behind the slices
   int rc, nact = 1;
-  // an un-transformed single-source input (the attention projection's) IS the operand: no copy
-  const bool plain = !have_act && !a.coef && !a.act && a.resample == RS_NONE && a.Cb == 0 && a.xa;
+  // an un-transformed single-source input (the attention projection's) IS the operand: no copy -- except for the Winograd
+  // kernel, which reads the 4 bytes in front of its operand (and discards them): it only ever sees act_tmp, a scratch region
+  // that is never the start of an allocation
+  const bool wino = wgrad_wino_applicable(a, taps, qkv_heads);
+  const bool plain = !wino && !have_act && !a.coef && !a.act && a.resample == RS_NONE && a.Cb == 0 && a.xa;
   const float* xact = plain ? a.xa : act_tmp;
   if (!have_act && !plain && (rc = launch_act_materialize(a, act_tmp, s))) return rc;
+  if (wino) return launch_wgrad_wino(a, xact, dw, db, s);
   if (taps == 9) {
     if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 9>>(b, xact, &nact, s);
     else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 9>>(b, xact, &nact, s);

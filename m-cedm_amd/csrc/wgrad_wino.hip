@@ -1,0 +1,406 @@
+// wgrad_wino.hip -- K10a': weight (and bias) gradient of the un-resampled 3x3 convolution in Winograd F(3x3, 2x2) form.
+//
+//   dW[co][ci][a][b] = sum_{n, y, x} dY[n][co][y][x] * X'[n][ci][y + a - 1][x + b - 1]            (adm_blocks.py:78-79, backward)
+//
+// is, per 2x2 tile of dY and the 4x4 tile of X' around it, a correlation with 3x3 outputs and a 2x2 "filter": 16 multiplies per
+// (co, ci) and tile instead of 36 (Lavin & Gray 2016, the F(3x3, 2x2) of their section 4.3 "training"):
+//
+//   dW = A^T [ sum_tiles (G dY_t G^T) o (B^T X'_t B) ] A        B^T as in the forward kernel (conv_wino.hip), G 4x2, A^T 3x4
+//
+// The sum over tiles is the K dimension of 16 independent GEMMs M_p[co][ci] (p = Winograd position (xi, nu)), K = B*H*W/4.
+// tools/wino_wgrad_error.py: fp32 error against fp64 <= 2x the direct form's, < 1 % of the bar gradients are held to.
+//
+// Mapping to one CU (one 512-thread workgroup, 8 waves, 2 per SIMD):
+//   * a workgroup owns ONE xi (a row of the 4x4 position grid), 128 output x 128 input channels and all four nu:
+//     4 x 4 x 4 = 64 accumulator blocks of 32 x 32 = half the CU's register file.  Wave w: nu = w >> 1, output-channel half
+//     w & 1 (two 32-blocks) x four input-channel blocks = 8 blocks = 128 accumulator registers.  Fixing xi per workgroup
+//     makes the transform work per MFMA a quarter of the forward kernel's: a workgroup needs only TWO rows of each 4x4 /
+//     2x2 tile (B^T and G have two non-zeros per row), and both operands feed 128 channels of the other.
+//   * K loop in stages of 16 tiles = 32 output pixels of one image row pair.  Per stage and wave 64 MFMAs (32x32x2: two tiles
+//     per instruction).  Both operands are transformed in registers straight from global memory -- X': one (channel, tile)
+//     per thread and task, two 16-byte loads at the tile's (unaligned) first column, 6 vector instructions, 4 LDS dwords;
+//     dY: one (channel, aligned quad = two tiles) per task -- and written to LDS in MFMA fragment order
+//     [nu][channel][16 tiles], 16-byte slots XOR-swizzled by (channel >> 2) & 3 so that the ds_read_b128 fragment reads and the
+//     transform's writes are bank-conflict free without padding: 64 KB per stage, double-buffered, ONE barrier per stage.
+//     The registers of stage g + 1 are committed and re-requested for stage g + 2 in slices between the MFMAs of stage g.
+//   * every split of the K range stores its partial blocks to [split][16][CoP][CiP]; wgrad_wino_reduce_kernel adds the
+//     splits in fp64 in a fixed order, applies the halves dropped from G and A^T . A, and writes the reference layout:
+//     no atomics, bitwise reproducible.  The four xi-siblings of a split read the same rows: their workgroup ids are
+//     chosen so that they share an XCD (one L2).
+//   * the bias gradient (sum of dY) falls out of the xi = 1 workgroup's row sums dY[2ty] + dY[2ty+1].
+#include <atomic>
+#include <cstdlib>
+
+#include "bwd.hpp"
+#include "conv_tile.hpp"
+#include "prof.hpp"
+
+namespace mcedm {
+
+constexpr int GW_T = 16;                       // tiles per stage
+constexpr int GW_CB = 128;                     // channels per block (output and input)
+constexpr int GW_PLANE = GW_CB * GW_T;         // floats per (nu, operand)
+constexpr int GW_OP = 4 * GW_PLANE;            // floats per operand and stage
+constexpr int GW_STAGE = 2 * GW_OP;            // X' then dY: 16384 floats = 64 KB
+
+struct WgWinoArgs {
+  const float* dy; const float* x;             // [B][Co][H][W], [B][Ci][H][W] (X' materialised)
+  float* part;                                 // [split][16][cop][cip]
+  float* dbp;                                  // [split][cop] or null
+  int Co, Ci, B, H, W;
+  int cob, cib, cop, cip;                      // 128-channel blocks; padded channel counts of the scratch
+  int nact, per, total;                        // splits that own stages, stages per split, stages in all
+  int nseg, th;                                // 32-pixel segments per row, tile rows
+  unsigned long long* dbg;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int XI>
+__device__ __forceinline__ void wgw_body(const WgWinoArgs& p, float* lds, int split, int cb_o, int cb_i) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nu = wave >> 1, coh = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int s_begin = split * p.per;
+  const int s_end = s_begin + p.per < p.total ? s_begin + p.per : p.total;
+  if (s_begin >= s_end) return;
+  const int G = s_end - s_begin;
+  const unsigned HW = (unsigned)p.H * p.W;
+  const int co0 = cb_o * GW_CB, ci0 = cb_i * GW_CB;
+  // the X' descriptor starts 16 bytes in FRONT of the tensor (the launcher guarantees they are readable: x lies inside a scratch
+  // allocation): the first tile of a row starts at column -1, which for the tensor's very first row is 4 bytes in front of it.
+  // Every out-of-image column is zeroed by the lane masks below; past the END of the tensor the range check returns zeros.
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x - 4, 4u * (unsigned)p.B * p.Ci * HW + 16u);
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.dy, 4u * (unsigned)p.B * p.Co * HW);
+  constexpr bool YA = XI != 3, YB = XI != 0;                  // which of the tile's two dY rows this xi reads
+  constexpr int NYR = (YA && YB) ? 2 : 1;
+
+  // ---- lane constants of the transform tasks
+  // X' task j (4 per thread): tile xt = tid & 15 of channel (tid >> 4) + 32 j; first column 2 xt - 1 (+ 4 floats: the descriptor's lead)
+  const int xt = tid & 15;
+  const unsigned xlb = 4u * ((unsigned)(tid >> 4) * HW + (unsigned)(2 * xt + 3));
+  const int xdst = (tid >> 4) * GW_T + 4 * ((xt >> 2) ^ (wave & 3)) + (xt & 3);      // (channel >> 2) & 3 == wave & 3 for every j
+  // dY task j (2 per thread): aligned quad yq = tid & 7 (tiles 2 yq, 2 yq + 1) of channel (tid >> 3) + 64 j
+  const int yq = tid & 7;
+  const unsigned ylb = 4u * ((unsigned)(tid >> 3) * HW + 4u * yq);
+  const int ydst = GW_OP + (tid >> 3) * GW_T + 4 * ((yq >> 1) ^ ((tid >> 5) & 3)) + 2 * (yq & 1);
+  // MFMA fragments: lane (l31, h), k-group grp: slot 2 grp + h of its channel
+  int fo[2];
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) fo[grp] = l31 * GW_T + 4 * ((2 * grp + h) ^ ((l31 >> 2) & 3));
+
+  // ---- geometry of the stage that is loaded next (wave-uniform), masks of the stage waiting in registers
+  int lst = s_begin;
+  int lseg = lst % p.nseg, lty = (lst / p.nseg) % p.th, ln = lst / (p.nseg * p.th);
+  unsigned g_xa, g_xb, g_y; float g_mrow, g_sl, g_sr;
+  auto set_geo = [&]() {
+    int ya, yb; float mrow = 1.f;
+    if (XI == 0) { ya = 2 * lty - 1; yb = 2 * lty + 1; if (ya < 0) { ya = 0; mrow = 0.f; } }
+    else if (XI == 3) { ya = 2 * lty; yb = 2 * lty + 2; if (yb > p.H - 1) { yb = p.H - 1; mrow = 0.f; } }
+    else { ya = 2 * lty; yb = 2 * lty + 1; }
+    const unsigned xplane = (unsigned)(ln * p.Ci + ci0) * HW + (unsigned)lseg * 32u;
+    g_xa = 4u * (xplane + (unsigned)ya * p.W);
+    g_xb = 4u * (xplane + (unsigned)yb * p.W);
+    g_y = 4u * ((unsigned)(ln * p.Co + co0) * HW + (unsigned)(2 * lty + (YA ? 0 : 1)) * p.W + (unsigned)lseg * 32u);
+    g_mrow = mrow; g_sl = lseg == 0 ? 0.f : 1.f; g_sr = lseg == p.nseg - 1 ? 0.f : 1.f;
+  };
+  auto advance = [&]() {                                      // past the end of this split's range: stay on its last stage
+    if (lst + 1 < s_end) {
+      ++lst;
+      if (++lseg == p.nseg) { lseg = 0; if (++lty == p.th) { lty = 0; ++ln; } }
+    }
+    set_geo();
+  };
+  set_geo();
+  float c_mrow = 1.f;
+  unsigned ml = ~0u, mr = ~0u;                                  // bit masks: what lies outside the image may be anything, NaN included
+  auto take_masks = [&]() { c_mrow = g_mrow; ml = (xt == 0 && g_sl == 0.f) ? 0u : ~0u; mr = (xt == GW_T - 1 && g_sr == 0.f) ? 0u : ~0u; };
+
+  f32x4 xr[4][2], yr[2][NYR];
+  auto load_x = [&](int j) {
+    const unsigned cj = 4u * 32u * (unsigned)j * HW;
+    xr[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xlb + (g_xa + cj), 0, 0));
+    xr[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xlb + (g_xb + cj), 0, 0));
+  };
+  auto load_y = [&](int j) {
+    const unsigned vo = ylb + (g_y + 4u * 64u * (unsigned)j * HW);
+    yr[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, vo, 0, 0));
+    if (NYR == 2) yr[j][NYR - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, vo, 4u * (unsigned)p.W, 0));
+  };
+  // B^T row xi down the tile's rows, then B^T along its columns: 4 Winograd-domain values of (channel, tile) -> LDS
+  auto commit_x = [&](int j, float* sb) {
+    const f32x4 a = xr[j][0], b = xr[j][1];
+    f32x4 r;
+    if (XI == 0) r = a * c_mrow - b;
+    else if (XI == 1) r = a + b;
+    else if (XI == 2) r = b - a;
+    else r = a - b * c_mrow;
+    // (through scalar copies: __builtin_bit_cast applied to the vector-element lvalue r[3] reads element 0 with this hipcc)
+    const float e0 = r[0], e3 = r[3];
+    const float r0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & ml);
+    const float r3 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e3) & mr);
+    float* d = sb + xdst + j * 32 * GW_T;
+    d[0 * GW_PLANE] = r0 - r[2];
+    d[1 * GW_PLANE] = r[1] + r[2];
+    d[2 * GW_PLANE] = r[2] - r[1];
+    d[3 * GW_PLANE] = r[1] - r3;
+  };
+  // G' = [[1,0],[1,1],[1,-1],[0,1]] (the halves of G are applied by the reduction): row xi, then along the columns of both tiles
+  float bsum[2] = {0.f, 0.f};
+  auto commit_y = [&](int j, float* sb, bool bias) {
+    f32x4 s;
+    if (XI == 0 || XI == 3) s = yr[j][0];
+    else if (XI == 1) s = yr[j][0] + yr[j][NYR - 1];
+    else s = yr[j][0] - yr[j][NYR - 1];
+    float* d = sb + ydst + j * 64 * GW_T;
+    *reinterpret_cast<f32x2*>(d + 0 * GW_PLANE) = f32x2{s[0], s[2]};
+    *reinterpret_cast<f32x2*>(d + 1 * GW_PLANE) = f32x2{s[0] + s[1], s[2] + s[3]};
+    *reinterpret_cast<f32x2*>(d + 2 * GW_PLANE) = f32x2{s[0] - s[1], s[2] - s[3]};
+    *reinterpret_cast<f32x2*>(d + 3 * GW_PLANE) = f32x2{s[1], s[3]};
+    if (XI == 1 && bias) bsum[j] += (s[0] + s[1]) + (s[2] + s[3]);
+  };
+  const bool do_bias = XI == 1 && cb_i == 0 && p.dbp != nullptr;
+
+  // ---- prologue: stage 0 -> buffer 0, stage 1 -> registers
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_x(j);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) load_y(j);
+  take_masks();
+  advance();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) commit_x(j, lds);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) commit_y(j, lds, do_bias);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_x(j);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) load_y(j);
+  take_masks();
+  advance();
+
+  f32x16 acc[2][4];
+  {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("" : "+v"(z));
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, z, zero16, 0, 0, 0);
+      }
+  }
+  __syncthreads();
+
+  // ---- the K loop: one trip = one stage.  8 slots of [B fragment of the next slot | 8 MFMAs | one slice of side work]:
+  // slots 0-3 commit X' task j of stage g + 1 and request it again for stage g + 2, slots 4-5 the same for the dY tasks, slot 6
+  // moves the geometry on.  A slice touches only the OTHER stage buffer: one barrier per trip.
+  for (int g = 0; g < G; ++g) {
+    const int cur = g & 1;
+    const float* fbuf = lds + cur * GW_STAGE;
+    float* nbuf = lds + (cur ^ 1) * GW_STAGE;
+    const bool cvalid = g + 1 < G;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      const float* xf = fbuf + nu * GW_PLANE + fo[grp];
+      const float* yf = fbuf + GW_OP + nu * GW_PLANE + coh * 64 * GW_T + fo[grp];
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(yf);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(yf + 32 * GW_T);
+      f32x4 bc = *reinterpret_cast<const f32x4*>(xf);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 bn = bc;
+        if (j < 3) bn = *reinterpret_cast<const f32x4*>(xf + (j + 1) * 32 * GW_T);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bc[s], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bc[s], acc[1][j], 0, 0, 0);
+        }
+        const int slot = grp * 4 + j;
+        if (slot < 4) { commit_x(slot, nbuf); load_x(slot); }
+        else if (slot < 6) { commit_y(slot - 4, nbuf, do_bias && cvalid); load_y(slot - 4); }
+        if (j < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x286, 3, 0);            // VALU | SALU | DS write
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (slot == 6) { take_masks(); advance(); }
+        __builtin_amdgcn_sched_barrier(0);
+        bc = bn;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- this split's partial blocks -> [split][xi * 4 + nu][co][ci] (plain stores; 128-byte segments per half-wave)
+  float* out = p.part + ((size_t)split * 16 + XI * 4 + nu) * p.cop * p.cip;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (2 * coh + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ci = ci0 + 32 * j + l31;
+        out[(size_t)co * p.cip + ci] = acc[i][j][r];
+      }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float v = bsum[j];
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+      if (yq == 0) p.dbp[(size_t)split * p.cop + co0 + (tid >> 3) + 64 * j] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgWinoArgs p) {
+  extern __shared__ float lds[];
+  // workgroup id -> (split, sibling): the 4 * cib * cob siblings of a split sit 8 ids apart = on the same XCD (ids go round-robin
+  // over the 8 XCDs), so that three of their four reads of the same dY / X' rows hit that XCD's L2
+  const int nsib = 4 * p.cib * p.cob;
+  const int bid = blockIdx.x;
+  const int grp8 = bid / (8 * nsib), rem = bid - grp8 * 8 * nsib;
+  const int sib = rem >> 3, split = grp8 * 8 + (rem & 7);
+  if (split >= p.nact) return;
+  const int xi = sib & 3, blk = sib >> 2;
+  const int cb_i = blk % p.cib, cb_o = blk / p.cib;
+  switch (xi) {
+    case 0: wgw_body<0>(p, lds, split, cb_o, cb_i); break;
+    case 1: wgw_body<1>(p, lds, split, cb_o, cb_i); break;
+    case 2: wgw_body<2>(p, lds, split, cb_o, cb_i); break;
+    default: wgw_body<3>(p, lds, split, cb_o, cb_i); break;
+  }
+}
+
+// dW[co][ci][a][b] = sum_{xi, nu} A^T[a][xi] A^T[b][nu] c[xi] c[nu] sum_split part[split][xi][nu][co][ci]
+//   A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]   (the last column carries the sign of B^T's last row (0,1,0,-1))
+//   c = (1, 1/2, 1/2, 1): the halves of G = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]] that the kernel's transform leaves out.
+// One workgroup per (co, 64 input channels): thread (p, ci) sums position p over the splits in split order in fp64 (four
+// interleaved chains: a fixed order), the 16 sums meet in LDS, threads (tap, ci) apply A^T . A.  db[co] = sum_split dbp.
+__global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbp,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int Cout, int Cin,
+                                                                 int cop, int cip, int nact) {
+  __shared__ double m[16][64];
+  const int tid = threadIdx.x, cl = tid & 63, pos = tid >> 6;
+  const int citiles = cip / 64;
+  const int co = blockIdx.x / citiles, ci = (blockIdx.x % citiles) * 64 + cl;
+  const size_t block = (size_t)16 * cop * cip;
+  const float* src = part + ((size_t)pos * cop + co) * cip + ci;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int sp = 0;
+  for (; sp + 4 <= nact; sp += 4) {
+    const float v0 = src[(size_t)sp * block], v1 = src[(size_t)(sp + 1) * block];
+    const float v2 = src[(size_t)(sp + 2) * block], v3 = src[(size_t)(sp + 3) * block];
+    s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+  }
+  for (; sp < nact; ++sp) s0 += (double)src[(size_t)sp * block];
+  const int xi = pos >> 2, nu = pos & 3;
+  const double cs = ((xi == 1 || xi == 2) ? 0.5 : 1.0) * ((nu == 1 || nu == 2) ? 0.5 : 1.0);
+  m[pos][cl] = ((s0 + s1) + (s2 + s3)) * cs;
+  __syncthreads();
+  if (tid < 9 * 64 && ci < Cin) {
+    const int tap = tid >> 6, a = tap / 3, b = tap % 3;
+    // rows of A^T as (xi, sign) lists: a = 0: +0 +1 +2; a = 1: +1 -2; a = 2: +1 +2 -3
+    double r = 0.0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const double wa = a == 0 ? (x < 3 ? 1.0 : 0.0) : a == 1 ? (x == 1 ? 1.0 : x == 2 ? -1.0 : 0.0) : (x == 0 ? 0.0 : x == 3 ? -1.0 : 1.0);
+      if (wa == 0.0) continue;
+      double t = 0.0;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const double wb = b == 0 ? (n < 3 ? 1.0 : 0.0) : b == 1 ? (n == 1 ? 1.0 : n == 2 ? -1.0 : 0.0) : (n == 0 ? 0.0 : n == 3 ? -1.0 : 1.0);
+        if (wb != 0.0) t += wb * m[x * 4 + n][cl];
+      }
+      r += wa * t;
+    }
+    dw[((size_t)co * Cin + ci) * 9 + tap] = (float)r;
+  }
+  if (db && blockIdx.x % citiles == 0 && tid == 0) {
+    double s = 0.0;
+    for (int k = 0; k < nact; ++k) s += (double)dbp[(size_t)k * cop + co];
+    db[co] = (float)s;
+  }
+}
+
+static int g_wgw = -1;       // -1: default (env MCEDM_WGRAD_WINO, else on); 0 / 1: forced by mcedm_op_set_wgrad_wino
+void set_wgrad_wino(int enable) { g_wgw = enable; }
+static int wgw_env() {
+  if (g_wgw >= 0) return g_wgw;
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_WGRAD_WINO"); env = e ? atoi(e) : 1; }
+  return env;
+}
+
+// splits of the K range: one round of one workgroup per CU over the 4 * cib * cob siblings, a multiple of 8 (XCD mapping).
+// A function of the channel counts only, so that the scratch can be sized at plan time.
+static int wgw_nsplit(int Cout, int Cin) {
+  const int nsib = 4 * (Cout / GW_CB) * (Cin / GW_CB);
+  int ns = 256 / nsib;
+  ns = ns / 8 * 8;
+  return ns < 8 ? 8 : ns;
+}
+bool wgrad_wino_shape_ok(int Cout, int Cin, int taps) { return taps == 9 && Cout % GW_CB == 0 && Cin % GW_CB == 0 && Cout > 0 && Cin > 0; }
+size_t wgrad_wino_scratch_floats(int Cout, int Cin, int taps) {
+  if (!wgrad_wino_shape_ok(Cout, Cin, taps)) return 0;
+  return (size_t)wgw_nsplit(Cout, Cin) * ((size_t)16 * Cout * Cin + Cout);
+}
+
+bool wgrad_wino_applicable(const WgradArgs& a, int taps, int qkv_heads) {
+  const int Cin = a.Ca + a.Cb;
+  if (!wgw_env() || qkv_heads != 0 || !wgrad_wino_shape_ok(a.Cout, Cin, taps)) return false;
+  if (a.W % 32 != 0 || a.H % 2 != 0 || a.H < 2 || a.B < 1) return false;
+  if ((reinterpret_cast<size_t>(a.dy) & 15) != 0) return false;
+  const unsigned long long HW = (unsigned long long)a.H * a.W;
+  return 4ull * a.B * Cin * HW + 16 < (1ull << 32) && 4ull * a.B * a.Cout * HW < (1ull << 32);      // 32-bit buffer offsets
+}
+
+int launch_wgrad_wino(const WgradArgs& a, const float* x, float* dw, float* db, hipStream_t s) {
+  MCEDM_REQUIRE(wgrad_wino_applicable(a, 9, 0), "wgrad_wino: shape not served by the Winograd weight-gradient kernel");
+  MCEDM_REQUIRE(a.dy && x && a.dwp && dw, "wgrad_wino: null pointer");
+  const int Cin = a.Ca + a.Cb;
+  const unsigned long long HW = (unsigned long long)a.H * a.W;
+  WgWinoArgs p{};
+  p.dy = a.dy; p.x = x; p.Co = a.Cout; p.Ci = Cin; p.B = a.B; p.H = a.H; p.W = a.W;
+  p.cob = a.Cout / GW_CB; p.cib = Cin / GW_CB; p.cop = a.Cout; p.cip = Cin;
+  p.nseg = a.W / 32; p.th = a.H / 2;
+  p.total = a.B * p.th * p.nseg;
+  int nsplit = wgw_nsplit(a.Cout, Cin);
+  if (nsplit > p.total) nsplit = p.total;
+  p.per = ceil_div(p.total, nsplit);
+  p.nact = ceil_div(p.total, p.per);
+  p.part = a.dwp;
+  p.dbp = db ? a.dwp + (size_t)wgw_nsplit(a.Cout, Cin) * 16 * a.Cout * Cin : nullptr;
+  const int nsib = 4 * p.cib * p.cob;
+  const int grid = ceil_div(p.nact, 8) * 8 * nsib;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  MCEDM_HIP_TRY(hipGetDevice(&dev));
+  MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  if (!attr_set[dev].load(std::memory_order_acquire)) {
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[dev].store(true, std::memory_order_release);
+  }
+  {
+    const double flops = 2.0 * a.B * (double)HW * a.Cout * Cin * 9;       // algorithmic (the direct form's); 4 / 9 are issued
+    ProfScope ps("wgrad_wino_kernel", flops, 4.0 * a.B * (double)HW * (a.Cout + Cin), s);
+    hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), 2 * GW_STAGE * sizeof(float), s, p);
+    MCEDM_LAUNCH_CHECK("wgrad_wino_kernel");
+  }
+  {
+    const double elems = 16.0 * a.Cout * Cin;
+    ProfScope ps("wgrad_wino_reduce_kernel", p.nact * elems, 4.0 * (p.nact * elems + 9.0 * a.Cout * Cin), s);
+    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.Cout * (Cin / 64)), dim3(1024), 0, s, p.part, p.dbp, dw, db, a.Cout, Cin, p.cop,
+                       p.cip, p.nact);
+    MCEDM_LAUNCH_CHECK("wgrad_wino_reduce_kernel");
+  }
+  return MCEDM_OK;
+}
+
+}  // namespace mcedm

@@ -853,7 +853,8 @@ OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_
               "mcedm_op_attention", "mcedm_op_set_conv_tile", "mcedm_prof_enable", "mcedm_prof_report",
               "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd",
               "mcedm_op_set_conv_debug", "mcedm_op_set_conv8", "mcedm_op_set_conv_resident", "mcedm_op_set_attn_fused", "mcedm_op_embedding",
-              "mcedm_op_conv_wino_packed_floats", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino", "mcedm_op_set_conv_wino", "mcedm_op_set_conv_wino1"]
+              "mcedm_op_conv_wino_packed_floats", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino", "mcedm_op_set_conv_wino", "mcedm_op_set_conv_wino1",
+              "mcedm_op_set_wgrad_wino"]
 
 
 def prof_enable(on: bool) -> None:
@@ -893,10 +894,17 @@ def set_conv_wino(enable: int = -1) -> None:
 
 def set_conv_wino1(enable: int = -1) -> None:
     """Which Winograd kernel serves the 128-channel shapes: 1 = one wave per SIMD (conv_wino1.hip), 0 = two (conv_wino.hip);
-    -1 = default (1).  Bit-identical results either way."""
+    -1 = default (0: the one-wave kernel is 6-9 % slower).  Bit-identical results either way."""
     lib = _bind_ops()
     lib.mcedm_op_set_conv_wino1.argtypes = [C.c_int]
     check(lib.mcedm_op_set_conv_wino1(int(enable)), "set_conv_wino1")
+
+
+def set_wgrad_wino(enable: int = -1) -> None:
+    """Winograd F(3x3, 2x2) weight-gradient kernel (wgrad_wino.hip): 1 / 0 (direct split-K kernel everywhere); -1 = default (on)."""
+    lib = _bind_ops()
+    lib.mcedm_op_set_wgrad_wino.argtypes = [C.c_int]
+    check(lib.mcedm_op_set_wgrad_wino(int(enable)), "set_wgrad_wino")
 
 
 def set_conv_resident(enable: int = -1) -> None:
