@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define MCEDM_ABI_VERSION 3   /* 3: mcedm_edm_loss / mcedm_sqnorm take caller-owned reduction scratch; mcedm_ddim_timesteps */
+#define MCEDM_ABI_VERSION 4   /* 4: per-plan kernel variants (mcedm_*_plan_set_variant), mcedm_heun_sample_rng;
+                               * 3: mcedm_edm_loss / mcedm_sqnorm take caller-owned reduction scratch; mcedm_ddim_timesteps */
 /* Device scratch of one grid-wide fixed-order reduction (mcedm_edm_loss, mcedm_sqnorm): 8-byte aligned, contents
  * irrelevant on entry, private to the call until it has completed on its stream.  Two calls that may run concurrently (two
  * plans on two streams of one device) need two scratch areas; calls ordered on one stream can share one. */
@@ -88,6 +89,21 @@ const char* mcedm_last_error(void);
 int mcedm_unet_plan_create(const mcedm_unet_desc* desc, mcedm_plan** out);
 void mcedm_unet_plan_destroy(mcedm_plan* plan);
 
+/* Kernel variants of ONE plan (re-entrant per plan).  Every kernel family that exists in two forms is chosen per
+ * call in three steps, first hit wins: the plan's own setting (this function; a field of the plan, in force while one of the
+ * plan's entry points executes on the calling thread), the process-wide test hooks mcedm_op_set_* below (kernel-level calls
+ * have no plan), the environment variable.  value: 1 on, 0 off, -1 back to the process default.  Two plans in one process --
+ * on two threads or two streams -- cannot flip each other's kernels.  MCEDM_VARIANT_CONV_WINO also decides how a plan lays
+ * out its workspace (whether a block's 1x1 skip projection is folded into conv1): set it before the first
+ * mcedm_unet_workspace_bytes / forward of the plan and leave it. */
+#define MCEDM_VARIANT_CONV_WINO 0       /* Winograd F(2x2, 3x3) forward / data-gradient convs (env MCEDM_WINOGRAD, default 1) */
+#define MCEDM_VARIANT_CONV_WINO1 1      /* its one-wave-per-SIMD form for 128-channel shapes (env MCEDM_WINO1, default 0) */
+#define MCEDM_VARIANT_CONV_RESIDENT 2   /* input-resident conv kernels at <= 32 x 32 (env MCEDM_CONV_RESIDENT, default 1) */
+#define MCEDM_VARIANT_CONV8 3           /* experimental 8-wave direct conv (env MCEDM_CONV8, default 0) */
+#define MCEDM_VARIANT_ATTN_FUSED 4      /* single-launch attention block at 8 x 8 x 64 (env MCEDM_ATTN_FUSED, default 1) */
+#define MCEDM_VARIANT_WGRAD_WINO 5      /* Winograd F(3x3, 2x2) weight gradient (env MCEDM_WGRAD_WINO, default 1) */
+int mcedm_unet_plan_set_variant(mcedm_plan* plan, int which, int value);
+
 /* Parameter table in DhariwalUNet.state_dict() order (parameters only, no buffers).
  * name is owned by the plan. */
 int mcedm_unet_param_count(const mcedm_plan* plan);
@@ -136,6 +152,16 @@ int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, const mcedm_sa
                       const float* cond, const float* mask, const float* init_noise,
                       const double* step_noise, double* out, int return_last, void* workspace,
                       size_t workspace_bytes, int B, int H, int W, void* stream);
+
+/* mcedm_heun_sample with the per-step churn noise drawn ON THE DEVICE: models/mcedm.py:604-608 draws randn_like(x_cur) in every
+ * step; here the kernel that applies `x_hat = x_cur + sqrt(t_hat^2 - t_cur^2) * S_noise * eps * mask` generates eps itself
+ * (Philox4x32-10 + Box-Muller in fp64; key = the 64-bit seed at *rng_seed in DEVICE memory, counter = (element pair, step index)),
+ * so there is no [timesteps][B][C][H][W] fp64 step_noise tensor and a captured HIP graph replays with fresh noise once the host
+ * has written a new seed.  Same moments as, but not the stream of, torch's generator; mcedm_normal_fill(out, n, rng_seed, draw = i)
+ * writes step i's draw out, and feeding those tensors to mcedm_heun_sample reproduces this call bit for bit. */
+int mcedm_heun_sample_rng(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp, const float* cond,
+                          const float* mask, const float* init_noise, const uint64_t* rng_seed, double* out, int return_last,
+                          void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
 /* PDE guidance inside the single-task sampler (PlCondEdm.sample_edm with guide_dx=True, models/ddim.py:1532-1601:
  * get_dx_log_prob :641-650 -> get_dx_pde :1424-1450, used at :1577-1579 and :1589-1591): after every denoiser call
  * dx = mean over the two fields of d residual(x_unnorm) / d x_unnorm, x_unnorm = (h from cond[:, 0], u = denoised state),
@@ -388,6 +414,7 @@ typedef struct {
 typedef struct mcedm_ddpm_plan mcedm_ddpm_plan;
 int mcedm_ddpm_plan_create(const mcedm_ddpm_desc* desc, mcedm_ddpm_plan** out);
 void mcedm_ddpm_plan_destroy(mcedm_ddpm_plan* plan);
+int mcedm_ddpm_plan_set_variant(mcedm_ddpm_plan* plan, int which, int value);      /* as mcedm_unet_plan_set_variant */
 /* Parameter table in Model.state_dict() order (names as the reference's: "temb.dense.0.weight", "down.0.block.0.norm1.weight", ...). */
 int mcedm_ddpm_param_count(const mcedm_ddpm_plan* plan);
 int mcedm_ddpm_param_info(const mcedm_ddpm_plan* plan, int index, const char** name, int64_t* numel, int32_t* ndim,

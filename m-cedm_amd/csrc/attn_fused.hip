@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void attn_block64_kernel(AttnBlockArgs a) {
 static int g_attn_fused = -1;      // -1: env MCEDM_ATTN_FUSED (default on); test hook
 void set_attn_fused(int enable) { g_attn_fused = enable; }
 bool attn_block_fused_applicable(int C, int heads, int H, int W, int groups) {
-  if (g_attn_fused < 0) { const char* e = getenv("MCEDM_ATTN_FUSED"); g_attn_fused = e ? atoi(e) : 1; }
-  return g_attn_fused != 0 && C == 64 && heads == 1 && H == 8 && W == 8 && groups == 16;
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_ATTN_FUSED"); env = e ? atoi(e) : 1; }
+  return variant_choice(KV_ATTN_FUSED, g_attn_fused, env) != 0 && C == 64 && heads == 1 && H == 8 && W == 8 && groups == 16;
 }
 
 // y, z: [B][64][8][8]; wq / bq, wp / bp: the packed 1x1 tables of the block's qkv and proj convs

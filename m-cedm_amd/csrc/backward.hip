@@ -281,6 +281,7 @@ static std::vector<int> bucket_candidates(const mcedm_plan& P) {
 }
 
 extern "C" int mcedm_unet_grad_buckets(const mcedm_plan* plan, int max_buckets, int32_t* first_param, int* n_buckets) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && first_param && n_buckets && max_buckets >= 1, "grad_buckets: bad argument");
   const mcedm_plan& P = *plan;
   int64_t total = 0;
@@ -431,6 +432,7 @@ extern "C" int mcedm_edm_denoise_backward(const mcedm_plan* plan, const void* pa
                                           const float* x, const float* sigma, int n_sigma, const float* cond,
                                           const float* dD, float* const* grads, void* workspace, size_t workspace_bytes,
                                           int B, int H, int W, double sigma_data, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   (void)sigma; (void)sigma_data;
   return denoise_backward_impl(plan, packed, params, x, nullptr, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W, 0,
                                nullptr, nullptr, stream);
@@ -441,6 +443,7 @@ extern "C" int mcedm_edm_denoise_backward_dx(const mcedm_plan* plan, const void*
                                              const float* cond, const float* dD, float* const* grads, void* workspace,
                                              size_t workspace_bytes, int B, int H, int W, double sigma_data, int n_buckets,
                                              const int32_t* bucket_first_param, void* const* bucket_events, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   (void)sigma; (void)sigma_data;
   MCEDM_REQUIRE(n_buckets >= 0, "denoise_backward_dx: n_buckets must be >= 0");
   return denoise_backward_impl(plan, packed, params, x, dx, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W,
@@ -453,6 +456,7 @@ extern "C" int mcedm_edm_denoise_backward_bucketed(const mcedm_plan* plan, const
                                                    size_t workspace_bytes, int B, int H, int W, double sigma_data,
                                                    int n_buckets, const int32_t* bucket_first_param,
                                                    void* const* bucket_events, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   (void)sigma; (void)sigma_data;
   MCEDM_REQUIRE(n_buckets >= 1, "denoise_backward_bucketed: n_buckets must be >= 1");
   return denoise_backward_impl(plan, packed, params, x, nullptr, n_sigma, cond, dD, grads, workspace, workspace_bytes, B, H, W,

@@ -37,6 +37,25 @@ void set_error(const char* fmt, ...);
     }                                                                                         \
   } while (0)
 
+// Kernel-variant choices.  Three levels, first hit wins: the plan whose entry point is executing on this thread
+// (mcedm_*_plan_set_variant; a field of the plan, so two plans in one process -- on two threads or two streams -- cannot flip each
+// other's kernels), the process-wide test hooks mcedm_op_set_* (kernel-level calls have no plan), the environment.
+enum KernelVariant { KV_CONV_WINO = 0, KV_CONV_WINO1 = 1, KV_CONV_RESIDENT = 2, KV_CONV8 = 3, KV_ATTN_FUSED = 4, KV_WGRAD_WINO = 5,
+                     KV_COUNT = 6 };
+struct KernelVariants { int v[KV_COUNT] = {-1, -1, -1, -1, -1, -1}; };
+const KernelVariants* current_variants();                 // of the executing plan-level call on this thread, or null
+struct VariantScope {                                      // first statement of every extern "C" function that takes a plan
+  const KernelVariants* prev;
+  explicit VariantScope(const KernelVariants* kv);
+  ~VariantScope();
+};
+// value of switch `which`: the executing plan's if it set one, else `global` (an mcedm_op_set_* value) if >= 0, else env_default
+static inline int variant_choice(int which, int global, int env_default) {
+  const KernelVariants* kv = current_variants();
+  if (kv && kv->v[which] >= 0) return kv->v[which];
+  return global >= 0 ? global : env_default;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

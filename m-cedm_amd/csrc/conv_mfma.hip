@@ -844,9 +844,10 @@ static int dispatch(const ConvArgs& a, hipStream_t stream) {
     return launch_cfg<ConvCfg<32, 8, 32, 1, 4, TAPS, KC>>(a, stream);
   }
   if (a.W >= 24) {
-    if (g_conv8 < 0) { const char* e = getenv("MCEDM_CONV8"); g_conv8 = e ? atoi(e) : 0; }
+    static int conv8_env = -1;
+    if (conv8_env < 0) { const char* e = getenv("MCEDM_CONV8"); conv8_env = e ? atoi(e) : 0; }
     // experimental 8-wave kernel (needs about one workgroup per CU); results are bit-identical to <128, 8, 32>
-    if (g_conv8 && !a.sk_wpk && a.gsum_rc != 2 && TAPS == 9 && a.resample == RS_NONE && coutp % 128 == 0 && a.Ca + a.Cb <= 2048 &&
+    if (variant_choice(KV_CONV8, g_conv8, conv8_env) && !a.sk_wpk && a.gsum_rc != 2 && TAPS == 9 && a.resample == RS_NONE && coutp % 128 == 0 && a.Ca + a.Cb <= 2048 &&
         blocks_for(128, 16, 32) >= 224)
       return launch_conv8(a, stream);
     if (coutp % 128 == 0 && blocks_for(128, 8, 32) >= want) return launch_cfg<ConvCfg<128, 8, 32, 1, 4, TAPS, KC>>(a, stream);

@@ -573,10 +573,9 @@ __global__ __launch_bounds__(256, 2) void conv_resident_kernel(ConvArgs p, int t
 static int g_resident = -1;      // -1: default (env MCEDM_CONV_RESIDENT, else on); 0 / 1: forced by mcedm_op_set_conv_resident
 void set_conv_resident(int enable) { g_resident = enable; }
 static int resident_level() {     // 0: off, > 0: on
-  if (g_resident >= 0) return g_resident;
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_CONV_RESIDENT"); env = e ? atoi(e) : 1; }
-  return env;
+  return variant_choice(KV_CONV_RESIDENT, g_resident, env);
 }
 
 static constexpr int LDS_MAX = 160 * 1024;

@@ -157,6 +157,10 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
           if (i + 1 < RSUB || lane + 64 * i < RROWS * RPITCH) rb[(sc * WKC + kl) * RPLANE + lane + 64 * i] = v;
         }
       } else {
+        // zero padding = (v - mean) * 0 + 0 on the lane's copy of the row.  PRECONDITION: finite activations -- an out-of-image
+        // lane loads element 0 of the plane, and an Inf / NaN there (or a (v - mean) that overflows) would make the padding NaN
+        // instead of 0; the up-sampling variant above masks the finished value bit-wise.  (A network whose activations are
+        // not finite has no meaningful output either way; two v_and per pair here would cost ~3 % of the slice's vector work.)
         const unsigned mk = rkeepC[0] & ck;
         const float scm = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cf.scale) & mk);
         const float ofm = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, cf.offset) & mk);
@@ -519,10 +523,9 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
 static int g_wino = -1;      // -1: default (env MCEDM_WINOGRAD, else on); 0 / 1: forced by mcedm_op_set_conv_wino
 void set_conv_wino(int enable) { g_wino = enable; }
 static int wino_env() {                                        // MCEDM_WINOGRAD=0: never take this kernel
-  if (g_wino >= 0) return g_wino;
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_WINOGRAD"); env = e ? atoi(e) : 1; }
-  return env;
+  return variant_choice(KV_CONV_WINO, g_wino, env);            // the executing plan's choice, the process-wide hook, the environment
 }
 static int wino_mode_env() {                                   // MCEDM_WINO_MODE: ablation bits of the -DMCEDM_WINO_TIMELINE build (else unused)
   static int env = -1;

@@ -422,10 +422,9 @@ __global__ __launch_bounds__(Wino1Cfg::NT, 1) void conv_wino1_kernel(const ConvA
 static int g_wino1 = -1;      // -1: default (env MCEDM_WINO1, else OFF: measured 9 % slower, see the header); 0 / 1: forced by mcedm_op_set_conv_wino1
 void set_conv_wino1(int enable) { g_wino1 = enable; }
 static int wino1_env() {
-  if (g_wino1 >= 0) return g_wino1;
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_WINO1"); env = e ? atoi(e) : 0; }
-  return env;
+  return variant_choice(KV_CONV_WINO1, g_wino1, env);
 }
 
 // a (already validated by launch_conv_wino) with Cout % 128 == 0: the one-wave-per-SIMD kernel; -1 when switched off

@@ -61,6 +61,7 @@ struct mcedm_ddpm_plan {
   std::vector<mcedm::DLevel> down, up;
   mcedm::DRes mid1, mid2;
   mcedm::DAttn mid_attn;
+  mcedm::KernelVariants variants;   // per-plan kernel choices (mcedm_ddpm_plan_set_variant); -1 = process default
   int rows = 0;              // total rows of the combined bias table (sum of cout over the ResnetBlocks)
   // packed buffer (float offsets)
   size_t freqs = mcedm::NONE, w0 = mcedm::NONE, b0 = mcedm::NONE, w1 = mcedm::NONE, b1 = mcedm::NONE;
@@ -253,6 +254,13 @@ extern "C" int mcedm_ddpm_plan_create(const mcedm_ddpm_desc* d, mcedm_ddpm_plan*
   return MCEDM_OK;
 }
 
+extern "C" int mcedm_ddpm_plan_set_variant(mcedm_ddpm_plan* plan, int which, int value) {
+  MCEDM_REQUIRE(plan, "ddpm_plan_set_variant: null plan");
+  MCEDM_REQUIRE(which >= 0 && which < KV_COUNT, "ddpm_plan_set_variant: unknown switch %d", which);
+  MCEDM_REQUIRE(value >= -1 && value <= 1, "ddpm_plan_set_variant: value must be -1 (process default), 0 or 1");
+  plan->variants.v[which] = value;
+  return MCEDM_OK;
+}
 extern "C" void mcedm_ddpm_plan_destroy(mcedm_ddpm_plan* plan) { delete plan; }
 extern "C" int mcedm_ddpm_param_count(const mcedm_ddpm_plan* plan) { return plan ? (int)plan->params.size() : MCEDM_ERR_INVALID; }
 extern "C" int mcedm_ddpm_param_info(const mcedm_ddpm_plan* plan, int index, const char** name, int64_t* numel, int32_t* ndim,
@@ -266,6 +274,7 @@ extern "C" int mcedm_ddpm_param_info(const mcedm_ddpm_plan* plan, int index, con
   return MCEDM_OK;
 }
 extern "C" int mcedm_ddpm_packed_bytes(const mcedm_ddpm_plan* plan, size_t* bytes) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && bytes, "ddpm_packed_bytes: null argument");
   *bytes = plan->packed_floats * sizeof(float);
   return MCEDM_OK;
@@ -317,6 +326,7 @@ static int dpack(const DAttn& a, const float* const* params, float* pk, hipStrea
 
 extern "C" int mcedm_ddpm_pack_weights(const mcedm_ddpm_plan* plan, const float* const* params, const float* temb_freqs,
                                        void* packed, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && params && temb_freqs && packed, "ddpm_pack_weights: null argument");
   const mcedm_ddpm_plan& P = *plan;
   for (size_t i = 0; i < P.params.size(); ++i)
@@ -697,6 +707,7 @@ static int nearest_step(const float* steps, int n, float sigma) {
 }  // namespace mcedm
 
 extern "C" int mcedm_ddpm_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* bytes) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && bytes, "ddpm_workspace_bytes: null argument");
   DHeader hd; size_t act = 0;
   int rc = ddpm_sizes(*plan, B, &hd, &act);
@@ -707,6 +718,7 @@ extern "C" int mcedm_ddpm_workspace_bytes(const mcedm_ddpm_plan* plan, int B, si
 
 extern "C" int mcedm_ddpm_forward(const mcedm_ddpm_plan* plan, const void* packed, const float* x, float t, float* out,
                                   void* workspace, size_t workspace_bytes, int B, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && packed && x && out && workspace, "ddpm_forward: null argument");
   DHeader hd; size_t act = 0;
   int rc = ddpm_sizes(*plan, B, &hd, &act);
@@ -718,6 +730,7 @@ extern "C" int mcedm_ddpm_forward(const mcedm_ddpm_plan* plan, const void* packe
 
 extern "C" int mcedm_ddpm_forward_sc(const mcedm_ddpm_plan* plan, const void* packed, const float* x, const float* x_self_cond,
                                      float t, float* out, void* workspace, size_t workspace_bytes, int B, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && packed && x && out && workspace, "ddpm_forward_sc: null argument");
   MCEDM_REQUIRE(!x_self_cond || plan->desc.self_cond, "ddpm_forward_sc: the network was built without self-conditioning channels");
   DHeader hd; size_t act = 0;
@@ -730,6 +743,7 @@ extern "C" int mcedm_ddpm_forward_sc(const mcedm_ddpm_plan* plan, const void* pa
 
 extern "C" int mcedm_ddpm_denoise(const mcedm_ddpm_plan* plan, const void* packed, const float* x, float sigma, float c_noise,
                                   float* D_out, float* F_out, void* workspace, size_t workspace_bytes, int B, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && packed && x && D_out && workspace, "ddpm_denoise: null argument");
   DHeader hd; size_t act = 0;
   int rc = ddpm_sizes(*plan, B, &hd, &act);
@@ -762,6 +776,7 @@ __global__ void repaint_mask_kernel(float* __restrict__ m, int C, int H, int W, 
 }  // namespace mcedm
 
 extern "C" int mcedm_repaint_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* bytes) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && bytes, "repaint_workspace_bytes: null argument");
   size_t u = 0;
   int rc = mcedm_ddpm_workspace_bytes(plan, B, &u);
@@ -795,12 +810,14 @@ extern "C" int mcedm_repaint_sample(const mcedm_ddpm_plan* plan, const void* pac
                                     const float* hu, const float* init_noise, const double* step_noise,
                                     const double* repeat_noise, double* out, int return_last, void* workspace,
                                     size_t workspace_bytes, int B, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   return repaint_impl(plan, packed, sp, hu, init_noise, step_noise, repeat_noise, nullptr, out, return_last, workspace,
                       workspace_bytes, B, stream);
 }
 extern "C" int mcedm_repaint_sample_rng(const mcedm_ddpm_plan* plan, const void* packed, const mcedm_repaint_desc* sp,
                                         const float* hu, const float* init_noise, const uint64_t* rng_seed, double* out,
                                         int return_last, void* workspace, size_t workspace_bytes, int B, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(rng_seed != nullptr, "repaint_sample_rng: rng_seed is null");
   return repaint_impl(plan, packed, sp, hu, init_noise, nullptr, nullptr, reinterpret_cast<const unsigned long long*>(rng_seed),
                       out, return_last, workspace, workspace_bytes, B, stream);
@@ -928,6 +945,7 @@ static DdimBufs ddim_bufs(const mcedm_ddpm_plan& P, int B) {
 }  // namespace mcedm
 
 extern "C" int mcedm_ddim_workspace_bytes(const mcedm_ddpm_plan* plan, int B, size_t* bytes) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && bytes, "ddim_workspace_bytes: null argument");
   size_t u = 0;
   int rc = mcedm_ddpm_workspace_bytes(plan, B, &u);
@@ -975,6 +993,7 @@ extern "C" int mcedm_ddim_repaint_sample(const mcedm_ddpm_plan* plan, const void
                                          const float* hu, const float* init_noise, const float* eta_noise, float* xs_out,
                                          float* x0_out, int return_last, void* workspace, size_t workspace_bytes, int B,
                                          void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && packed && sp && hu && init_noise && xs_out && workspace, "ddim_repaint_sample: null argument");
   const mcedm_ddpm_plan& P = *plan;
   MCEDM_REQUIRE(P.desc.in_channels == P.desc.out_channels, "ddim_repaint_sample: in_channels != out_channels");

@@ -201,8 +201,10 @@ __device__ __forceinline__ void normal_pair(const unsigned (&c)[4], double& z0, 
   sincos(6.283185307179586476925 * u2, &sn, &cs);
   z0 = r * cs; z1 = r * sn;
 }
+// mask (optional): x_hat = x_cur + (c * eps) * mask, the joint model's churn (models/mcedm.py:608); NULL multiplies by 1.0 exactly
 __global__ void heun_churn_rng_kernel(double* __restrict__ x, const unsigned long long* __restrict__ seed_dev,
-                                      unsigned long long draw, double c, size_t total, float* __restrict__ x32) {
+                                      unsigned long long draw, double c, size_t total, float* __restrict__ x32,
+                                      const float* __restrict__ mask) {
   const unsigned long long seed = *seed_dev;
   const size_t pairs = (total + 1) / 2;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
@@ -210,14 +212,19 @@ __global__ void heun_churn_rng_kernel(double* __restrict__ x, const unsigned lon
     philox4x32_10(ctr, (unsigned)seed, (unsigned)(seed >> 32));
     double z0, z1;
     normal_pair(ctr, z0, z1);
-    const double v0 = x[2 * i] + c * z0;
+    const double m0 = mask ? (double)mask[2 * i] : 1.0;
+    const double v0 = x[2 * i] + (c * z0) * m0;
     x[2 * i] = v0; x32[2 * i] = (float)v0;
-    if (2 * i + 1 < total) { const double v1 = x[2 * i + 1] + c * z1; x[2 * i + 1] = v1; x32[2 * i + 1] = (float)v1; }
+    if (2 * i + 1 < total) {
+      const double m1 = mask ? (double)mask[2 * i + 1] : 1.0;
+      const double v1 = x[2 * i + 1] + (c * z1) * m1;
+      x[2 * i + 1] = v1; x32[2 * i + 1] = (float)v1;
+    }
   }
 }
 int launch_heun_churn_rng(double* x, const unsigned long long* seed_dev, unsigned long long draw, double c, size_t total, float* x32,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(heun_churn_rng_kernel, dim3(grid_for((total + 1) / 2)), dim3(256), 0, s, x, seed_dev, draw, c, total, x32);
+                          hipStream_t s, const float* mask) {
+  hipLaunchKernelGGL(heun_churn_rng_kernel, dim3(grid_for((total + 1) / 2)), dim3(256), 0, s, x, seed_dev, draw, c, total, x32, mask);
   MCEDM_LAUNCH_CHECK("heun_churn_rng_kernel");
   return MCEDM_OK;
 }

@@ -16,7 +16,7 @@ int launch_heun_churn(double* x, const double* eps, const float* mask, double c,
 // x += c * N(0, 1) with the noise generated in the kernel (Philox4x32-10 keyed by the 64-bit seed at *seed_dev, counter =
 // (element pair, draw)); launch_normal_fill writes the same draw out as a tensor
 int launch_heun_churn_rng(double* x, const unsigned long long* seed_dev, unsigned long long draw, double c, size_t total, float* x32,
-                          hipStream_t s);
+                          hipStream_t s, const float* mask = nullptr);
 int launch_normal_fill(double* out, const unsigned long long* seed_dev, unsigned long long draw, size_t total, hipStream_t s);
 // dxg / wgt / gdiv: optional PDE-guidance term of the single-task sampler, d -= (double)((wgt * dxg) / gdiv) formed in fp32
 // (models/ddim.py:1577-1579, 1590-1591: `weight * dx / t_hat`, with t_hat in BOTH stages)

@@ -9,6 +9,7 @@
 #include "edm.hpp"
 #include "pack.hpp"
 #include "plan.hpp"
+#include "prof.hpp"
 #include "bwd.hpp"
 
 namespace mcedm {
@@ -104,6 +105,14 @@ static void place_norm(Taker& t, NormP& n) { n.gamma = t.take(n.C); n.beta = t.t
 using namespace mcedm;
 
 extern "C" int mcedm_version(void) { return MCEDM_ABI_VERSION; }
+
+extern "C" int mcedm_unet_plan_set_variant(mcedm_plan* plan, int which, int value) {
+  MCEDM_REQUIRE(plan, "plan_set_variant: null plan");
+  MCEDM_REQUIRE(which >= 0 && which < KV_COUNT, "plan_set_variant: unknown switch %d", which);
+  MCEDM_REQUIRE(value >= -1 && value <= 1, "plan_set_variant: value must be -1 (process default), 0 or 1");
+  plan->variants.v[which] = value;
+  return MCEDM_OK;
+}
 extern "C" const char* mcedm_last_error(void) { return g_err; }
 
 extern "C" int mcedm_unet_plan_create(const mcedm_unet_desc* d, mcedm_plan** out) {
@@ -235,6 +244,7 @@ extern "C" int mcedm_unet_param_info(const mcedm_plan* plan, int index, const ch
 }
 
 extern "C" int mcedm_unet_packed_bytes(const mcedm_plan* plan, size_t* bytes) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && bytes, "packed_bytes: null argument");
   *bytes = plan->packed_floats * sizeof(float);
   return MCEDM_OK;
@@ -292,14 +302,20 @@ struct Packer {
   int count = 0;
   hipStream_t s;
   int status = MCEDM_OK;
+  double bytes = 0.0;           // read + written by the batch (profiler row: an HBM-bound kernel)
   void flush() {
-    if (count == 0 || status != MCEDM_OK) { count = 0; return; }
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(48, count), dim3(256), 0, s, b);
-    if (hipGetLastError() != hipSuccess) { set_error("pack_batch_kernel launch failed"); status = MCEDM_ERR_HIP; }
-    count = 0;
+    if (count == 0 || status != MCEDM_OK) { count = 0; bytes = 0.0; return; }
+    {
+      ProfScope ps("pack_batch_kernel", 0.0, bytes, s);
+      hipLaunchKernelGGL(pack_batch_kernel, dim3(48, count), dim3(256), 0, s, b);
+      if (hipGetLastError() != hipSuccess) { set_error("pack_batch_kernel launch failed"); status = MCEDM_ERR_HIP; }
+    }
+    count = 0; bytes = 0.0;
   }
   void add(const PackJob& j) {
     b.j[count] = j;
+    // direct tables: one float read per float written; Winograd: 9 taps read, 16 positions written per (cout, cin)
+    bytes += j.kind == 0 ? 8.0 * j.total : 4.0 * (9.0 + 16.0) * j.total;
     if (++count == PACK_MAX) flush();
   }
   void conv(const float* w, float* dst, int Cout, int Cin, int taps, int qkv_heads, int tflip) {
@@ -352,6 +368,7 @@ static void pack_norm(const NormP& n, const float* const* params, float* pk, Cop
 }  // namespace mcedm
 
 extern "C" int mcedm_unet_pack_weights(const mcedm_plan* plan, const float* const* params, void* packed, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && params && packed, "pack_weights: null argument");
   const mcedm_plan& P = *plan;
   for (size_t i = 0; i < P.params.size(); ++i)
@@ -807,6 +824,7 @@ static int denoise_impl(const mcedm_plan& P, const Layout& L, const Header& hd, 
 }  // namespace mcedm
 
 extern "C" int mcedm_unet_workspace_bytes(const mcedm_plan* plan, int B, int H, int W, int training, size_t* bytes) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && bytes, "workspace_bytes: null argument");
   Layout L;
   int rc = build_layout(*plan, B, H, W, training, B, &L);
@@ -819,6 +837,7 @@ extern "C" int mcedm_unet_forward_dx(const mcedm_plan* plan, const void* packed,
                                      const float* x_scale, const float* noise_labels, int n_noise, float* out,
                                      void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
                                      void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && packed && x && noise_labels && out && workspace, "unet_forward: null argument");
   MCEDM_REQUIRE(dx == nullptr || plan->desc.dx_mode != MCEDM_DX_NONE, "unet_forward: dx given to a plan without dx_cond");
   Layout L;
@@ -847,6 +866,7 @@ extern "C" int mcedm_unet_forward(const mcedm_plan* plan, const void* packed, co
                                   const float* x_scale, const float* noise_labels, int n_noise, float* out,
                                   void* workspace, size_t workspace_bytes, int B, int H, int W, int training,
                                   void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   return mcedm_unet_forward_dx(plan, packed, x, nullptr, cond, x_scale, noise_labels, n_noise, out, workspace, workspace_bytes, B, H,
                                W, training, stream);
 }
@@ -855,6 +875,7 @@ extern "C" int mcedm_edm_denoise_dx(const mcedm_plan* plan, const void* packed, 
                                     int n_sigma, const float* cond, float* D_out, float* F_out, void* workspace,
                                     size_t workspace_bytes, int B, int H, int W, int training, double sigma_data,
                                     void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && packed && x && sigma && D_out && workspace, "edm_denoise: null argument");
   MCEDM_REQUIRE(dx == nullptr || plan->desc.dx_mode != MCEDM_DX_NONE, "edm_denoise: dx given to a plan without dx_cond");
   Layout L;
@@ -873,6 +894,7 @@ extern "C" int mcedm_edm_denoise(const mcedm_plan* plan, const void* packed, con
                                  int n_sigma, const float* cond, float* D_out, float* F_out, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, int training, double sigma_data,
                                  void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   return mcedm_edm_denoise_dx(plan, packed, x, nullptr, sigma, n_sigma, cond, D_out, F_out, workspace, workspace_bytes, B, H, W,
                               training, sigma_data, stream);
 }
@@ -908,6 +930,7 @@ static SamplerBufs sampler_bufs(const mcedm_plan& P, int B, int H, int W) {
 }  // namespace mcedm
 
 extern "C" int mcedm_sampler_workspace_bytes(const mcedm_plan* plan, int B, int H, int W, size_t* bytes) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(plan && bytes, "sampler_workspace_bytes: null argument");
   size_t u = 0;
   int rc = mcedm_unet_workspace_bytes(plan, B, H, W, 0, &u);
@@ -941,20 +964,35 @@ static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mc
                             const float* cond, const float* mask, const float* init_noise,
                             const double* step_noise, double* out, int return_last, void* workspace,
                             size_t workspace_bytes, int B, int H, int W, const mcedm_guidance_desc* gd, void* stream,
-                            const mcedm_guidance_desc* dxc = nullptr);
+                            const mcedm_guidance_desc* dxc = nullptr, const uint64_t* rng_seed = nullptr);
 
 extern "C" int mcedm_heun_sample(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
                                  const float* cond, const float* mask, const float* init_noise,
                                  const double* step_noise, double* out, int return_last, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   return heun_sample_impl(plan, packed, sp, cond, mask, init_noise, step_noise, out, return_last, workspace, workspace_bytes,
                           B, H, W, nullptr, stream);
+}
+
+// The churn noise of every step generated inside the kernel that applies it (Philox4x32-10 keyed by *rng_seed, draw = step
+// index): no [timesteps][B][C][H][W] fp64 tensor (2.1 GB at 50 x 160 x 2 x 128 x 128, the reference's shipped sampler config,
+// configs/diff_sampler/edm_sampler.yaml) and one HIP graph replays with fresh noise after the host bumps the seed.
+extern "C" int mcedm_heun_sample_rng(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
+                                     const float* cond, const float* mask, const float* init_noise, const uint64_t* rng_seed,
+                                     double* out, int return_last, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                                     void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
+  MCEDM_REQUIRE(rng_seed != nullptr, "heun_sample_rng: rng_seed (a 64-bit seed in device memory) is null");
+  return heun_sample_impl(plan, packed, sp, cond, mask, init_noise, nullptr, out, return_last, workspace, workspace_bytes,
+                          B, H, W, nullptr, stream, nullptr, rng_seed);
 }
 
 extern "C" int mcedm_heun_sample_guided(const mcedm_plan* plan, const void* packed, const mcedm_sampler_desc* sp,
                                         const mcedm_guidance_desc* gd, const float* cond, const float* mask,
                                         const float* init_noise, const double* step_noise, double* out, int return_last,
                                         void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(gd != nullptr && (gd->system == 1 || gd->system == 2), "heun_sample_guided: guidance system must be 1 (SWE) or 2 (Darcy)");
   MCEDM_REQUIRE(plan && plan->desc.in_channels == 1 && plan->desc.cond_channels >= 1 && cond != nullptr && mask == nullptr,
                 "heun_sample_guided: PDE guidance is defined for the single-task sampler (state u, conditioning h in cond[:, 0]; "
@@ -967,6 +1005,7 @@ extern "C" int mcedm_heun_sample_dxcond(const mcedm_plan* plan, const void* pack
                                         const mcedm_guidance_desc* dxc, const mcedm_guidance_desc* gd, const float* cond,
                                         const float* init_noise, const double* step_noise, double* out, int return_last,
                                         void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream) {
+  VariantScope variant_scope__(plan ? &plan->variants : nullptr);
   MCEDM_REQUIRE(dxc != nullptr && (dxc->system == 1 || dxc->system == 2), "heun_sample_dxcond: dx system must be 1 (SWE) or 2 (Darcy)");
   MCEDM_REQUIRE(gd == nullptr || gd->system == 1 || gd->system == 2, "heun_sample_dxcond: guidance system must be 1 (SWE) or 2 (Darcy)");
   MCEDM_REQUIRE(plan && plan->desc.dx_mode != MCEDM_DX_NONE && plan->desc.dx_channels == 1 && plan->desc.in_channels == 1 &&
@@ -981,7 +1020,7 @@ static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mc
                             const float* cond, const float* mask, const float* init_noise,
                             const double* step_noise, double* out, int return_last, void* workspace,
                             size_t workspace_bytes, int B, int H, int W, const mcedm_guidance_desc* gd, void* stream,
-                            const mcedm_guidance_desc* dxc) {
+                            const mcedm_guidance_desc* dxc, const uint64_t* rng_seed) {
   MCEDM_REQUIRE(plan && packed && sp && init_noise && out && workspace, "heun_sample: null argument");
   const mcedm_plan& P = *plan;
   MCEDM_REQUIRE(P.desc.in_channels == P.desc.out_channels, "heun_sample: in_channels != out_channels");
@@ -996,7 +1035,7 @@ static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mc
   for (int i = 0; i < N; ++i) {
     const bool in_range = sp->S_min <= t[i] && t[i] <= sp->S_max;                    // mcedm.py:606
     gammas[i] = in_range ? std::min(sp->S_churn / N, std::sqrt(2.0) - 1.0) : 0.0;
-    MCEDM_REQUIRE(gammas[i] == 0.0 || step_noise != nullptr, "heun_sample: S_churn > 0 needs step_noise");
+    MCEDM_REQUIRE(gammas[i] == 0.0 || step_noise != nullptr || rng_seed != nullptr, "heun_sample: S_churn > 0 needs step_noise (or mcedm_heun_sample_rng)");
   }
   Layout L;
   if ((rc = build_layout(P, B, H, W, 0, 1, &L))) return rc;
@@ -1027,7 +1066,9 @@ static int heun_sample_impl(const mcedm_plan* plan, const void* packed, const mc
     const double t_hat = t_cur + gammas[i] * t_cur;                                   // mcedm.py:607
     if (gammas[i] != 0.0) {
       const double c = std::sqrt(t_hat * t_hat - t_cur * t_cur) * sp->S_noise;
-      if ((rc = launch_heun_churn(x, step_noise + (size_t)i * total, mask, c, total, x32, s))) return rc;
+      if (step_noise) rc = launch_heun_churn(x, step_noise + (size_t)i * total, mask, c, total, x32, s);
+      else rc = launch_heun_churn_rng(x, reinterpret_cast<const unsigned long long*>(rng_seed), (unsigned long long)i, c, total, x32, s, mask);
+      if (rc) return rc;
     }
     // Euler step (mcedm.py:611-618); dx_cond: dx_in = get_dx_input(h, x_hat) first (ddim.py:1571)
     float* dxin = nullptr;

@@ -122,6 +122,7 @@ struct mcedm_plan {
   int film_rows = 0;
   size_t packed_floats = 0;
   int levels_div = 1;          // 2^(n_levels-1)
+  mcedm::KernelVariants variants;   // per-plan kernel choices (mcedm_unet_plan_set_variant); -1 = process default
 };
 
 namespace mcedm {

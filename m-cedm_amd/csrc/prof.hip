@@ -17,6 +17,11 @@ static std::mutex g_mu;
 
 bool prof_enabled() { return g_on; }
 
+static thread_local const KernelVariants* t_variants = nullptr;
+const KernelVariants* current_variants() { return t_variants; }
+VariantScope::VariantScope(const KernelVariants* kv) : prev(t_variants) { t_variants = kv; }
+VariantScope::~VariantScope() { t_variants = prev; }
+
 static hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;

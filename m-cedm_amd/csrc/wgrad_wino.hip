@@ -332,10 +332,9 @@ __global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float* __
 static int g_wgw = -1;       // -1: default (env MCEDM_WGRAD_WINO, else on); 0 / 1: forced by mcedm_op_set_wgrad_wino
 void set_wgrad_wino(int enable) { g_wgw = enable; }
 static int wgw_env() {
-  if (g_wgw >= 0) return g_wgw;
   static int env = -1;
   if (env < 0) { const char* e = getenv("MCEDM_WGRAD_WINO"); env = e ? atoi(e) : 1; }
-  return env;
+  return variant_choice(KV_WGRAD_WINO, g_wgw, env);
 }
 
 // splits of the K range: one round of one workgroup per CU over the 4 * cib * cob siblings, a multiple of 8 (XCD mapping).

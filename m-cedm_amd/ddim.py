@@ -178,7 +178,9 @@ class PlCondEdm(_EvalMetrics, _Base):
         self.sigma_min, self.sigma_max = 0.002, 80
         self.sparams = hparams.sampler if hparams.get("sampler", None) is not None else self.get_edm_sampler_params()
         self.test_sparams = self.sparams
-        self.h_ch, self.u_ch = m.cond_channels, m.out_ch
+        # a default until the first batch sets the widths (the reference has none: models/ddim.py:1120-1121 are its first
+        # assignments); the node_type channel added above is not part of the known state
+        self.h_ch, self.u_ch = m.cond_channels - (1 if self.node_type else 0), m.out_ch
         self._train_ws, self._sample_ws, self._grad_buf = _lib.Workspace(), _lib.Workspace(), None
         self._train_generation = 0
         self._graphs = {}

@@ -31,7 +31,10 @@ EXPORTS = [
     "mcedm_repaint_sample_rng", "mcedm_normal_fill", "mcedm_ddpm_forward_sc", "mcedm_ddim_workspace_bytes",
     "mcedm_ddim_repaint_sample", "mcedm_ddim_timesteps",
     "mcedm_unet_forward_dx", "mcedm_edm_denoise_dx", "mcedm_edm_denoise_backward_dx", "mcedm_heun_sample_dxcond",
+    "mcedm_unet_plan_set_variant", "mcedm_ddpm_plan_set_variant", "mcedm_heun_sample_rng",
 ]
+# kernel families that exist in two forms (include/mcedm_hip.h MCEDM_VARIANT_*)
+VARIANTS = {"conv_wino": 0, "conv_wino1": 1, "conv_resident": 2, "conv8": 3, "attn_fused": 4, "wgrad_wino": 5}
 
 
 class UNetDesc(C.Structure):
@@ -43,7 +46,7 @@ class UNetDesc(C.Structure):
 
 
 DX_NONE, DX_CAT, DX_ENC = 0, 1, 2      # MCEDM_DX_* (include/mcedm_hip.h)
-ABI_VERSION = 3                        # MCEDM_ABI_VERSION
+ABI_VERSION = 4                        # MCEDM_ABI_VERSION
 REDUCE_SCRATCH_BYTES = 4096 * 8 + 64   # MCEDM_REDUCE_SCRATCH_BYTES
 
 
@@ -262,6 +265,13 @@ class Plan:
         if h:
             self._lib.mcedm_unet_plan_destroy(h)
 
+    def set_variant(self, which: str, value: int = -1) -> None:
+        """This plan's own choice for one kernel family (``VARIANTS``): 1 / 0, -1 = the process default (mcedm_op_set_* or the
+        environment).  In force whenever one of THIS plan's entry points runs; other plans are not affected.  'conv_wino'
+        also shapes the workspace layout: set it before the plan's first use."""
+        self._lib.mcedm_unet_plan_set_variant.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        check(self._lib.mcedm_unet_plan_set_variant(self._h, VARIANTS[which], int(value)), "plan_set_variant")
+
     # ---- derived weights ---------------------------------------------------------------
     def pack(self, params: Dict[str, torch.Tensor], packed: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Pack the named fp32 device parameters (keys = DhariwalUNet.state_dict() names)."""
@@ -367,8 +377,11 @@ class Plan:
 
     def sample(self, packed, sd: SamplerDesc, cond, mask, init_noise, step_noise=None, return_last: bool = True,
                ws: Optional[Workspace] = None, out: Optional[torch.Tensor] = None,
-               guidance: Optional["GuidanceDesc"] = None, dx_input: Optional["GuidanceDesc"] = None) -> torch.Tensor:
-        """dx_input: the residual whose gradient at the current state is the network's dx input (dx_cond plans)."""
+               guidance: Optional["GuidanceDesc"] = None, dx_input: Optional["GuidanceDesc"] = None,
+               rng_seed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dx_input: the residual whose gradient at the current state is the network's dx input (dx_cond plans).
+        rng_seed: a one-element int64 DEVICE tensor -- the churn noise of every step is then generated inside the kernel that
+        applies it (mcedm_heun_sample_rng) instead of being read from step_noise [N, B, C, H, W] float64."""
         B, _, H, W = init_noise.shape
         ws = ws or Workspace()
         buf = ws.get(self.sampler_workspace_bytes(B, H, W), init_noise.device)
@@ -391,6 +404,16 @@ class Plan:
                                                      _ptr(mask), _ptr(init_noise), _ptr(step_noise, torch.float64),
                                                      _ptr(out, torch.float64), int(return_last), buf.data_ptr(), buf.numel(),
                                                      B, H, W, _stream()), "heun_sample_guided")
+            return out
+        if rng_seed is not None:
+            if step_noise is not None:
+                raise RuntimeError("sample: give step_noise (materialised draws) or rng_seed (device-side draws), not both")
+            if rng_seed.dtype != torch.int64 or rng_seed.numel() != 1 or rng_seed.device != init_noise.device:
+                raise RuntimeError("sample: rng_seed must be a one-element int64 tensor on the sampler's device")
+            check(self._lib.mcedm_heun_sample_rng(self._h, packed.data_ptr(), C.byref(sd), _ptr(cond), _ptr(mask),
+                                                  _ptr(init_noise), rng_seed.data_ptr(), _ptr(out, torch.float64),
+                                                  int(return_last), buf.data_ptr(), buf.numel(), B, H, W, _stream()),
+                  "heun_sample_rng")
             return out
         check(self._lib.mcedm_heun_sample(self._h, packed.data_ptr(), C.byref(sd), _ptr(cond), _ptr(mask),
                                           _ptr(init_noise), _ptr(step_noise, torch.float64), _ptr(out, torch.float64),
@@ -478,6 +501,11 @@ class DdpmPlan:
         h, self._h = getattr(self, "_h", None), None
         if h:
             self._lib.mcedm_ddpm_plan_destroy(h)
+
+    def set_variant(self, which: str, value: int = -1) -> None:
+        """As ``Plan.set_variant``: this plan's own kernel choice, -1 = the process default."""
+        self._lib.mcedm_ddpm_plan_set_variant.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        check(self._lib.mcedm_ddpm_plan_set_variant(self._h, VARIANTS[which], int(value)), "ddpm_plan_set_variant")
 
     def pack(self, params: Dict[str, torch.Tensor], temb_freqs: torch.Tensor, packed: Optional[torch.Tensor] = None):
         """params keyed like Model.state_dict(); temb_freqs [ch/2] device fp32, built by the caller exactly as
@@ -635,15 +663,19 @@ class GraphedSampler:
 
     def __init__(self, plan: "Plan", packed: torch.Tensor, sd: SamplerDesc, B: int, H: int, W: int, masked: bool = True,
                  has_cond: bool = True, churn: bool = False, return_last: bool = True, ws: Optional[Workspace] = None,
-                 guidance: Optional["GuidanceDesc"] = None, dx_input: Optional["GuidanceDesc"] = None):
+                 guidance: Optional["GuidanceDesc"] = None, dx_input: Optional["GuidanceDesc"] = None, device_noise: bool = False):
+        """churn with device_noise: the per-step draws are generated inside the sampler's kernels from ``self.seed`` (an int64
+        device scalar the call rewrites before each replay) -- no [N, B, C, H, W] float64 buffer, fresh noise per replay."""
         dev = packed.device
         self.plan, self.packed, self.sd, self.return_last = plan, packed, sd, return_last
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev) if (churn and device_noise) else None
         self.guidance, self.dx_input = guidance, dx_input      # host-side descriptions, baked into the captured kernel arguments
         C = plan.in_channels
         self.cond = torch.zeros((B, plan.cond_channels, H, W), device=dev) if has_cond else None
         self.mask = torch.zeros((B, C, H, W), device=dev) if masked else None
         self.init = torch.zeros((B, C, H, W), device=dev)
-        self.step_noise = torch.zeros((sd.timesteps, B, C, H, W), dtype=torch.float64, device=dev) if churn else None
+        self.step_noise = (torch.zeros((sd.timesteps, B, C, H, W), dtype=torch.float64, device=dev)
+                           if churn and not device_noise else None)
         T = 1 if return_last else sd.timesteps + 1
         self.out = torch.empty((B, T, H, W, C), dtype=torch.float64, device=dev)
         self.ws = _PinnedWorkspace(ws, plan.sampler_workspace_bytes(B, H, W), dev)
@@ -651,10 +683,18 @@ class GraphedSampler:
 
     def _run(self):
         self.plan.sample(self.packed, self.sd, self.cond, self.mask, self.init, self.step_noise, self.return_last, self.ws,
-                         out=self.out, guidance=self.guidance, dx_input=self.dx_input)
+                         out=self.out, guidance=self.guidance, dx_input=self.dx_input, rng_seed=self.seed)
 
-    def __call__(self, cond, mask, init_noise, step_noise=None) -> torch.Tensor:
-        """Returns the instance's static output tensor (overwritten by the next call)."""
+    def __call__(self, cond, mask, init_noise, step_noise=None, seed=None) -> torch.Tensor:
+        """Returns the instance's static output tensor (overwritten by the next call).  seed (device-noise instances): python
+        int or int64 tensor, the key of this call's churn draws."""
+        if (self.seed is None) != (seed is None):
+            raise RuntimeError("GraphedSampler: 'seed' goes with device_noise=True instances (and only with them)")
+        if seed is not None:
+            if torch.is_tensor(seed):
+                self.seed.copy_(seed.reshape(1))
+            else:
+                self.seed.fill_(int(seed))
         for dst, src, name in ((self.cond, cond, "cond"), (self.mask, mask, "mask"), (self.init, init_noise, "init_noise"),
                                (self.step_noise, step_noise, "step_noise")):
             if (dst is None) != (src is None):

@@ -41,6 +41,20 @@ except Exception:  # pragma: no cover - exercised where Lightning is absent
         def log(self, *a, **k):
             pass
 
+        # Lightning's defaults for the two hooks the drop-in overrides (pytorch_lightning/core/module.py): the optimiser step runs
+        # the closure (zero_grad + training_step + backward), gradient clipping is clip_grad_norm_ on the optimiser's parameters
+        def optimizer_step(self, epoch=None, batch_idx=None, optimizer=None, optimizer_idx=0, optimizer_closure=None, *a, **k):
+            optimizer.step(closure=optimizer_closure)
+
+        def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
+            if gradient_clip_val is None or gradient_clip_val <= 0:
+                return
+            params = [p for g in optimizer.param_groups for p in g["params"]]
+            if gradient_clip_algorithm in (None, "norm"):
+                torch.nn.utils.clip_grad_norm_(params, gradient_clip_val)
+            else:
+                torch.nn.utils.clip_grad_value_(params, gradient_clip_val)
+
 
 class DotDict(dict):
     __getattr__ = dict.__getitem__
@@ -168,6 +182,11 @@ class PlMcedm(_Base):
         self._grad_buf = None
         self._train_generation = 0
         self._graphs = {}
+        # where the sampler's per-step churn noise (models/mcedm.py:608) comes from: "device" = generated inside the kernel that
+        # applies it (mcedm_heun_sample_rng; keyed by a seed drawn from torch's CPU generator, so seed_everything still pins a
+        # run), "torch" = torch.randn((N, B, 2, H, W), float64) materialised up front (2.1 GB at the reference's shipped
+        # 50-step / n_samples 5 config and 32 inputs; what the golden vectors inject)
+        self.noise_source = os.environ.get("MCEDM_NOISE_SOURCE", "device")
 
     # ---- configuration hooks (same names as the reference) ------------------------------------------
     @staticmethod
@@ -197,7 +216,19 @@ class PlMcedm(_Base):
                 self.normalizer_target.set_stats(st["target_mean"], st["target_std"])
 
     def configure_optimizers(self):
+        """models/mcedm.py:139-161.  ``optimizer: Adam`` on the device returns ``optim.FusedAdamEma`` -- a torch.optim.Optimizer
+        over flat buffers whose ``step()`` is the fused clip + Adam + EMA kernels (K11), state_dict in torch.optim.Adam form;
+        ``MCEDM_FUSED_OPT=0`` (or amsgrad, or a module still on the CPU) keeps plain ``torch.optim.Adam``."""
+        self._fused_opt = None
         if self.optimizer == "Adam":
+            p0 = next(self.model.parameters())
+            if os.environ.get("MCEDM_FUSED_OPT", "1") != "0" and p0.is_cuda and not self.amsgrad:
+                from .optim import FusedAdamEma
+                ema = self.ema_model.ma_model if self.ema_model is not None else None
+                opt = FusedAdamEma(self.model, ema, lr=self.lr, betas=(self.beta1, 0.999), eps=self.eps,
+                                   weight_decay=self.weight_decay, ema_beta=self.ema_model.beta if ema is not None else 0.999)
+                self._fused_opt = opt
+                return {"optimizer": opt}
             opt = torch.optim.Adam(self.model.parameters(), lr=self.lr, weight_decay=self.weight_decay,
                                    betas=(self.beta1, 0.999), amsgrad=self.amsgrad, eps=self.eps)
         elif self.optimizer == "RMSProp":
@@ -209,9 +240,31 @@ class PlMcedm(_Base):
         return {"optimizer": opt}
 
     def optimizer_step(self, *args, **kwargs):
+        """models/mcedm.py:163-168: Lightning's step, then EmaModel.update -- which the fused optimiser's kernel has already done."""
         super().optimizer_step(*args, **kwargs)
-        if self.ema_model is not None:
+        if self.ema_model is not None and getattr(self, "_fused_opt", None) is None:
             self.ema_model.update(self.model)
+
+    def configure_gradient_clipping(self, optimizer, *args, **kwargs):
+        """Lightning calls this between backward and the optimiser's update (configs/trainer/trainer_ddim.yaml:8-9:
+        gradient_clip_val 1.0, norm).  With the fused optimiser the clip is not a pass of its own: the value is handed to the
+        optimiser, whose kernel scales the gradient by min(1, max_norm / (|g| + 1e-6)) like clip_grad_norm_.  Accepts the hook's
+        signatures of pytorch_lightning 1.x (optimizer, optimizer_idx, gradient_clip_val, gradient_clip_algorithm) and 2.x."""
+        val, algo = kwargs.get("gradient_clip_val"), kwargs.get("gradient_clip_algorithm")
+        pos = list(args)
+        if len(pos) == 3:
+            pos = pos[1:]                                   # 1.x: optimizer_idx first
+        if pos and val is None:
+            val = pos[0]
+        if len(pos) > 1 and algo is None:
+            algo = pos[1]
+        algo = getattr(algo, "value", algo)                 # GradClipAlgorithmType enum -> "norm" / "value"
+        raw = getattr(optimizer, "_optimizer", optimizer)   # LightningOptimizer wrapper
+        fused = getattr(self, "_fused_opt", None)
+        if fused is not None and raw is fused and algo in (None, "norm"):
+            fused.max_norm = float(val) if val is not None and val > 0 else None
+            return
+        self.clip_gradients(optimizer, gradient_clip_val=val, gradient_clip_algorithm=algo)
 
     # ---- data transforms (host-side elementwise, mcedm.py:170-197) --------------------------------------
     def data_transform(self, h, u):
@@ -335,23 +388,32 @@ class PlMcedm(_Base):
         N = sd.timesteps
         t = _lib.edm_t_steps(sd)
         churn = any((min(sd.S_churn / N, math.sqrt(2) - 1) if sd.S_min <= t[i] <= sd.S_max else 0) > 0 for i in range(N))
-        step_noise = torch.randn((N,) + tuple(hu.shape), dtype=torch.float64, device=hu.device) if churn else None
+        if self.noise_source not in ("device", "torch"):
+            raise RuntimeError(f"noise_source must be 'device' or 'torch', not {self.noise_source!r}")
+        dev_noise = churn and self.noise_source == "device"
+        step_noise = (torch.randn((N,) + tuple(hu.shape), dtype=torch.float64, device=hu.device)
+                      if churn and not dev_noise else None)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dev_noise else None        # CPU generator: no device sync
         cond, hu_mask, hu_noise = cond.float().contiguous(), hu_mask.float().contiguous(), hu_noise.contiguous()
         with torch.no_grad():
             packed = net.packed_weights()
-            eager = lambda c, m_, i, sn: net.plan.sample(packed, sd, c, m_, i, sn, return_last=return_last, ws=self._sample_ws)
+
+            def eager(c, m_, i, sn, seed=None):
+                rs = torch.tensor([seed], dtype=torch.int64, device=i.device) if seed is not None else None
+                return net.plan.sample(packed, sd, c, m_, i, sn, return_last=return_last, ws=self._sample_ws, rng_seed=rs)
+            kw = dict(seed=seed) if dev_noise else {}
             if os.environ.get("MCEDM_HIP_GRAPH", "1") == "0":
-                return eager(cond, hu_mask, hu_noise, step_noise)
+                return eager(cond, hu_mask, hu_noise, step_noise, **kw)
             # the ~4000 launches of one sampling call replayed from one HIP graph (lib.GraphedSampler); at most two
             # instances are kept per module (the evaluation loops repeat one call; a ragged last batch is the second),
             # they borrow this module's sampler workspace, and a failed capture falls back to the eager call
             B, _, H, W = hu_noise.shape
-            key = (B, H, W, bool(return_last), churn, packed.data_ptr(), hu_noise.device.index,
+            key = (B, H, W, bool(return_last), churn, dev_noise, packed.data_ptr(), hu_noise.device.index,
                    tuple(getattr(sd, f) for f, _ in sd._fields_))
             fn = _lib.graphed_or_eager(self._graphs, key, lambda: _lib.GraphedSampler(
                 net.plan, packed, sd, B, H, W, masked=True, has_cond=True, churn=churn, return_last=return_last,
-                ws=self._sample_ws), eager)
-            out = fn(cond, hu_mask, hu_noise, step_noise)
+                ws=self._sample_ws, device_noise=dev_noise), eager)
+            out = fn(cond, hu_mask, hu_noise, step_noise, **kw)
             return out.clone() if fn is not eager else out
 
     # ---- evaluation loops (host-side bookkeeping, mcedm.py:283-441) ----------------------------------------

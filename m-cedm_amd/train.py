@@ -37,6 +37,44 @@ def shard_range(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def sample_edm_sharded(module, hu, cond, hu_mask, sparams, return_last=True, guide_dx=False, gather=True, group=None):
+    """``module.sample_edm`` with the ``(n_samples * B)`` axis split over the ranks (BASELINE config 4 is
+    ``n_samples = 16`` on 8 GPUs): rank r samples the contiguous items ``shard_range(n, r, world)`` -- batch items are
+    independent and the sigma schedule is shared, so there is no collective inside the loop -- and, with ``gather=True``, one
+    ``all_gather`` of the final ``[b, t, h, w, c]`` float64 states puts them back in the caller's order, i.e. the reference's
+    ``(n b)`` layout that ``test_step`` reshapes to ``n b ...`` (models/mcedm.py:356-385).  Shards of unequal size (n not a
+    multiple of the world size) are padded for the exchange; a rank without items contributes nothing.  With world size 1, or
+    ``gather=False`` (the rank keeps its own shard), no communication happens.  Every rank must call it with the same n.
+
+    The noise the sampler draws (``torch.randn_like`` inside ``sample_edm``) comes from each rank's own generator, like every DDP
+    rank of the reference; a sample's bits do not depend on the batch it is computed in (tests/test_hip_fullsize.py), so with the
+    same noise the gathered tensor equals the unsharded call bit for bit (tests/test_parallel_cpu.py, tests/test_hip_multirank.py)."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    n = hu.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    own = None
+    if hi > lo:
+        own = module.sample_edm(hu[lo:hi], cond[lo:hi], hu_mask[lo:hi], sparams, return_last=return_last, guide_dx=guide_dx)
+    if world == 1 or not gather:
+        return own
+    # shape of one item's trajectory: from this rank's own result, else from a rank that has one (n < world leaves ranks empty)
+    meta = torch.tensor(list(own.shape[1:]) if own is not None else [0, 0, 0, 0], dtype=torch.int64, device=hu.device)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    item = next((tuple(int(v) for v in m.tolist()) for m in metas if int(m.sum()) > 0), None)
+    if item is None:
+        raise RuntimeError("sample_edm_sharded: no rank has an item to sample (n = 0)")
+    sizes = [shard_range(n, r, world) for r in range(world)]
+    pad = max(b - a for a, b in sizes)
+    send = torch.zeros((pad,) + item, dtype=torch.float64, device=hu.device)
+    if own is not None:
+        send[:hi - lo] = own.to(torch.float64)
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    return torch.cat([p[:b - a] for p, (a, b) in zip(parts, sizes)], dim=0)
+
+
 def _world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The golden vectors inject the sampler's per-step churn noise as torch tensors (monkey-patched torch.randn): the drop-in modules
+# built by the tests therefore materialise it the reference's way.  The product default -- draws generated inside the sampler's
+# kernels (PlMcedm.noise_source = "device", mcedm_heun_sample_rng) -- has its own tests, which set the attribute explicitly.
+os.environ.setdefault("MCEDM_NOISE_SOURCE", "torch")
 
 
 def pytest_configure(config):

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     exported = sorted(set(re.findall(r"\bT (mcedm_[a-z0-9_]+)$", nm, flags=re.M)))
     assert exported == names, (set(exported) ^ set(names))
     assert sorted(set(L.EXPORTS + L.OP_EXPORTS)) == names, set(L.EXPORTS + L.OP_EXPORTS) ^ set(names)
-    assert lib.mcedm_version() == 3
+    assert lib.mcedm_version() == 4
 
 
 def test_plan_parameter_table_matches_state_dict_order():
@@ -179,3 +179,23 @@ def test_bench_roofline_helpers():
     assert [r["name"] for r in rows] == ["gn_bwd_kernel"] and abs(rows[0]["hbm_frac"] - round(1.2e10 / 5.5e-3 / 1e9, 1) / 8000.0) < 1e-3
     ro = bench.roofline_of(prof)
     assert ro["kernel"].startswith("conv_wino") and abs(ro["executed_over_algorithmic"] - 4 / 9) < 1e-12 and ro["frac"] < ro["direct_equivalent_frac"]
+
+
+def test_plan_variants_are_per_plan_and_validated():
+    """mcedm_unet_plan_set_variant (ABI 4): a field of the plan, validated on the host.  With the Winograd kernels switched off a
+    decoder block's 1x1 skip projection is folded into conv1 again, so that plan's workspace layout differs from its sibling's --
+    visible without a GPU."""
+    cfg = orc.UNetConfig(ch=128, ch_mult=(1, 1, 1, 1), attn_resolutions=(16,))
+    mk = lambda: L.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks,
+                        cfg.attn_resolutions, cfg.resolution)
+    pa, pb = mk(), mk()
+    base = pb.workspace_bytes(2, 64, 64)
+    assert pa.workspace_bytes(2, 64, 64) == base
+    pa.set_variant("conv_wino", 0)
+    assert pa.workspace_bytes(2, 64, 64) != base and pb.workspace_bytes(2, 64, 64) == base
+    pa.set_variant("conv_wino", -1)
+    assert pa.workspace_bytes(2, 64, 64) == base
+    lib = L.load()
+    lib.mcedm_unet_plan_set_variant.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    assert lib.mcedm_unet_plan_set_variant(pa._h, 99, 1) != 0 and b"unknown switch" in lib.mcedm_last_error()
+    assert lib.mcedm_unet_plan_set_variant(pa._h, 0, 7) != 0

@@ -126,7 +126,7 @@ def test_cond_edm_node_type_channel_golden(golden, monkeypatch):
     st = fx.TRAIN_NORM_STATS
     m.normalizer_input.set_stats(torch.tensor(st[0]), torch.tensor(st[1]))
     m.normalizer_target.set_stats(torch.tensor(st[2]), torch.tensor(st[3]))
-    m.h_ch = m.u_ch = 1
+    assert (m.h_ch, m.u_ch) == (1, 1)         # the constructor's default does not count the node_type channel
     hn4 = ((h - st[0]) / st[1]).cuda()
     close(m.get_cond_in(hn4, ((u - st[2]) / st[3]).cuda(), None, None), g["node::cond_in"], rtol=0, atol=0)
     monkeypatch.setattr(torch, "randn_like", lambda t, **k: noise.cuda())

@@ -77,3 +77,70 @@ def test_two_ranks_on_one_card_equal_the_full_batch_step():
     torch.testing.assert_close(r0["p"], full.flat_p.cpu(), rtol=1e-4, atol=1e-6 * scale)
     torch.testing.assert_close(r0["ema"], full.flat_ema.cpu(), rtol=1e-4, atol=1e-6 * scale)
     torch.testing.assert_close(r0["m"], full.flat_m.cpu(), rtol=1e-3, atol=1e-6 * float(full.flat_m.abs().max()))
+
+
+def _module():
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd.mcedm import PlMcedm
+    from tests.test_hip_module import hparams
+    m = PlMcedm(hparams(fx.CFG_P)).cuda()
+    P = orc.make_params(fx.CFG_P, 7)
+    with torch.no_grad():
+        for n, p in m.model.named_parameters():
+            p.copy_(P[n])
+        for n, p in m.ema_model.ma_model.named_parameters():
+            p.copy_(P[n])
+    return m
+
+
+def _sampling_inputs(n):
+    cond, mask, init, _ = fx.sampler_inputs("det_u", n, 32, 32)
+    return cond.cuda(), mask.cuda(), init.float().cuda()
+
+
+def _sample_worker(rank, world, port, out, n):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mcedm_amd.train import sample_edm_sharded, shard_range
+    m = _module()
+    cond, mask, init = _sampling_inputs(n)
+    lo, hi = shard_range(n, rank, world)
+    # the sampler's own draw (torch.randn_like(hu), models/mcedm.py:576) replaced by this rank's slice of ONE fixed noise tensor, so
+    # that the sharded and the unsharded call integrate the same initial states
+    real = torch.randn_like
+    torch.randn_like = lambda t, **k: init[lo:hi].to(k.get("dtype", t.dtype))
+    try:
+        xs = sample_edm_sharded(m, torch.zeros_like(cond[:, :2]), cond, mask, m.sparams, return_last=True)
+    finally:
+        torch.randn_like = real
+    torch.save(xs.cpu(), f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_sampling_on_two_ranks_equals_the_unsharded_call_bit_for_bit():
+    """SURVEY.md 8e, models/mcedm.py:356-385: PlMcedm.sample_edm with the batch axis split over two ranks (both on cuda:0, gloo) and
+    one all_gather of the final float64 states: every rank ends up with the unsharded call's tensor, bit for bit and in its order
+    (3 = 2 + 1 items: ragged shards)."""
+    import socket
+    n = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "s")
+        mp.spawn(_sample_worker, args=(2, port, out, n), nprocs=2, join=True)
+        r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    m = _module()
+    cond, mask, init = _sampling_inputs(n)
+    real = torch.randn_like
+    torch.randn_like = lambda t, **k: init.to(k.get("dtype", t.dtype))
+    try:
+        full = m.sample_edm(torch.zeros_like(cond[:, :2]), cond, mask, m.sparams, return_last=True).cpu()
+    finally:
+        torch.randn_like = real
+    assert full.dtype == torch.float64 and tuple(full.shape) == (n, 1, 32, 32, 2)
+    assert torch.equal(r0, r1), "the ranks disagree on the gathered tensor"
+    assert torch.equal(r0, full), f"sharded + gathered differs from the unsharded call: max |d| {float((r0 - full).abs().max()):.3e}"

@@ -155,3 +155,62 @@ def test_fused_trainer_optimizer_state_round_trips_through_torch_adam():
     bad["state"][3]["step"] = torch.tensor(5.0)
     with pytest.raises(RuntimeError, match="disagree on the step"):
         t2.load_optimizer_state_dict(bad)
+
+
+class _ItemwiseSampler:
+    """Stand-in for a module's sample_edm on the CPU: a deterministic per-item map of (cond, mask) with the reference's return
+    layout 'b t h w c' float64 (models/mcedm.py:636-638).  What the test pins is the sharding and the gather order, not the sampler
+    (whose batch-invariance on the device is tests/test_hip_fullsize.py's subject)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def sample_edm(self, hu, cond, hu_mask, sparams, return_last=True, guide_dx=False):
+        self.calls.append(tuple(hu.shape))
+        x = (cond[:, :2].double() * (1 - hu_mask.double()) + torch.sin(3.0 * cond[:, :2].double()) * hu_mask.double())
+        xs = x.permute(0, 2, 3, 1).unsqueeze(1)                           # b 1 h w c
+        return xs if return_last else torch.cat([xs * 0.5, xs], dim=1)
+
+
+def _shard_worker(rank, world, port, out, n, return_last):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd.train import sample_edm_sharded, shard_range
+    g = torch.Generator().manual_seed(11)
+    cond = torch.randn(n, 2, 6, 4, generator=g)
+    mask = (torch.rand(n, 2, 6, 4, generator=g) > 0.5).float()
+    hu = torch.zeros(n, 2, 6, 4)
+    mod = _ItemwiseSampler()
+    got = sample_edm_sharded(mod, hu, cond, mask, None, return_last=return_last)
+    own = sample_edm_sharded(mod, hu, cond, mask, None, return_last=return_last, gather=False)
+    lo, hi = shard_range(n, rank, world)
+    ref = _ItemwiseSampler().sample_edm(hu, cond, mask, None, return_last=return_last)
+    ok = torch.equal(got, ref) and got.dtype == torch.float64
+    ok_own = (own is None and hi == lo) or (own is not None and torch.equal(own, ref[lo:hi]))
+    out.put((rank, ok, ok_own, mod.calls, (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,return_last", [(6, True), (5, False), (1, True)])
+def test_sharded_sampling_gathers_in_the_callers_order(n, return_last):
+    """SURVEY.md 8e / models/mcedm.py:356-385: the (n_samples * B) axis split over two ranks and gathered back must equal the
+    unsharded call bit for bit, in the '(n b)' order test_step reshapes -- even shards (6), ragged ones (5 = 3 + 2) and a rank
+    without any item (1 = 1 + 0)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 31500 + (os.getpid() + 7 * n) % 2000
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, out, n, return_last)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(out.get(timeout=5) for _ in range(2))
+    for rank, ok, ok_own, calls, (lo, hi) in res:
+        assert ok, f"rank {rank}: gathered states differ from the unsharded call"
+        assert ok_own, f"rank {rank}: gather=False must return the rank's own shard"
+        assert all(c[0] == hi - lo for c in calls) and (len(calls) == (2 if hi > lo else 0)), (rank, calls, lo, hi)
+    assert res[0][4][0] == 0 and res[0][4][1] == res[1][4][0] and res[1][4][1] == n
