@@ -116,6 +116,10 @@ def load() -> C.CDLL:
     lib.mcedm_sampler_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(sz)]
     lib.mcedm_heun_sample.argtypes = [vp, vp, C.POINTER(SamplerDesc), f32p, f32p, f32p, f64p, f64p, i32, vp, sz,
                                       i32, i32, i32, vp]
+    lib.mcedm_heun_sample_rng.argtypes = [vp, vp, C.POINTER(SamplerDesc), f32p, f32p, f32p, vp, f64p, i32, vp, sz,
+                                          i32, i32, i32, vp]
+    lib.mcedm_unet_plan_set_variant.argtypes = [vp, i32, i32]
+    lib.mcedm_ddpm_plan_set_variant.argtypes = [vp, i32, i32]
     lib.mcedm_edm_t_steps.argtypes = [C.POINTER(SamplerDesc), C.POINTER(C.c_double)]
     lib.mcedm_edm_loss.argtypes = [f32p, f32p, f32p, f32p, i32, i32, i32, i32, C.c_double, f32p, f32p, vp, sz, vp]
     lib.mcedm_edm_noise_inputs.argtypes = [f32p, f32p, f32p, f32p, i32, i32, i32, i32, C.c_double, C.c_double, f32p,

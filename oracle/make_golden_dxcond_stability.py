@@ -10,8 +10,11 @@ the reference AGAINST ITSELF (build container only):
   * with one input perturbed by one unit in the last place: the conditioning field h, the initial noise, one conv weight.
 
 For every variant it counts the entries of the FINAL state that differ from the unperturbed 8-thread run by more than the
-bar the GPU test uses (1e-5 * max|trajectory| + 1e-4 |ref|), and the first sampled trajectory index (0, 6, 12, 18) at which
-any entry does.  Written to tests/golden/dxcond_stability.npz; the GPU test takes its allowance from these numbers.
+bar the GPU test uses, and the first sampled trajectory index (0, 6, 12, 18) at which any entry does -- twice: against the
+round-4 bar (1e-5 * max|trajectory| + 1e-4 |ref|; keys `final_bad_frac`, `first_bad_step`) and against the round-5 bar that
+holds every sampled step to ITS OWN magnitude (1e-5 * max|that step's state| + 1e-4 |ref|; keys `*_own`; the final state
+is ~60x smaller than the sigma = 80 initial one).  Written to tests/golden/dxcond_stability.npz; the GPU test takes its
+allowance from the `_own` numbers.
 
     cd oracle && PYTHONPATH=/root/repo python make_golden_dxcond_stability.py
 """
@@ -64,12 +67,16 @@ def main():
             P2[name] = ulp(P[name])
             variants["weight_ulp"] = run(cfg, P2, system, st, h, u_noise, steps)
             key = f"{mode}_{system}"
-            fracs, firsts = [], []
+            fracs, firsts, fracs_own, firsts_own = [], [], [], []
             for vname, xs in variants.items():
                 bad = (xs - base).abs() > 1e-5 * scale + 1e-4 * base.abs()
                 frac = float(bad[:, -1].double().mean())
                 per = [bool(bad[:, i].any()) for i in (0, 6, 12, 18)]
                 first = ([i for i, b in zip((0, 6, 12, 18), per) if b] + [-1])[0]
+                own = [(xs[:, i] - base[:, i]).abs() > 1e-5 * float(base[:, i].abs().max()) + 1e-4 * base[:, i].abs() for i in (0, 6, 12, 18)]
+                fracs_own.append(float(own[-1].double().mean()))
+                firsts_own.append(([i for i, b in zip((0, 6, 12, 18), own) if bool(b.any())] + [-1])[0])
+                print(f"      per-step bar: {fracs_own[-1] * 100:6.3f} % of the final state outside; first sampled step outside: {firsts_own[-1]}")
                 rel = float(((xs[:, -1] - base[:, -1]).abs().max()) / scale)
                 print(f"  reference vs itself, {key:14s} {vname:11s}: {frac * 100:6.3f} % of the final state outside the bar "
                       f"(max |d| / max|x| = {rel:.2e}); first sampled step outside: {first}")
@@ -78,6 +85,8 @@ def main():
             out[f"{key}::variants"] = np.array(list(variants))
             out[f"{key}::final_bad_frac"] = np.array(fracs)
             out[f"{key}::first_bad_step"] = np.array(firsts)
+            out[f"{key}::final_bad_frac_own"] = np.array(fracs_own)
+            out[f"{key}::first_bad_step_own"] = np.array(firsts_own)
     mg.save("dxcond_stability.npz", **out)
 
 

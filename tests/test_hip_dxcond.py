@@ -12,6 +12,8 @@ from oracle import fixtures as fx
 from oracle import mcedm_oracle as orc
 from tests.test_hip_cond_edm import cond_hparams
 
+from tests._tol import close_per_entry
+
 pytestmark = pytest.mark.gpu
 MODES = ("cat", "enc")
 
@@ -103,22 +105,28 @@ def test_sample_edm_dx_cond_golden(golden, mode, system, guided):
         # step 6) and in none of the cat case.  The device is held to that: the cat case at the bar throughout; the enc case at
         # the bar through step 6 and, in the final state, at most 4x the reference's own worst self-disagreement outside it
         # (the device differs from the reference in the summation order of every convolution, not of one).
+        # Round 5: every sampled step is held to ITS OWN magnitude (atol 1e-5 x max|that state|, 60x tighter on the final state
+        # than the trajectory-wide atol was), and the fixture measures the reference against itself at that bar (`_own` keys):
+        # 25.6-28.3 % of the enc case's final state there, still never by step 6, none of the cat case.  The allowance is
+        # 1.5x the reference's own worst.
         stab = golden("dxcond_stability.npz")
-        ref_self = float(stab[f"{mode}_darcy::final_bad_frac"].max())
-        assert int(stab[f"{mode}_darcy::first_bad_step"][stab[f"{mode}_darcy::first_bad_step"] >= 0].min(initial=99)) > 6
-        close(xs[:, 0:7:6], traj[:, :2], rtol=1e-4, atol=1e-5 * scale)
-        bad = (xs[:, -1:].cpu() - ref).abs() > 1e-5 * scale + 1e-4 * ref.abs()
+        ref_self = float(stab[f"{mode}_darcy::final_bad_frac_own"].max())
+        first_own = stab[f"{mode}_darcy::first_bad_step_own"]
+        assert int(first_own[first_own >= 0].min(initial=99)) > 6
+        close_per_entry(xs[:, 0:7:6], traj[:, :2], what=f"{key} steps 0 / 6")
+        bad = (xs[:, -1:].cpu() - ref).abs() > 1e-5 * float(ref.abs().max()) + 1e-4 * ref.abs()
         frac = float(bad.double().mean())
         print(f"   entries of the final state outside the bar: {frac * 100:.3f} % (reference vs itself: up to {ref_self * 100:.3f} %)")
         assert bool(torch.isfinite(xs).all())
         if ref_self == 0.0:
-            close(xs[:, -1:], ref, rtol=1e-4, atol=1e-5 * scale)
-            close(xs[:, ::6], traj, rtol=1e-4, atol=1e-5 * scale)
+            close_per_entry(xs[:, -1:], ref, what=f"{key} final state")
+            close_per_entry(xs[:, ::6], traj, what=f"{key} trajectory")
         else:
-            assert frac <= 4.0 * ref_self, (frac, ref_self)
+            assert frac <= 1.5 * ref_self, (frac, ref_self)
         return
-    close(xs[:, -1:], ref, rtol=1e-4, atol=1e-5 * scale)
-    close(xs[:, ::6], traj, rtol=1e-4, atol=1e-5 * scale)
+    # every sampled step against ITS OWN magnitude (the final state is ~100x smaller than the sigma = 80 initial one)
+    close_per_entry(xs[:, -1:], ref, what=f"{key} final state")
+    close_per_entry(xs[:, ::6], traj, what=f"{key} trajectory")
 
 
 @pytest.mark.parametrize("mode", MODES)
