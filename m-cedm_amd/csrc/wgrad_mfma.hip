@@ -12,6 +12,8 @@
 // wave-instruction) and wgrad_reduce_kernel adds the slices in split order in fp64 and writes the reference
 // [co][ci][kh][kw] layout, so the gradients (and with them a training run) are bitwise reproducible.  The block with
 // ci-tile 0 also sums its dY tiles over pixels: that is the bias gradient, reduced the same way.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "prof.hpp"
 #include "bwd.hpp"
@@ -32,6 +34,14 @@ struct WgCfg {
   static constexpr int SUB = (PLANE + 255) / 256;
   static_assert(NPIX == 64, "64-pixel tiles");
 };
+
+bool wgrad_thin_applicable(const WgradArgs& a, int taps, int qkv_heads);
+int launch_wgrad_thin(const WgradArgs& a, float* dw, float* db, hipStream_t s);
+static bool wgrad_thin_enabled() {                       // MCEDM_WGRAD_THIN=0: the MFMA block kernel for these shapes too (A/B runs)
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_WGRAD_THIN"); env = e ? atoi(e) : 1; }
+  return env != 0;
+}
 
 __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -406,6 +416,7 @@ int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_hea
   // an un-transformed single-source input (the attention projection's) IS the operand: no copy -- except for the Winograd
   // kernel, which reads the 4 bytes in front of its operand (and discards them): it only ever sees act_tmp, a scratch region
   // that is never the start of an allocation
+  if (!have_act && wgrad_thin_applicable(a, taps, qkv_heads) && wgrad_thin_enabled()) return launch_wgrad_thin(a, dw, db, s);
   const bool wino = wgrad_wino_applicable(a, taps, qkv_heads);
   const bool plain = !wino && !have_act && !a.coef && !a.act && a.resample == RS_NONE && a.Cb == 0 && a.xa;
   const float* xact = plain ? a.xa : act_tmp;
@@ -428,6 +439,315 @@ int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_hea
                      (int)cip, nact, qkv_heads);
   MCEDM_LAUNCH_CHECK("wgrad_reduce_kernel");
   return MCEDM_OK;
+}
+
+// =====================================================================================================================
+// Thin shapes: the 3x3 weight gradient when ONE side has at most 4 channels -- conv_in (cat(cond, x): 4 input channels) and
+// out_conv (2 output channels), adm_blocks.py:383-385, 403.  The 64 x 64-channel MFMA block of wgrad_kernel is 3-6 % full there
+// (0.6 ms each at 128^2, B = 32: 5.9 TFLOP/s); the work is one pass over the wide tensor (268 MB) and 9 * S multiply-adds per
+// element, i.e. HBM-bound.  One wave per (sample, wide channel, 64-column block), lanes along x, a sliding 3 x 3 window of the
+// thin tensor's S channels in registers (3 S loads per row, L1 / L2 hits: every wave of the sample reads the same thin planes):
+//
+//   big = X' (S = Cout, out_conv):  R[ci][co][k] = sum X'[ci][y][x] * dY[co][y - 1 + k / 3][x - 1 + k % 3]  ->  dW[co][ci][8 - k]
+//   big = dY (S = Cin,  conv_in):   R[co][ci][k] = sum dY[co][y][x] * X'[ci][y - 1 + k / 3][x - 1 + k % 3]  ->  dW[co][ci][k]
+//
+// X' = act(coef(cat(xa, xb))) is applied on the fly (no materialisation pass: the out_conv's 268 MB copy disappears as well); the
+// zero padding is applied AFTER the transform.  Per-wave partial sums (fixed-order butterfly) go to [sample][block][wide][10 S];
+// wgrad_thin_reduce_kernel adds them in that order in fp64: no atomics, bitwise reproducible.  The bias gradient rides along.
+template <int S, bool BIG_IS_X>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradArgs p, float* __restrict__ part, int ncol, int CB, int nwaves) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= nwaves) return;                                   // whole waves
+  const int cbk = w % ncol, cb = (w / ncol) % CB, n = w / (ncol * CB);
+  const int H = p.H, W = p.W, Cin = p.Ca + p.Cb;
+  const size_t HW = (size_t)H * W;
+  const int x = cbk * 64 + lane;
+  const bool xin = x < W;
+  const int xc = xin ? x : W - 1;
+  const int xl = xc > 0 ? xc - 1 : 0, xr = xc + 1 < W ? xc + 1 : W - 1;
+  const bool okl = xin && x > 0, okr = xin && x + 1 < W;
+  // wide plane (and its transform row when it is X')
+  const float* bigp;
+  Coef bcf{0.f, 1.f, 0.f, 0.f};
+  if (BIG_IS_X) {
+    const bool in_a = cb < p.Ca;
+    bigp = (in_a ? p.xa + ((size_t)n * p.Ca + cb) * HW : p.xb + ((size_t)n * p.Cb + (cb - p.Ca)) * HW);
+    if (p.coef) bcf = p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + cb];
+  } else {
+    bigp = p.dy + ((size_t)n * p.Cout + cb) * HW;
+  }
+  // thin planes (and their transform rows when they are X')
+  const float* sp[S];
+  Coef scf[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    scf[s] = Coef{0.f, 1.f, 0.f, 0.f};
+    if (BIG_IS_X) {
+      sp[s] = p.dy + ((size_t)n * p.Cout + s) * HW;
+    } else {
+      const bool in_a = s < p.Ca;
+      sp[s] = in_a ? p.xa + ((size_t)n * p.Ca + s) * HW : p.xb + ((size_t)n * p.Cb + (s - p.Ca)) * HW;
+      if (p.coef) scf[s] = p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + s];
+    }
+  }
+  auto xform = [&](float v, const Coef& cf) {
+    const float t = (v - cf.mean) * cf.scale + cf.offset;
+    return p.act ? silu_w(t) : t;
+  };
+  // row r of the thin tensor at columns x - 1, x, x + 1 (zeros outside the image; clamped addresses, values selected)
+  auto load_row = [&](int r, float (&dst)[S][3]) {
+    const bool rok = (unsigned)r < (unsigned)H;
+    const size_t ro = (size_t)(rok ? r : 0) * W;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float a = sp[s][ro + xl], b = sp[s][ro + xc], c = sp[s][ro + xr];
+      if (!BIG_IS_X) { a = xform(a, scf[s]); b = xform(b, scf[s]); c = xform(c, scf[s]); }
+      dst[s][0] = (rok && okl) ? a : 0.f;
+      dst[s][1] = (rok && xin) ? b : 0.f;
+      dst[s][2] = (rok && okr) ? c : 0.f;
+    }
+  };
+  float acc[S][9];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[s][k] = 0.f;
+  float bsum[S];                                              // bias gradient: sum of dY (the wide operand: slot 0; the thin one: the
+#pragma unroll                                                 // windows' centres, counted once, by the waves of wide channel 0)
+  for (int s = 0; s < S; ++s) bsum[s] = 0.f;
+  float win[3][S][3];                                         // rows y - 1, y, y + 1
+  load_row(-1, win[0]);
+  load_row(0, win[1]);
+  for (int y = 0; y < H; ++y) {
+    load_row(y + 1, win[2]);
+    float bv = bigp[(size_t)y * W + xc];
+    if (BIG_IS_X) bv = xform(bv, bcf);
+    bv = xin ? bv : 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[s][k] = fmaf(bv, win[k / 3][s][k % 3], acc[s][k]);
+    if (!BIG_IS_X) bsum[0] += bv;
+    else if (cb == 0) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) bsum[s] += win[1][s][1];
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { win[0][s][c] = win[1][s][c]; win[1][s][c] = win[2][s][c]; }
+  }
+  // wave sums (fixed-order butterfly) -> this wave's record
+  float* rec = part + ((size_t)(n * ncol + cbk) * CB + cb) * (10 * S);
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      float v = acc[s][k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) rec[s * 9 + k] = v;
+    }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float v = bsum[s];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) rec[9 * S + s] = v;
+  }
+}
+
+// The same for power-of-two widths 16 .. 256 (every image the networks see): FOUR pixels per lane and 16-byte loads.  The general
+// kernel above issues 3 S + 1 dword loads per pixel row and lane and is bound by the NUMBER of vector-memory instructions (a CU
+// accepts one every ~25 cycles: 438 us for the out_conv at 128^2, B = 32, whatever the unrolling); here a lane owns the aligned
+// quad x0 .. x0 + 3 of a row, a row is W / 4 lanes and a wave holds 64 / (W / 4) row streams that walk disjoint bands of rows:
+// S + 1 16-byte loads per 4 pixels, the window's two outer columns come from the neighbouring lanes (ds_bpermute; the row's
+// first / last lane sits on the image border: zero).  36 S multiply-adds per lane and trip.
+template <int S, bool BIG_IS_X>
+__global__ __launch_bounds__(256) void wgrad_thin4_kernel(WgradArgs p, float* __restrict__ part, int CB, int nwaves) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= nwaves) return;                                   // whole waves
+  const int cb = w % CB, n = w / CB;
+  const int H = p.H, W = p.W, Cin = p.Ca + p.Cb;
+  const size_t HW = (size_t)H * W;
+  const int nq = W >> 2;                                     // lanes per row (a power of two, 4 .. 64)
+  const int xq = lane & (nq - 1), st = lane / nq, streams = 64 / nq;
+  const int rows = (H + streams - 1) / streams;              // rows per stream
+  const int y0 = st * rows, y1 = y0 + rows < H ? y0 + rows : H;
+  const float* bigp;
+  Coef bcf{0.f, 1.f, 0.f, 0.f};
+  if (BIG_IS_X) {
+    const bool in_a = cb < p.Ca;
+    bigp = (in_a ? p.xa + ((size_t)n * p.Ca + cb) * HW : p.xb + ((size_t)n * p.Cb + (cb - p.Ca)) * HW);
+    if (p.coef) bcf = p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + cb];
+  } else {
+    bigp = p.dy + ((size_t)n * p.Cout + cb) * HW;
+  }
+  const float* sp[S];
+  Coef scf[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    scf[s] = Coef{0.f, 1.f, 0.f, 0.f};
+    if (BIG_IS_X) {
+      sp[s] = p.dy + ((size_t)n * p.Cout + s) * HW;
+    } else {
+      const bool in_a = s < p.Ca;
+      sp[s] = in_a ? p.xa + ((size_t)n * p.Ca + s) * HW : p.xb + ((size_t)n * p.Cb + (s - p.Ca)) * HW;
+      if (p.coef) scf[s] = p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + s];
+    }
+  }
+  auto xform = [&](float v, const Coef& cf) {
+    const float t = (v - cf.mean) * cf.scale + cf.offset;
+    return p.act ? silu_w(t) : t;
+  };
+  // window row r of the thin tensor: columns x0 - 1 .. x0 + 4 of every channel (zeros outside the image, applied after the transform)
+  auto load_row = [&](int r, float (&dst)[S][6]) {
+    const bool rok = (unsigned)r < (unsigned)H;
+    const size_t ro = (size_t)(rok ? r : 0) * W + 4 * xq;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      f32x4 q = *reinterpret_cast<const f32x4*>(sp[s] + ro);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = q[e];
+        if (!BIG_IS_X) v = xform(v, scf[s]);
+        dst[s][1 + e] = rok ? v : 0.f;
+      }
+      const float l = __shfl_up(dst[s][4], 1, 64), rr = __shfl_down(dst[s][1], 1, 64);
+      dst[s][0] = xq > 0 ? l : 0.f;
+      dst[s][5] = xq < nq - 1 ? rr : 0.f;
+    }
+  };
+  float acc[S][9];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[s][k] = 0.f;
+  float bsum[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) bsum[s] = 0.f;
+  float win[3][S][6];
+  load_row(y0 - 1, win[0]);
+  load_row(y0, win[1]);
+  for (int i = 0; i < rows; ++i) {                             // the same trip count in every lane (the shuffles need all of them)
+    const int y = y0 + i;
+    const bool live = y < y1;
+    load_row(y + 1, win[2]);
+    const int yc = y < H ? y : H - 1;
+    const f32x4 bq = *reinterpret_cast<const f32x4*>(bigp + (size_t)yc * W + 4 * xq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = bq[j];
+      if (BIG_IS_X) v = xform(v, bcf);
+      v = live ? v : 0.f;
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[s][k] = fmaf(v, win[k / 3][s][j + k % 3], acc[s][k]);
+      if (!BIG_IS_X) bsum[0] += v;
+    }
+    if (BIG_IS_X && cb == 0 && live) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) bsum[s] += (win[1][s][1] + win[1][s][2]) + (win[1][s][3] + win[1][s][4]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { win[0][s][c] = win[1][s][c]; win[1][s][c] = win[2][s][c]; }
+  }
+  float* rec = part + ((size_t)n * CB + cb) * (10 * S);
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      float v = acc[s][k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) rec[s * 9 + k] = v;
+    }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float v = bsum[s];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) rec[9 * S + s] = v;
+  }
+}
+
+// dW / db from the records, in (sample, column block) order in fp64.  One thread per (wide channel, thin channel, tap); the
+// bias gradient comes from the records' last S slots (see the kernel).
+template <bool BIG_IS_X>
+__global__ void wgrad_thin_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int S,
+                                         int CB, int nrec, int Cin) {
+  const int rl = 10 * S;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= CB * S * 9) return;
+  const int k = i % 9, s = (i / 9) % S, cb = i / (9 * S);
+  double sum = 0.0;
+  for (int r = 0; r < nrec; ++r) sum += (double)part[((size_t)r * CB + cb) * rl + s * 9 + k];
+  if (BIG_IS_X) dw[((size_t)s * Cin + cb) * 9 + (8 - k)] = (float)sum;       // s = co, cb = ci
+  else dw[((size_t)cb * Cin + s) * 9 + k] = (float)sum;                       // cb = co, s = ci
+  if (db && k == 0 && (BIG_IS_X ? cb == 0 : s == 0)) {
+    double b = 0.0;
+    const int slot = BIG_IS_X ? s : 0;
+    for (int r = 0; r < nrec; ++r) b += (double)part[((size_t)r * CB + cb) * rl + 9 * S + slot];
+    db[BIG_IS_X ? s : cb] = (float)b;
+  }
+}
+
+bool wgrad_thin_applicable(const WgradArgs& a, int taps, int qkv_heads) {
+  const int Cin = a.Ca + a.Cb;
+  if (taps != 9 || qkv_heads != 0 || a.resample != RS_NONE || a.B < 1) return false;
+  const bool thin_out = a.Cout >= 1 && a.Cout <= 4 && Cin >= 16, thin_in = Cin >= 1 && Cin <= 4 && a.Cout >= 16;
+  if (!thin_out && !thin_in) return false;
+  if (thin_in && a.xa == nullptr) return false;
+  const int CB = thin_out ? Cin : a.Cout, S = thin_out ? a.Cout : Cin;
+  const size_t rec = (size_t)a.B * ceil_div(a.W, 64) * CB * (10 * S);
+  return rec <= wgrad_scratch_floats(a.Cout, Cin, 9);
+}
+
+template <int S, bool BIG_IS_X>
+static int launch_thin_cfg(const WgradArgs& a, float* dw, float* db, hipStream_t s) {
+  const int Cin = a.Ca + a.Cb;
+  const int CB = BIG_IS_X ? Cin : a.Cout;
+  const bool pow2 = a.W >= 16 && a.W <= 256 && (a.W & (a.W - 1)) == 0;
+  const bool al16 = ((reinterpret_cast<size_t>(a.dy) | reinterpret_cast<size_t>(a.xa) | reinterpret_cast<size_t>(a.xb)) & 15) == 0;
+  const bool quad = pow2 && al16;
+  const int ncol = quad ? 1 : ceil_div(a.W, 64);
+  const int nwaves = a.B * CB * ncol;
+  const double px = (double)a.B * a.H * a.W;
+  {
+    ProfScope ps(quad ? "wgrad_thin4_kernel" : "wgrad_thin_kernel", 2.0 * px * a.Cout * Cin * 9, 4.0 * px * (a.Cout + Cin), s);
+    if (quad) hipLaunchKernelGGL((wgrad_thin4_kernel<S, BIG_IS_X>), dim3(ceil_div(nwaves, 4)), dim3(256), 0, s, a, a.dwp, CB, nwaves);
+    else hipLaunchKernelGGL((wgrad_thin_kernel<S, BIG_IS_X>), dim3(ceil_div(nwaves, 4)), dim3(256), 0, s, a, a.dwp, ncol, CB, nwaves);
+    MCEDM_LAUNCH_CHECK("wgrad_thin_kernel");
+  }
+  const int nout = CB * S * 9;
+  hipLaunchKernelGGL((wgrad_thin_reduce_kernel<BIG_IS_X>), dim3((nout + 255) / 256), dim3(256), 0, s, a.dwp, dw, db, S, CB, a.B * ncol, Cin);
+  MCEDM_LAUNCH_CHECK("wgrad_thin_reduce_kernel");
+  return MCEDM_OK;
+}
+
+int launch_wgrad_thin(const WgradArgs& a, float* dw, float* db, hipStream_t s) {
+  MCEDM_REQUIRE(wgrad_thin_applicable(a, 9, 0), "wgrad_thin: shape not served");
+  MCEDM_REQUIRE(a.dy && a.dwp && dw, "wgrad_thin: null pointer");
+  const int Cin = a.Ca + a.Cb;
+  if (a.Cout <= 4 && Cin >= 16) {
+    switch (a.Cout) {
+      case 1: return launch_thin_cfg<1, true>(a, dw, db, s);
+      case 2: return launch_thin_cfg<2, true>(a, dw, db, s);
+      case 3: return launch_thin_cfg<3, true>(a, dw, db, s);
+      default: return launch_thin_cfg<4, true>(a, dw, db, s);
+    }
+  }
+  switch (Cin) {
+    case 1: return launch_thin_cfg<1, false>(a, dw, db, s);
+    case 2: return launch_thin_cfg<2, false>(a, dw, db, s);
+    case 3: return launch_thin_cfg<3, false>(a, dw, db, s);
+    default: return launch_thin_cfg<4, false>(a, dw, db, s);
+  }
 }
 
 }  // namespace mcedm

@@ -54,6 +54,11 @@ CONV_SHAPES = [
     (2, 64, 0, 64, 16, 16, 3, 2, 1), (3, 2, 2, 64, 32, 32, 3, 0, 0), (2, 64, 0, 2, 32, 32, 3, 0, 1),
     (2, 128, 0, 64, 16, 16, 1, 0, 0), (1, 8, 0, 8, 4, 4, 3, 0, 1), (2, 40, 0, 24, 8, 8, 1, 0, 1),
     (4, 128, 0, 128, 64, 64, 3, 0, 1),
+    # thin shapes (wgrad_thin_kernel: at most 4 channels on one side -- conv_in, out_conv): ragged widths, 1 - 4 channels, concat
+    (3, 64, 0, 1, 12, 20, 3, 0, 1), (2, 32, 32, 3, 9, 70, 3, 0, 0), (2, 128, 0, 4, 16, 130, 3, 0, 1), (2, 128, 0, 2, 128, 128, 3, 0, 1),
+    (3, 1, 0, 32, 10, 24, 3, 0, 0), (2, 2, 1, 64, 7, 66, 3, 0, 1), (2, 2, 2, 128, 128, 128, 3, 0, 0),
+    # power-of-two widths take wgrad_thin4_kernel (four pixels per lane): more row streams than rows, a single stream, odd heights
+    (2, 64, 0, 3, 6, 16, 3, 0, 1), (1, 3, 0, 32, 5, 256, 3, 0, 0), (3, 32, 0, 4, 33, 64, 3, 0, 1),
 ]
 
 
