@@ -28,7 +28,8 @@ Workloads (BASELINE.json `configs`):
   ref128  the reference's own adm_edm_mcedm_res32 network (ch=64) on 128x128 fields, 32 states / GPU
   darcy128  the single-task conditional EDM (1 + 1 -> 1 channels, ch=128) on 128x128 Darcy-sized fields, 32 states / GPU (config 4)
   repaint128  RePaint-style EDM sampling of the DDPM U-Net, 18 steps x 32 resampling loops, 32 states / GPU       (config 5)
-The default run also reports s32 / ref128 / s128l3 / darcy128 / repaint128 as `secondary` entries.
+  ref_default  ref128's network with the reference's SHIPPED sampler config (50 steps, S_churn 15, n_samples 5): 99 evaluations / state
+The default run also reports s32 / ref128 / s128l3 / darcy128 / ref_default / repaint128 as `secondary` entries.
 """
 import argparse
 import hashlib
@@ -53,6 +54,11 @@ WORKLOADS = {
                 name="SWE-periodic 32x32, EDM U-Net ch=64 ch_mult=[1,1,1] (BASELINE config 2)"),
     "ref128": dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32,
                    name="SWE-periodic 128x128, reference adm_edm_mcedm_res32 U-Net ch=64"),
+    # the reference's SHIPPED sampler (configs/diff_sampler/edm_sampler.yaml:1-20: timesteps 50, S_churn 15, n_samples 5) on its own
+    # network: stochastic Heun, 2 * 50 - 1 = 99 U-Net evaluations per state, churn noise drawn on the device (mcedm_heun_sample_rng)
+    "ref_default": dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=30, steps=50, S_churn=15.0,
+                        name="SWE-periodic 128x128, reference U-Net ch=64, shipped sampler config (50 steps, S_churn 15, "
+                             "n_samples 5 x 6 inputs = 30 states), churn noise generated on the device"),
     # BASELINE config 4 read as the single-task model (configs/model/adm_edm_cond_h_res32.yaml: a -> u, 1 + 1 -> 1 channels,
     # PlCondEdm.sample_edm, no mask): 2 inputs x n_samples = 16 draws = 32 states per GPU
     "darcy128": dict(ch=128, ch_mult=(1, 1, 1, 1), attn=(16,), H=128, W=128, batch=32, single=True,
@@ -67,7 +73,7 @@ REPAINT = dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32, n_r
 # Algorithmic cost of ONE U-Net forward per sample (2 x MAC of conv / linear / attention; bytes of the fused
 # schedule): (GFLOP, MB).  darcy128 is the s128 network with 1-channel input / output (the difference is < 0.1 %).
 ALGORITHMIC = {"s32": (1.1115, 20.3), "ref128": (18.787, 230.0), "s128l3": (70.759, 452.5), "s128": (70.843, 463.9),
-               "darcy128": (70.843, 463.9)}
+               "darcy128": (70.843, 463.9), "ref_default": (18.787, 230.0)}
 # kernels bound by HBM rather than by the matrix pipe (their `gbps` against the 8 TB/s roofline is the number that matters)
 HBM_BOUND_KERNELS = ("gn_bwd_kernel", "conv_small_cout_kernel", "act_materialize_kernel", "gn_coef_kernel", "wgrad_reduce_kernel",
                      "wgrad_wino_reduce_kernel", "adam_ema_kernel", "heun", "edm_loss_kernel", "sqnorm_kernel", "gelu", "pack_batch_kernel",
@@ -255,19 +261,32 @@ class Runner:
         if single:      # conditioning field a (observed), state u generated everywhere: no mask (models/ddim.py:1532-1601)
             self.cond, self.mask, self.init = self.cond[:, :1].contiguous(), None, self.init[:, :1].contiguous()
 
-        class SP:      # configs/diff_sampler/edm_sampler.yaml with S_churn = 0 (deterministic Heun), w = 0
-            timesteps, sigma_min, sigma_max, rho, S_churn, S_min, S_max, S_noise, w = STEPS, 0.002, 80.0, 7.0, 0.0, 0.0, float("inf"), 1.0, 0.0
+        steps, churn = int(wl.get("steps", STEPS)), float(wl.get("S_churn", 0.0))
+
+        class SP:      # configs/diff_sampler/edm_sampler.yaml; the headline workloads with S_churn = 0 (deterministic Heun), w = 0
+            timesteps, sigma_min, sigma_max, rho, S_churn, S_min, S_max, S_noise, w = steps, 0.002, 80.0, 7.0, churn, 0.0, float("inf"), 1.0, 0.0
         self.sd = lib.sampler_desc(SP)
+        self.nfe = 2 * steps - 1
+        self.churn = churn > 0
+        self.calls = 0
+        self.seed = torch.zeros(1, dtype=torch.int64, device=device) if self.churn else None
         self.ws = lib.Workspace()
-        self.graph = lib.GraphedSampler(self.plan, self.packed, self.sd, self.B, self.H, self.W, masked=not single) if use_graph else None
+        self.graph = lib.GraphedSampler(self.plan, self.packed, self.sd, self.B, self.H, self.W, masked=not single,
+                                        churn=self.churn, device_noise=self.churn) if use_graph else None
 
     def step(self):
+        self.calls += 1
         if self.graph is not None:
+            if self.churn:
+                return self.graph(self.cond, self.mask, self.init, seed=4242 + self.calls)      # fresh noise every call
             return self.graph(self.cond, self.mask, self.init)
         return self.eager()
 
     def eager(self):
-        return self.plan.sample(self.packed, self.sd, self.cond, self.mask, self.init, None, return_last=True, ws=self.ws)
+        if self.churn:
+            self.seed.fill_(4242 + self.calls)
+        return self.plan.sample(self.packed, self.sd, self.cond, self.mask, self.init, None, return_last=True, ws=self.ws,
+                                rng_seed=self.seed)
 
     def profile(self, steps):
         """Separate event-timed pass (eager launches; HIP events cannot be recorded inside a graph)."""
@@ -374,13 +393,13 @@ def hbm_bound_rows(prof):
     return [dict(r, hbm_frac=round(r["gbps"] / PEAK_HBM_GBPS, 3)) for r in rows]
 
 
-def fractions(key, states_per_s, fwd_ms, B):
+def fractions(key, states_per_s, fwd_ms, B, nfe=None):
     """Both roofline fractions SURVEY.md 8(d) asks for next to every number, on the algorithmic cost of the workload:
     per U-Net forward (batch B in fwd_ms) and per denoised state (35 forwards) at the measured whole-job rate."""
     if key not in ALGORITHMIC:
         return {}
     gf, mb = ALGORITHMIC[key]
-    nfe = 2 * STEPS - 1
+    nfe = nfe or 2 * STEPS - 1
     return {"forward_fp32_frac_algorithmic": gf * 1e9 * B / (fwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "forward_hbm_frac": mb * 1e6 * B / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
             "per_state": {"gflop": gf * nfe, "gbyte": mb * nfe / 1e3,
@@ -627,7 +646,7 @@ def main():
     if not args.no_secondary and world == 1 and args.workload == "s128" and not args.batch:
         del run.graph
         torch.cuda.empty_cache()
-        for key in ("s32", "ref128", "s128l3", "darcy128"):
+        for key in ("s32", "ref128", "s128l3", "darcy128", "ref_default"):
             r2 = Runner(key, 0, device, 0, not args.no_graph)
             r2.step()
             torch.cuda.synchronize()
@@ -640,11 +659,11 @@ def main():
             p2 = r2.profile(1)
             ro = roofline_of(p2)
             line["secondary"][key] = {"workload": r2.wl["name"], "states_per_gpu": r2.B, "value": r2.B / dt, "unit": "states/s",
-                                      "ms_per_step": dt * 1e3, "steps": n2, "unet_fwd_ms": r2.fwd_ms(),
+                                      "ms_per_step": dt * 1e3, "steps": n2, "nfe_per_state": r2.nfe, "unet_fwd_ms": r2.fwd_ms(),
                                       "fp32_frac_whole_sampler": sum(r["flops"] for r in p2) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                       "dominant_kernel": ro["kernel"], "dominant_kernel_tflops": ro["achieved"],
                                       "dominant_kernel_frac": ro["frac"], "dominant_kernel_share": ro["share_of_kernel_time"]}
-            line["secondary"][key].update(fractions(key, r2.B / dt, line["secondary"][key]["unet_fwd_ms"], r2.B))
+            line["secondary"][key].update(fractions(key, r2.B / dt, line["secondary"][key]["unet_fwd_ms"], r2.B, r2.nfe))
             del r2
             torch.cuda.empty_cache()
 

@@ -102,6 +102,7 @@ void mcedm_unet_plan_destroy(mcedm_plan* plan);
 #define MCEDM_VARIANT_CONV8 3           /* experimental 8-wave direct conv (env MCEDM_CONV8, default 0) */
 #define MCEDM_VARIANT_ATTN_FUSED 4      /* single-launch attention block at 8 x 8 x 64 (env MCEDM_ATTN_FUSED, default 1) */
 #define MCEDM_VARIANT_WGRAD_WINO 5      /* Winograd F(3x3, 2x2) weight gradient (env MCEDM_WGRAD_WINO, default 1) */
+#define MCEDM_VARIANT_CONV1X1_REG 6     /* register-direct GEMM for un-transformed 1x1 convs at >= 32 x 32 (env MCEDM_CONV1X1_REG, default 1) */
 int mcedm_unet_plan_set_variant(mcedm_plan* plan, int which, int value);
 
 /* Parameter table in DhariwalUNet.state_dict() order (parameters only, no buffers).
@@ -365,6 +366,11 @@ int mcedm_op_set_conv_wino1(int enable);
  * multiples of 128 on images with W % 32 == 0: 1 on, 0 off (the direct split-K kernel everywhere), -1 back to the default (env
  * MCEDM_WGRAD_WINO, else on).  Read at every launch; the scratch size does not depend on it.  Process-global. */
 int mcedm_op_set_wgrad_wino(int enable);
+/* The register-direct GEMM kernel (conv1x1_reg.hip) for 1x1 convs without input transform (the decoder blocks' skip projections and
+ * their data gradients; Cout % 128 == 0, Cin % 16 == 0, Cin <= 256, H * W % 512 == 0): 1 on, 0 off (conv_mfma_kernel), -1 back to the
+ * default (env MCEDM_CONV1X1_REG, else on).  Results differ from conv_mfma_kernel's in the last bits only through ... nothing: both sum
+ * over ci in ascending pairs; tests hold them to rtol 1e-5.  Read at every launch.  Process-global. */
+int mcedm_op_set_conv1x1_reg(int enable);
 /* The single-launch attention part of a UNetBlock at 8 x 8 x 64 channels (attn_fused.hip; inference only): 1 on, 0 off
  * (qkv conv + attention kernel + proj conv), -1 back to the default (env MCEDM_ATTN_FUSED, else on).  Process-global. */
 int mcedm_op_set_attn_fused(int enable);

@@ -41,8 +41,8 @@ void set_error(const char* fmt, ...);
 // (mcedm_*_plan_set_variant; a field of the plan, so two plans in one process -- on two threads or two streams -- cannot flip each
 // other's kernels), the process-wide test hooks mcedm_op_set_* (kernel-level calls have no plan), the environment.
 enum KernelVariant { KV_CONV_WINO = 0, KV_CONV_WINO1 = 1, KV_CONV_RESIDENT = 2, KV_CONV8 = 3, KV_ATTN_FUSED = 4, KV_WGRAD_WINO = 5,
-                     KV_COUNT = 6 };
-struct KernelVariants { int v[KV_COUNT] = {-1, -1, -1, -1, -1, -1}; };
+                     KV_CONV1X1_REG = 6, KV_COUNT = 7 };
+struct KernelVariants { int v[KV_COUNT] = {-1, -1, -1, -1, -1, -1, -1}; };
 const KernelVariants* current_variants();                 // of the executing plan-level call on this thread, or null
 struct VariantScope {                                      // first statement of every extern "C" function that takes a plan
   const KernelVariants* prev;
@@ -163,6 +163,8 @@ static inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }     //
 int conv_resolve_identity(ConvArgs& a);                  // points a missing transform table at the identity row
 unsigned long long* conv_debug_buffer();
 int try_launch_conv_resident(const ConvArgs& a, int taps, hipStream_t stream);   // conv_resident.hip; -1: not served there
+int try_launch_conv1x1_reg(const ConvArgs& a, int taps, hipStream_t stream);     // conv1x1_reg.hip (un-transformed 1x1 convs); -1: not served
+void set_conv1x1_reg(int enable);                        // 1 / 0, -1: default (env MCEDM_CONV1X1_REG, else on)
 void set_conv_resident(int enable);                      // 1 / 0, -1: default (env MCEDM_CONV_RESIDENT, else on)
 static inline int conv_max_tiles(int H, int W) { return ((H + 3) / 4) * ((W + 7) / 8); }   // smallest pixel tile is 4x8 (conv_resident.hip)
 void set_conv_tile_override(int mt, int ph, int pw);

@@ -889,6 +889,10 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t stream) {
   // Winograd F(2x2, 3x3) kernel (conv_wino.hip) where the launch carries its weight table and the shape fits: chosen by shape
   // alone (never by the batch size), like every other tile choice here
   if (!g_force_mt && taps == 9 && a.wino && conv_wino_preferred(a) && conv_wino_applicable(a, taps)) return launch_conv_wino(a, stream);
+  if (!g_force_mt && taps == 1) {     // un-transformed 1x1 convs at >= 32 x 32 (the decoder's skip projections): register-direct GEMM
+    const int rc = try_launch_conv1x1_reg(a, taps, stream);
+    if (rc != -1) return rc;
+  }
   if (!g_force_mt) {     // small images: the input-resident kernel (conv_resident.hip), bit-identical per tile configuration
     const int rc = try_launch_conv_resident(a, taps, stream);
     if (rc != -1) return rc;

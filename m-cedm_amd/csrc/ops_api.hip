@@ -153,6 +153,11 @@ extern "C" int mcedm_op_set_conv_wino1(int enable) {
   return MCEDM_OK;
 }
 
+extern "C" int mcedm_op_set_conv1x1_reg(int enable) {
+  set_conv1x1_reg(enable);
+  return MCEDM_OK;
+}
+
 extern "C" int mcedm_op_set_wgrad_wino(int enable) {
   set_wgrad_wino(enable);
   return MCEDM_OK;

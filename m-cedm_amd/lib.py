@@ -34,7 +34,7 @@ EXPORTS = [
     "mcedm_unet_plan_set_variant", "mcedm_ddpm_plan_set_variant", "mcedm_heun_sample_rng",
 ]
 # kernel families that exist in two forms (include/mcedm_hip.h MCEDM_VARIANT_*)
-VARIANTS = {"conv_wino": 0, "conv_wino1": 1, "conv_resident": 2, "conv8": 3, "attn_fused": 4, "wgrad_wino": 5}
+VARIANTS = {"conv_wino": 0, "conv_wino1": 1, "conv_resident": 2, "conv8": 3, "attn_fused": 4, "wgrad_wino": 5, "conv1x1_reg": 6}
 
 
 class UNetDesc(C.Structure):
@@ -898,7 +898,7 @@ OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_
               "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd",
               "mcedm_op_set_conv_debug", "mcedm_op_set_conv8", "mcedm_op_set_conv_resident", "mcedm_op_set_attn_fused", "mcedm_op_embedding",
               "mcedm_op_conv_wino_packed_floats", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino", "mcedm_op_set_conv_wino", "mcedm_op_set_conv_wino1",
-              "mcedm_op_set_wgrad_wino"]
+              "mcedm_op_set_wgrad_wino", "mcedm_op_set_conv1x1_reg"]
 
 
 def prof_enable(on: bool) -> None:
@@ -942,6 +942,13 @@ def set_conv_wino1(enable: int = -1) -> None:
     lib = _bind_ops()
     lib.mcedm_op_set_conv_wino1.argtypes = [C.c_int]
     check(lib.mcedm_op_set_conv_wino1(int(enable)), "set_conv_wino1")
+
+
+def set_conv1x1_reg(enable: int = -1) -> None:
+    """Register-direct GEMM kernel for un-transformed 1x1 convs (conv1x1_reg.hip): 1 / 0 (conv_mfma_kernel); -1 = default (on)."""
+    lib = _bind_ops()
+    lib.mcedm_op_set_conv1x1_reg.argtypes = [C.c_int]
+    check(lib.mcedm_op_set_conv1x1_reg(int(enable)), "set_conv1x1_reg")
 
 
 def set_wgrad_wino(enable: int = -1) -> None:
