@@ -227,7 +227,7 @@ def committed_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (tools/rocpd_summary.py traffic writes
     profiles/r3_traffic.json with the digest of the kernel sources it was taken on); refused when the sources changed."""
     tr = None
-    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json"):       # newest committed pass first
+    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json"):       # newest committed pass first
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
             break

@@ -39,11 +39,17 @@ struct Conv1Args {
   int nwg;                                  // workgroups along x: workgroup b takes tiles b, b + nwg, b + 2 nwg, ...
 };
 
+// NI = 32-channel blocks per wave: 2 (64 channels x 128 pixels per wave, 16-byte loads; every input element is fetched by the two
+// waves that share a pixel quarter) or 4 (all 128 channels x 64 pixels per wave, 8-byte loads: every element fetched ONCE per
+// workgroup, twice the LDS fragment reads)
+template <int NI>
 __global__ __launch_bounds__(512, 1) void conv1x1_reg_kernel(const Conv1Args p) {
+  constexpr int NE = 8 / NI;                                      // pixels (= 32-column blocks) per lane
+  typedef float bvec __attribute__((ext_vector_type(NE)));
   extern __shared__ float wl[];                                   // [128][Cin + 16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int coh = wave & 1, pq = wave >> 1, l31 = lane & 31, h = lane >> 5;
+  const int coh = NI == 2 ? (wave & 1) : 0, pq = NI == 2 ? (wave >> 1) : wave, l31 = lane & 31, h = lane >> 5;
   const int Cin = p.Ca + p.Cb, nst = Cin / C1_KS;
   const int pitch = Cin + 16;
   const int m0 = blockIdx.y * C1_MT;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_reg_kernel(const Conv1Args p) 
   }
   __syncthreads();
 
-  const unsigned lvo = 4u * ((unsigned)h * p.HW + 4u * l31);      // lane part of every B load: channel parity, pixel quad
+  const unsigned lvo = 4u * ((unsigned)h * p.HW + (unsigned)NE * l31);      // lane part of every B load: channel parity, first pixel
   const int afo = (coh * 64 + l31) * pitch + 4 * ((l31 >> 2) & 3) * 0;   // row of this lane's first A block (the swizzle is applied per slot)
   const int asw = (l31 >> 2) & 3;
 
@@ -73,29 +79,30 @@ __global__ __launch_bounds__(512, 1) void conv1x1_reg_kernel(const Conv1Args p) 
   // few samples, channel by channel -- neighbouring 2 KB pieces of a plane are requested at about the same time
   for (int t = blockIdx.x; t < p.ntiles; t += p.nwg) {
     const int n = t / p.tiles_img, tq = t - n * p.tiles_img;
-    const unsigned px0 = (unsigned)tq * C1_PX + (unsigned)pq * 128u;
+    const unsigned px0 = (unsigned)tq * C1_PX + (unsigned)pq * (32u * NE);
     // B operand of stage c, slot (g, s): 16 bytes = channel 16 c + 8 g + 2 s + h, pixels px0 + 4 l31 ..  Issued from inline
     // assembly (scalar plane base + 32-bit lane offset): hipcc's wait-count insertion puts s_waitcnt vmcnt(0) at the head of
     // the K loop for loads it can see -- the whole memory latency exposed once per stage -- so these are invisible to it and
     // every consumer is ordered by the explicit counted wait below (wait_b).
-    auto load_b1 = [&](int c, int g, int s) -> f32x4 {
+    auto load_b1 = [&](int c, int g, int s) -> bvec {
       const int ci = C1_KS * c + 8 * g + 2 * s;
       const bool in_a = ci < p.Ca;
       const float* plane = in_a ? p.xa + ((size_t)n * p.Ca + ci) * p.HW + px0 : p.xb + ((size_t)n * p.Cb + (ci - p.Ca)) * p.HW + px0;
-      f32x4 v;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lvo), "s"(uniform_ptr(plane)) : "memory");
+      bvec v;
+      if (NE == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(lvo), "s"(uniform_ptr(plane)) : "memory");
+      else asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(lvo), "s"(uniform_ptr(plane)) : "memory");
       return v;
     };
     // slot (g, s) was requested exactly eight loads ago (one per slot, in slot order): seven younger loads may still be in flight
-    auto wait_b = [&](f32x4& v) { asm volatile("s_waitcnt vmcnt(7)" : "+v"(v)); };
-    f32x16 acc[2][4];
+    auto wait_b = [&](bvec& v) { asm volatile("s_waitcnt vmcnt(7)" : "+v"(v)); };
+    f32x16 acc[NI][NE];
     {
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       float z = 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NE; ++e) {
           asm volatile("" : "+v"(z));
           acc[i][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, z, zero16, 0, 0, 0);
         }
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(512, 1) void conv1x1_reg_kernel(const Conv1Args p) 
     // so the eight loads of a stage are spread over its 64 MFMAs and each has 7/8 of a stage to arrive.  (All eight issued together
     // in front of the stage back the vector-memory path up and the wave -- in-order issue -- cannot reach its MFMAs: 384 us instead
     // of the 250 us of matrix time, with loads alone taking 212 us.)
-    f32x4 bq[2][4];
+    bvec bq[2][4];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -114,19 +121,19 @@ __global__ __launch_bounds__(512, 1) void conv1x1_reg_kernel(const Conv1Args p) 
       const float* ar = wl + afo + c * C1_KS;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ar + 4 * ((2 * g + h) ^ asw));
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ar + 32 * pitch + 4 * ((2 * g + h) ^ asw));
+        f32x4 af[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) af[i] = *reinterpret_cast<const f32x4*>(ar + 32 * i * pitch + 4 * ((2 * g + h) ^ asw));
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           wait_b(bq[g][s]);
 #ifndef MCEDM_C1_LOADS_ONLY
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc[0][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bq[g][s][e], acc[0][e], 0, 0, 0);
-            acc[1][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bq[g][s][e], acc[1][e], 0, 0, 0);
-          }
+          for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i][e] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bq[g][s][e], acc[i][e], 0, 0, 0);
 #else                                                              // diagnostic build: consume the loads, skip the matrix work (wrong results)
-          acc[0][0][0] += bq[g][s][0] + bq[g][s][3] + a0[s] + a1[s];
+          acc[0][0][0] += bq[g][s][0] + bq[g][s][NE - 1] + af[0][s] + af[NI - 1][s];
 #endif
           bq[g][s] = load_b1(cn, g, s);
         }
@@ -136,18 +143,20 @@ __global__ __launch_bounds__(512, 1) void conv1x1_reg_kernel(const Conv1Args p) 
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]),
                  "+v"(bq[1][2]), "+v"(bq[1][3]));
     // ---- epilogue: + bias (+ residual), 16-byte stores: registers (e = 0 .. 3) of one accumulator row are four consecutive pixels
-    const size_t obase = ((size_t)n * p.Cout) * p.HW + px0 + 4u * l31;
+    const size_t obase = ((size_t)n * p.Cout) * p.HW + px0 + (unsigned)NE * l31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m0 + coh * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (co < p.Cout) {
           const float bv = p.bias ? p.bias[co] : 0.f;
-          f32x4 v = {acc[i][0][r] + bv, acc[i][1][r] + bv, acc[i][2][r] + bv, acc[i][3][r] + bv};
+          bvec v;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) v[e] = acc[i][e][r] + bv;
           const size_t o = obase + (size_t)co * p.HW;
-          if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
-          *reinterpret_cast<f32x4*>(p.out + o) = v;
+          if (p.res) v += *reinterpret_cast<const bvec*>(p.res + o);
+          *reinterpret_cast<bvec*>(p.out + o) = v;
         }
       }
   }
@@ -193,12 +202,16 @@ int try_launch_conv1x1_reg(const ConvArgs& a, int taps, hipStream_t stream) {
   MCEDM_HIP_TRY(hipGetDevice(&dev));
   MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
   if (!attr_set[dev].load(std::memory_order_acquire)) {
-    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv1x1_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv1x1_reg_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv1x1_reg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[dev].store(true, std::memory_order_release);
   }
   const double px = (double)a.B * (double)HW;
   ProfScope ps("conv1x1_reg_kernel", 2.0 * px * a.Cout * Cin, 4.0 * (px * (Cin + a.Cout * (a.res ? 2 : 1)) + (double)a.Cout * Cin), stream);
-  hipLaunchKernelGGL(conv1x1_reg_kernel, dim3(wgs, mblocks), dim3(512), lds, stream, p);
+  static int ni_env = -1;                                  // MCEDM_C1_NI: 2 or 4 (A/B runs; the two differ in the last bits of nothing: same sums)
+  if (ni_env < 0) { const char* e = getenv("MCEDM_C1_NI"); ni_env = e ? atoi(e) : 2; }      // NI = 4 measured 20 % slower (436 vs 364 us)
+  if (ni_env == 2) hipLaunchKernelGGL(conv1x1_reg_kernel<2>, dim3(wgs, mblocks), dim3(512), lds, stream, p);
+  else hipLaunchKernelGGL(conv1x1_reg_kernel<4>, dim3(wgs, mblocks), dim3(512), lds, stream, p);
   MCEDM_LAUNCH_CHECK("conv1x1_reg_kernel");
   return MCEDM_OK;
 }

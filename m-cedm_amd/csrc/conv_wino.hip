@@ -43,7 +43,10 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 }
 
 // UP: the conv input is the nearest-neighbour 2x up-sampling of the (activated) source (adm_blocks.py:69-73)
-template <class C, bool UP>
+// ACT = false: the launch has no activation (p.act == 0: the data-gradient convs of training, whose input is a raw gradient): the
+// plain variant's branch-free "evaluate SiLU and select" is compiled out -- ~20 of the ~58 vector instructions per chunk and lane,
+// every one of them matrix time (round 5; the forward convs of inference all carry the activation)
+template <class C, bool UP, bool ACT = true>
 __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(const ConvArgs p, int tiles_x, int tiles_img, int nch, int mblocks,
                                                                           int per, int mode) {
   constexpr int WSC = C::SC, VBUF = C::VBUF, RBUF = C::RBUF, MB = C::MB;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
         }
         // no branch (a slot must stay ONE basic block, see the K loop): SiLU is evaluated and selected
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { const f32x2 a = silu_f2(t[h]); t[h] = p.act ? a : t[h]; }
+        for (int h = 0; h < 2; ++h) { if constexpr (ACT) { const f32x2 a = silu_f2(t[h]); t[h] = p.act ? a : t[h]; } }
 #pragma unroll
         for (int i = 0; i < 4; ++i) rb[(sc * WKC + kl) * RPLANE + lofs[i]] = t[i >> 1][i & 1];
       }
@@ -533,6 +536,12 @@ static int wino_mode_env() {                                   // MCEDM_WINO_MOD
   return env;
 }
 
+static int wino_noact_env() {                                  // MCEDM_WINO_NOACT=0: the select-based variant for activation-free launches too (A/B)
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_WINO_NOACT"); env = e ? atoi(e) : 1; }
+  return env;
+}
+
 static int wino_min_hw_env() {                                 // MCEDM_WINO_MIN_HW: smallest image (pixels) served; below 32 x 32 the grid
   static int env = -1;                                  // (B * H * W / 128 workgroups) no longer fills the chip
   if (env < 0) { const char* e = getenv("MCEDM_WINO_MIN_HW"); env = e ? atoi(e) : 1024; }
@@ -592,6 +601,7 @@ static int launch_wino_cfg(const ConvArgs& a, hipStream_t stream) {
     ncu[dev].store(n_cu > 0 ? n_cu : 256, std::memory_order_release);
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv_wino_kernel<C, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[dev].store(true, std::memory_order_release);
   }
   static int per_env = -1;                                 // MCEDM_WINO_PER: force the tiles per workgroup (A/B runs; must divide)
@@ -606,6 +616,9 @@ static int launch_wino_cfg(const ConvArgs& a, hipStream_t stream) {
                4.0 * ((double)a.B * Cin * a.Hs * a.Ws + px * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * Cin * 9), stream);
   if (a.resample == RS_UP)
     hipLaunchKernelGGL((conv_wino_kernel<C, true>), dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,
+                       tiles_img, nch, cout_padded(a.Cout) / 32, per, wino_mode_env());
+  else if (!a.act && wino_noact_env())
+    hipLaunchKernelGGL((conv_wino_kernel<C, false, false>), dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,
                        tiles_img, nch, cout_padded(a.Cout) / 32, per, wino_mode_env());
   else
     hipLaunchKernelGGL((conv_wino_kernel<C, false>), dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,

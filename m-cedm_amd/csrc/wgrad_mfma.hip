@@ -48,47 +48,63 @@ __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_r
 // ---- step 1: materialise the conv input  X' = resample(act(coef(cat(xa, xb))))  once, at HBM speed --------------
 // (the forward never stores it; recomputing it inside the wgrad staging costs ~45 VALU ops per staged element and made
 // that kernel VALU-bound.)  One thread per 4 consecutive output pixels of a row when W % 4 == 0.
-__global__ __launch_bounds__(256) void act_materialize_kernel(WgradArgs p, float* __restrict__ out, size_t total4, int vec) {
+// grid = (planes, chunks of a plane): blockIdx.x = (sample, channel) -- one transform row and one source plane per workgroup, 32-bit
+// index arithmetic per quad (round 4's flat 64-bit index took four 64-bit divisions per quad: 3.7 TB/s read + write).
+__global__ __launch_bounds__(256) void act_materialize_kernel(WgradArgs p, float* __restrict__ out, int vec) {
   const int Cin = p.Ca + p.Cb;
-  const size_t HW = (size_t)p.H * p.W, HWs = (size_t)p.Hs * p.Ws;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t e0 = i * vec;
-    const int x0 = (int)(e0 % p.W);
-    const int y = (int)((e0 / p.W) % p.H);
-    const int ci = (int)((e0 / HW) % Cin);
-    const int n = (int)(e0 / (HW * Cin));
-    const bool in_a = ci < p.Ca;
-    const float* src = in_a ? p.xa : p.xb;
+  const unsigned HW = (unsigned)p.H * p.W, HWs = (unsigned)p.Hs * p.Ws;
+  const int n = blockIdx.x / Cin, ci = blockIdx.x - n * Cin;
+  const bool in_a = ci < p.Ca;
+  const float* src = in_a ? p.xa : p.xb;
+  float* dst = out + (size_t)blockIdx.x * HW;
+  const unsigned nq = HW / vec;
+  if (!src) {
+    for (unsigned q = blockIdx.y * 256u + threadIdx.x; q < nq; q += gridDim.y * 256u) {
+      if (vec == 4) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{0.f, 0.f, 0.f, 0.f};
+      else dst[q] = 0.f;
+    }
+    return;
+  }
+  const float* plane = src + ((size_t)n * (in_a ? p.Ca : p.Cb) + (in_a ? ci : ci - p.Ca)) * HWs;
+  Coef cf{0.f, 1.f, 0.f, 0.f};
+  if (p.coef) cf = p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + ci];
+  const unsigned wq = (unsigned)p.W / vec;                       // quads per output row
+  for (unsigned q = blockIdx.y * 256u + threadIdx.x; q < nq; q += gridDim.y * 256u) {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (src) {
-      const float* plane = src + ((size_t)n * (in_a ? p.Ca : p.Cb) + (in_a ? ci : ci - p.Ca)) * HWs;
-      Coef cf{0.f, 1.f, 0.f, 0.f};
-      if (p.coef) cf = p.coef[(p.coef_batch ? (size_t)n * Cin : 0) + ci];
+    if (p.resample == RS_NONE && vec == 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(plane + 4 * q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float tt = (s4[k] - cf.mean) * cf.scale + cf.offset;
+        v[k] = p.act ? silu_w(tt) : tt;
+      }
+    } else {
+      const unsigned y = q / wq, x0 = (q - y * wq) * vec;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (k < vec) {
-          const int x = x0 + k;
+          const unsigned x = x0 + k;
           if (p.resample == RS_NONE) {
-            const float tt = (plane[(size_t)y * p.Ws + x] - cf.mean) * cf.scale + cf.offset;
+            const float tt = (plane[y * p.Ws + x] - cf.mean) * cf.scale + cf.offset;
             v[k] = p.act ? silu_w(tt) : tt;
           } else if (p.resample == RS_UP) {
-            const float tt = (plane[(size_t)(y >> 1) * p.Ws + (x >> 1)] - cf.mean) * cf.scale + cf.offset;
+            const float tt = (plane[(y >> 1) * p.Ws + (x >> 1)] - cf.mean) * cf.scale + cf.offset;
             v[k] = p.act ? silu_w(tt) : tt;
           } else {
-            const float* q0 = plane + (size_t)(2 * y) * p.Ws + 2 * x;
+            const float* q0 = plane + (2 * y) * p.Ws + 2 * x;
             float s4[4] = {q0[0], q0[1], q0[p.Ws], q0[p.Ws + 1]};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float tt = (s4[q] - cf.mean) * cf.scale + cf.offset;
-              s4[q] = p.act ? silu_w(tt) : tt;
+            for (int j = 0; j < 4; ++j) {
+              const float tt = (s4[j] - cf.mean) * cf.scale + cf.offset;
+              s4[j] = p.act ? silu_w(tt) : tt;
             }
             v[k] = 0.25f * ((s4[0] + s4[1]) + (s4[2] + s4[3]));
           }
         }
       }
     }
-    if (vec == 4) *reinterpret_cast<f32x4*>(out + e0) = f32x4{v[0], v[1], v[2], v[3]};
-    else out[e0] = v[0];
+    if (vec == 4) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{v[0], v[1], v[2], v[3]};
+    else dst[q] = v[0];
   }
 }
 
@@ -395,11 +411,16 @@ static int launch_wg(const WgradArgs& a, const float* xact, int* nact, hipStream
 int launch_act_materialize(const WgradArgs& a, float* out, hipStream_t s) {
   const int Cin = a.Ca + a.Cb;
   const size_t total = (size_t)a.B * Cin * a.H * a.W;
-  const int vec = (a.W % 4 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0) ? 4 : 1;
-  const size_t n4 = total / vec;
-  const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  const bool src16 = ((reinterpret_cast<size_t>(a.xa) | reinterpret_cast<size_t>(a.xb)) & 15) == 0 && ((size_t)a.Hs * a.Ws) % 4 == 0;
+  const int vec = (a.W % 4 == 0 && (reinterpret_cast<size_t>(out) & 15) == 0 && ((size_t)a.H * a.W) % 4 == 0 &&
+                   (a.resample != RS_NONE || src16)) ? 4 : 1;
+  const unsigned nq = (unsigned)((size_t)a.H * a.W / vec);
+  MCEDM_REQUIRE((size_t)a.B * Cin < (1ull << 31) && (size_t)a.H * a.W < (1ull << 31), "act_materialize: shape out of range");
+  int bx = (int)((nq + 1023) / 1024);                         // four quads per thread and trip
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
   ProfScope ps("act_materialize_kernel", 10.0 * total, 4.0 * ((double)a.B * Cin * a.Hs * a.Ws + (double)total), s);
-  hipLaunchKernelGGL(act_materialize_kernel, dim3(blocks), dim3(256), 0, s, a, out, n4, vec);
+  hipLaunchKernelGGL(act_materialize_kernel, dim3(a.B * Cin, bx), dim3(256), 0, s, a, out, vec);
   MCEDM_LAUNCH_CHECK("act_materialize_kernel");
   return MCEDM_OK;
 }
