@@ -76,7 +76,7 @@ ALGORITHMIC = {"s32": (1.1115, 20.3), "ref128": (18.787, 230.0), "s128l3": (70.7
                "darcy128": (70.843, 463.9), "ref_default": (18.787, 230.0)}
 # kernels bound by HBM rather than by the matrix pipe (their `gbps` against the 8 TB/s roofline is the number that matters)
 HBM_BOUND_KERNELS = ("gn_bwd_kernel", "conv_small_cout_kernel", "act_materialize_kernel", "gn_coef_kernel", "wgrad_reduce_kernel",
-                     "wgrad_wino_reduce_kernel", "adam_ema_kernel", "heun", "edm_loss_kernel", "sqnorm_kernel", "gelu", "pack_batch_kernel",
+                     "wgrad_wino_reduce_kernel", "wgrad_thin", "adam_ema_kernel", "heun", "edm_loss_kernel", "sqnorm_kernel", "gelu", "pack_batch_kernel",
                      "pack_conv_kernel", "wino_pack_kernel")
 TRAIN_LEG_TIMEOUT_S = 300      # watchdog of the multi-rank training leg (an untimed extra of the line)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak

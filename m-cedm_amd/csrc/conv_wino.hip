@@ -173,9 +173,9 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
           const f32x2 v = {raw[sc][cw][2 * h], raw[sc][cw][2 * h + 1]};
           t[h] = (v - cf.mean) * scm + ofm;
         }
-        // no branch (a slot must stay ONE basic block, see the K loop): SiLU is evaluated and selected
+        // no branch (a slot must stay ONE basic block, see the K loop): the activation is a template parameter
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { if constexpr (ACT) { const f32x2 a = silu_f2(t[h]); t[h] = p.act ? a : t[h]; } }
+        for (int h = 0; h < 2; ++h) { if constexpr (ACT) t[h] = silu_f2(t[h]); }       // ACT == (p.act != 0): the launcher's choice
 #pragma unroll
         for (int i = 0; i < 4; ++i) rb[(sc * WKC + kl) * RPLANE + lofs[i]] = t[i >> 1][i & 1];
       }
@@ -536,12 +536,6 @@ static int wino_mode_env() {                                   // MCEDM_WINO_MOD
   return env;
 }
 
-static int wino_noact_env() {                                  // MCEDM_WINO_NOACT=0: the select-based variant for activation-free launches too (A/B)
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("MCEDM_WINO_NOACT"); env = e ? atoi(e) : 1; }
-  return env;
-}
-
 static int wino_min_hw_env() {                                 // MCEDM_WINO_MIN_HW: smallest image (pixels) served; below 32 x 32 the grid
   static int env = -1;                                  // (B * H * W / 128 workgroups) no longer fills the chip
   if (env < 0) { const char* e = getenv("MCEDM_WINO_MIN_HW"); env = e ? atoi(e) : 1024; }
@@ -609,7 +603,9 @@ static int launch_wino_cfg(const ConvArgs& a, hipStream_t stream) {
   int per = wino_tiles_per_wg(total, tiles_img, ncu[dev].load(std::memory_order_acquire) * (C::MB == 4 ? 1 : 2));
   if (per_env > 0 && tiles_img % per_env == 0) per = per_env;
   char name[64] = "";
-  if (prof_enabled()) snprintf(name, sizeof(name), "conv_wino_kernel<WinoCfg<%d>, %s>", C::MB, a.resample == RS_UP ? "true" : "false");   // = rocprofv3's name
+  const bool noact = a.resample != RS_UP && !a.act;
+  if (prof_enabled()) snprintf(name, sizeof(name), "conv_wino_kernel<WinoCfg<%d>, %s, %s>", C::MB, a.resample == RS_UP ? "true" : "false",
+                               noact ? "false" : "true");   // = rocprofv3's name
   const double px = (double)a.B * a.H * a.W;
   // algorithmic cost = the direct convolution's (2 * MAC); the kernel issues 4 / 9 of these as matrix flops
   ProfScope ps(name, 2.0 * px * a.Cout * (double)Cin * 9,
@@ -617,7 +613,7 @@ static int launch_wino_cfg(const ConvArgs& a, hipStream_t stream) {
   if (a.resample == RS_UP)
     hipLaunchKernelGGL((conv_wino_kernel<C, true>), dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,
                        tiles_img, nch, cout_padded(a.Cout) / 32, per, wino_mode_env());
-  else if (!a.act && wino_noact_env())
+  else if (noact)
     hipLaunchKernelGGL((conv_wino_kernel<C, false, false>), dim3((unsigned)(total / per), a.Cout / C::MT), dim3(C::NT), lds_bytes, stream, a, tiles_x,
                        tiles_img, nch, cout_padded(a.Cout) / 32, per, wino_mode_env());
   else

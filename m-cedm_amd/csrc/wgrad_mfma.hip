@@ -388,7 +388,10 @@ static int launch_wg(const WgradArgs& a, const float* xact, int* nact, hipStream
   // one full round of resident workgroups (256 CUs x 2): a 1.5-round grid wastes a quarter of the machine.
   // The split factor depends on the conv's shape and the tile count only: same shapes -> same bits.
   int nsplit = wgrad_nsplit_max(a.Cout, a.Ca + a.Cb);
-  if (nsplit > ntiles) nsplit = ntiles;
+  // at least two 64-pixel tiles per split: a split's partial block ([taps][64][64] floats: 147 KB for a 3x3 conv) costs a store
+  // here and a read in the reduction -- with one tile per split (3x3 convs at 16^2, B = 32: 128 splits) the kernel wrote and the
+  // reduction re-read 75 MB for 2.4 GFLOP of matrix work
+  if (nsplit > ntiles / 2) nsplit = ntiles / 2;
   if (nsplit < 1) nsplit = 1;
   const int cop = ctiles * 64, cip = itiles * 64;
   if (nact) *nact = ceil_div(ntiles, ceil_div(ntiles, nsplit));     // splits that own at least one tile (the others do not store)

@@ -274,8 +274,10 @@ def test_s128_network_training_step_at_a_winograd_size_vs_oracle(lib):
     finally:
         lib.prof_enable(False)
     names = rows
-    n_plain = rows.get("conv_wino_kernel<WinoCfg<4>, false>", 0)
-    n_up = rows.get("conv_wino_kernel<WinoCfg<4>, true>", 0)
+    n_plain = sum(v for k, v in rows.items() if k.startswith("conv_wino_kernel<WinoCfg<4>, false"))      # with / without activation
+    n_up = sum(v for k, v in rows.items() if k.startswith("conv_wino_kernel<WinoCfg<4>, true"))
+    assert rows.get("conv_wino_kernel<WinoCfg<4>, false, false>", 0) >= 8, rows      # the data-gradient convs: no activation
+    assert rows.get("wgrad_wino_kernel", 0) >= 8, rows                              # the 128-channel 3x3 weight gradients
     # forward convs of the 64^2 and 32^2 levels and, in the backward, their data-gradient convs
     assert n_plain >= 20 and n_up >= 1, (n_plain, n_up, names)
     close(loss, ref_loss.detach().reshape(1), what="loss")
