@@ -297,9 +297,14 @@ int launch_small_gemm(const float* A, const float* Bm, float* Cm, int M, int N, 
 // =========================================================================================================
 #define MCEDM_KEY_OF(r, h) ((r & 3) + 8 * (r >> 2) + 4 * (h))
 
-__global__ __launch_bounds__(64) void attn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ a,
-                                                            const float* __restrict__ da, float* __restrict__ lse, int T) {
-  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+// KW waves per workgroup take the key tiles w, w + KW, ... of the SAME 32-query tile and their (running max, sum) pairs meet in
+// LDS, merged by wave 0 in wave order (round 5: one wave per tile was 512 waves per launch at T = 256, B = 32, two heads -- half a
+// wave per SIMD with every K load and every exp chain exposed: 107 us for 0.5 GFLOP)
+template <int KW>
+__global__ __launch_bounds__(64 * KW) void attn_bwd_stats_kernel(const float* __restrict__ qkv, const float* __restrict__ a,
+                                                                 const float* __restrict__ da, float* __restrict__ lse, int T) {
+  __shared__ float ml[KW][2][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * 32;
   const size_t bh = blockIdx.y;
   const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
@@ -311,11 +316,11 @@ __global__ __launch_bounds__(64) void attn_bwd_stats_kernel(const float* __restr
   for (int s = 0; s < 32; ++s) {
     const size_t o = (size_t)(2 * s + h) * T + qc;
     qreg[s] = Q[o] * 0.125f;
-    delta += da[bh * 64 * (size_t)T + o] * a[bh * 64 * (size_t)T + o];
+    if (wave == 0) delta += da[bh * 64 * (size_t)T + o] * a[bh * 64 * (size_t)T + o];
   }
   delta += __shfl_xor(delta, 32);
   float m = -INFINITY, l = 0.f;
-  for (int k0 = 0; k0 < T; k0 += 32) {
+  for (int k0 = 32 * wave; k0 < T; k0 += 32 * KW) {
     const int kk = k0 + l31, kc = kk < T ? kk : T - 1;
     f32x16 sc;
 #pragma unroll
@@ -337,6 +342,19 @@ __global__ __launch_bounds__(64) void attn_bwd_stats_kernel(const float* __restr
     rs += __shfl_xor(rs, 32);
     l = l * expf(m - mn) + rs;
     m = mn;
+  }
+  if (KW > 1) {
+    if (h == 0) { ml[wave][0][l31] = m; ml[wave][1][l31] = l; }
+    __syncthreads();
+    if (wave > 0) return;
+    m = -INFINITY; l = 0.f;
+#pragma unroll
+    for (int w = 0; w < KW; ++w) {                          // wave order: a fixed order (a wave without key tiles holds (-inf, 0))
+      const float mw = ml[w][0][l31], lw = ml[w][1][l31];
+      const float mn = fmaxf(m, mw);
+      if (mn > -INFINITY) l = l * expf(m - mn) + lw * expf(mw - mn);
+      m = mn;
+    }
   }
   if (q < T && h == 0) {
     lse[(bh * T + q) * 2] = m + logf(l);
@@ -518,7 +536,9 @@ int launch_attention_bwd(const float* qkv, const float* a, const float* da, floa
   MCEDM_REQUIRE(B > 0 && heads > 0 && T > 0 && (long long)B * heads <= 65535, "attention_bwd: bad shape");
   const dim3 grid(ceil_div(T, 32), B * heads);
   ProfScope ps("attention_bwd", 10.0 * B * heads * (double)T * T * 64, 4.0 * 8 * B * heads * 64.0 * T, s);
-  hipLaunchKernelGGL(attn_bwd_stats_kernel, grid, dim3(64), 0, s, qkv, a, da, lse, T);
+  if (T >= 128) hipLaunchKernelGGL(attn_bwd_stats_kernel<4>, grid, dim3(256), 0, s, qkv, a, da, lse, T);
+  else if (T >= 64) hipLaunchKernelGGL(attn_bwd_stats_kernel<2>, grid, dim3(128), 0, s, qkv, a, da, lse, T);
+  else hipLaunchKernelGGL(attn_bwd_stats_kernel<1>, grid, dim3(64), 0, s, qkv, a, da, lse, T);
   MCEDM_LAUNCH_CHECK("attn_bwd_stats_kernel");
   // split factor: a function of T only (never of the batch size)
   if (T >= 128) {
