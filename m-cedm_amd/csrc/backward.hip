@@ -81,6 +81,7 @@ __global__ void colsum_kernel(const float* __restrict__ A, int rows, int cols, i
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float s = 0.f;
+#pragma unroll 8
   for (int r = 0; r < rows; ++r) s += A[(size_t)r * lda + c];
   out[c] = s;
 }
