@@ -282,3 +282,60 @@ def test_dx_conditioned_network_at_full_size(mode):
         for n, g_ in zip(plan.param_names, grads):
             if n.startswith(("dx_enc.", "combine_enc.")):
                 assert float(g_.abs().max()) > 0, n
+
+
+# ---- config 2 at ITS batch (64 states of 32 x 32 on one GPU), config 5 with ITS 32 resampling loops -----
+def test_config2_batch_64_against_oracle():
+    """BASELINE config 2 as bench.py runs it -- the reference's ch = 64 network on 64 states of 32 x 32, 18 Heun steps -- against
+    the oracle on the SAME batch (every state, every mask kind), not on a 4- or 6-state stand-in: the kernels the batch of 64
+    selects (one round of `WinoCfg<2>` workgroups at 32^2, the input-resident tiles below) are the ones compared."""
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd import lib
+    cfg = fx.CFG_P
+    plan = lib.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks, cfg.attn_resolutions,
+                    cfg.resolution)
+    P = orc.make_params(cfg, 7)
+    packed = plan.pack({k: v.cuda() for k, v in P.items()})
+    B, S = 64, 32
+    g = torch.Generator().manual_seed(64)
+    state = torch.randn(B, 2, S, S, generator=g)
+    kinds = ("u", "h", "h_time")
+    m = torch.cat([fx.task_mask(kinds[i % 3], 1, S, S) for i in range(B)])
+    cond = state * (1 - m) + torch.randn(B, 2, S, S, generator=g) * m
+    init = torch.randn(B, 2, S, S, generator=g)
+    sp = orc.SamplerParams(timesteps=18)
+    xs = plan.sample(packed, lib.sampler_desc(sp), cond.cuda(), m.cuda(), init.cuda(), None)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    with torch.no_grad():
+        ref = orc.sample_edm(P, cfg, cond, m, sp, init)
+    print(f"config 2, 64 states: max|d| = {float((xs.cpu() - ref).abs().max()):.3e} on max|x| = {float(ref.abs().max()):.2f}")
+    torch.testing.assert_close(xs.cpu(), ref, rtol=1e-4, atol=1e-5)
+    obs = (m == 0).permute(0, 2, 3, 1)
+    assert torch.equal(xs[:, 0].cpu()[obs], cond.permute(0, 2, 3, 1).double()[obs])
+
+
+def test_repaint_with_all_32_resampling_loops_against_oracle():
+    """BASELINE config 5's loop count -- n_repeat = 32 resampling loops per Heun step (README.md:60-61, configs/diff_sampler/
+    edm_sampler_inv.yaml) -- on the DDPM U-Net at 32 x 32 so that the oracle finishes in seconds: 3 steps x 32 loops = 160
+    evaluations, every intermediate state of the outer loop against its own magnitude."""
+    import mcedm_amd  # noqa: F401
+    from mcedm_amd import lib
+    c = dorc.DdpmConfig(resolution=32, attn_resolutions=(8,))
+    plan = lib.DdpmPlan(c.in_channels, c.out_ch, c.ch, c.ch_mult, c.num_res_blocks, c.attn_resolutions, c.resolution)
+    P = dorc.make_params(c, 23)
+    packed = plan.pack({k: v.cuda() for k, v in P.items()}, dorc.timestep_freqs(c.ch).cuda())
+    B, N, R, S = 2, 3, 32, 32
+    sp = dorc.RepaintParams(timesteps=N, n_repeat=R, S_churn=0.0, n_time_h=0, n_time_u=16)
+    betas = dorc.betas_of(c)
+    rd, keep = lib.repaint_desc(sp, dorc.edm_steps_of(betas), dorc.alphas_ext_of(betas), 1, 1)
+    g = torch.Generator().manual_seed(32)
+    hu = torch.randn(B, 2, S, S, generator=g)
+    init = torch.randn(B, 2, S, S, generator=g)
+    steps = torch.randn(N, B, 2, S, S, generator=g).double()
+    reps = torch.randn(N, R - 1, B, 2, S, S, generator=g).double()
+    xs = plan.repaint_sample(packed, rd, hu.cuda(), init.cuda(), None, reps.cuda(), return_last=False)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    with torch.no_grad():
+        ref = dorc.sample_edm_repaint(P, c, hu, sp, init, [s for s in steps], [[r for r in rr] for rr in reps], return_last=False)
+    print(f"repaint, 32 loops: max|d| = {float((xs.cpu() - ref).abs().max()):.3e} on max|x| = {float(ref.abs().max()):.1f}")
+    close_per_entry(xs, ref, what="repaint with 32 resampling loops")
