@@ -664,6 +664,30 @@ def main():
                                       "dominant_kernel": ro["kernel"], "dominant_kernel_tflops": ro["achieved"],
                                       "dominant_kernel_frac": ro["frac"], "dominant_kernel_share": ro["share_of_kernel_time"]}
             line["secondary"][key].update(fractions(key, r2.B / dt, line["secondary"][key]["unet_fwd_ms"], r2.B, r2.nfe))
+            if key in ("s32", "ref128") and not args.no_train:
+                # config 2 is "train + sample": one optimisation step of this network (noise, forward, loss, backward, clip, Adam,
+                # EMA; the fused trainer) at the workload's batch, 1 warm-up + 3 steps
+                try:
+                    from mcedm_amd.train import FlatTrainState
+                    gen = torch.Generator(device="cpu").manual_seed(11)
+                    xs2 = torch.randn(r2.B, 2, r2.H, r2.W, generator=gen).to(device)
+                    nz2 = torch.randn(r2.B, 2, r2.H, r2.W, generator=gen).to(device)
+                    rn2 = torch.randn(r2.B, generator=gen).to(device)
+                    ts2 = FlatTrainState(r2.plan, r2.params, packed=r2.packed)
+                    ts2.step(xs2, r2.cond, r2.mask, nz2, rn2)
+                    torch.cuda.synchronize()
+                    t3 = time.perf_counter()
+                    for _ in range(3):
+                        l2 = ts2.step(xs2, r2.cond, r2.mask, nz2, rn2)
+                    torch.cuda.synchronize()
+                    tms = (time.perf_counter() - t3) / 3 * 1e3
+                    assert torch.isfinite(l2).all()
+                    gf = ALGORITHMIC[key][0]
+                    line["secondary"][key].update({"train_step_ms": tms, "train_samples_per_sec": r2.B / (tms * 1e-3),
+                                                   "train_fp32_frac": 3 * gf * 1e9 * r2.B / (tms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS})
+                    del ts2
+                except Exception as e:                                   # an extra of the line: never fatal
+                    line["secondary"][key]["train_error"] = f"{type(e).__name__}: {str(e)[:200]}"
             del r2
             torch.cuda.empty_cache()
 

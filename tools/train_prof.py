@@ -9,7 +9,7 @@ from oracle import mcedm_oracle as orc
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "s128"
 cfg = orc.UNetConfig(ch=128, ch_mult=(1, 1, 1, 1), attn_resolutions=(16,)) if wl == "s128" else orc.UNetConfig()
-B, H, W = (32, 128, 128) if wl == "s128" else (64, 32, 32)
+B, H, W = (32, 128, 128) if wl in ("s128", "ref128") else (64, 32, 32)
 dev = torch.device("cuda")
 plan = lib.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks, cfg.attn_resolutions, cfg.resolution)
 params = {k: v.to(dev) for k, v in orc.make_params(cfg, 7).items()}
