@@ -1,5 +1,7 @@
 // bwd_kernels.hip -- K10b: backward of GroupNorm+FiLM+SiLU(+2x resampling), parameter-gradient reductions,
 // the tiny dense products of the embedding MLP backward, and the attention backward (flash-style recompute).
+#include <cstdlib>
+
 #include "bwd.hpp"
 #include "prof.hpp"
 
@@ -532,6 +534,180 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(const float* __re
   }
 }
 
+// ---- T % 128 == 0: the streamed operand staged in LDS, shared by the four waves of a workgroup (round 5) ---------------------
+// The kernels above read every MFMA operand of the streamed axis straight from global memory: one dword load per lane and MFMA
+// (96 per 32-key tile), and a CU accepts a vector-memory instruction every ~25 cycles whatever its width -- 18.9 TFLOP/s at
+// T = 1024 (the reference network's attention at 32^2: 4.5 ms of its 25 ms training step).  Here a workgroup = four 32-token
+// tiles of the kept axis (one per wave) x the SAME 32-token chunks of the streamed axis: a chunk is fetched once per workgroup
+// with two 16-byte loads per thread and tensor, written to LDS in the two layouts its two uses need ([channel][token] for the
+// first GEMMs, [token][channel] at pitch 65 for the second: both conflict-free), double-buffered, one barrier per chunk; the
+// MFMA operands are LDS dwords.  Same sums in the same order per output element as the kernels above except that a wave now
+// walks ALL chunks in ascending order instead of every fourth (no cross-wave merge): deterministic, batch independent.
+constexpr int ATP = 65;                    // pitch of the transposed chunk images
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
+                                                              const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
+  __shared__ float Kc[2][64 * 32], Vc[2][64 * 32], Kt[2][32 * ATP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const size_t bh = blockIdx.y;
+  const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
+  const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
+  const float* dA = da + bh * 64 * (size_t)T;
+  const int q = blockIdx.x * 128 + 32 * wave + l31;
+  float qreg[32], dareg[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    qreg[s] = Q[(size_t)(2 * s + h) * T + q] * 0.125f;
+    dareg[s] = dA[(size_t)(2 * s + h) * T + q];
+  }
+  const float L = lse[(bh * T + q) * 2], delta = lse[(bh * T + q) * 2 + 1];
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  // staging: thread -> (channel c, key quad kq) of the chunk, two of them per tensor
+  f32x4 rk[2], rv[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 256 * j, c = idx >> 3, kq = idx & 7;
+      rk[j] = *reinterpret_cast<const f32x4*>(K + (size_t)c * T + k0 + 4 * kq);
+      rv[j] = *reinterpret_cast<const f32x4*>(V + (size_t)c * T + k0 + 4 * kq);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 256 * j, c = idx >> 3, kq = idx & 7;
+      *reinterpret_cast<f32x4*>(&Kc[buf][c * 32 + 4 * kq]) = rk[j];
+      *reinterpret_cast<f32x4*>(&Vc[buf][c * 32 + 4 * kq]) = rv[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Kt[buf][(4 * kq + e) * ATP + c] = rk[j][e];
+    }
+  };
+  const int nch = T / 32;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int n = 0; n < nch; ++n) {
+    const int buf = n & 1;
+    if (n + 1 < nch) fetch(32 * (n + 1));
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kc[buf][(2 * st + h) * 32 + l31], qreg[st], sc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[buf][(2 * st + h) * 32 + l31], dareg[st], dp, 0, 0, 0);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] = expf(sc[r] - L) * (dp[r] - delta);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[buf][MCEDM_KEY_OF(r, h) * ATP + 32 * i + l31], ds[r], o[i], 0, 0, 0);
+    if (n + 1 < nch) commit(buf ^ 1);
+    __syncthreads();
+  }
+  float* dQ = dqkv + (bh * 3 + 0) * 64 * (size_t)T;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQ[(size_t)(32 * i + MCEDM_KEY_OF(r, h)) * T + q] = o[i][r] * 0.125f;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
+                                                               const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
+  __shared__ float Qc[2][64 * 32], Ac[2][64 * 32], Qt[2][32 * ATP], At[2][32 * ATP], Ls[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const size_t bh = blockIdx.y;
+  const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
+  const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
+  const float* dA = da + bh * 64 * (size_t)T;
+  const int key = blockIdx.x * 128 + 32 * wave + l31;
+  float kreg[32], vreg[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    kreg[s] = K[(size_t)(2 * s + h) * T + key];
+    vreg[s] = V[(size_t)(2 * s + h) * T + key];
+  }
+  f32x16 ok[2], ov[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ok[i][r] = 0.f; ov[i][r] = 0.f; }
+  f32x4 rq[2], ra[2];
+  float rl = 0.f;
+  auto fetch = [&](int q0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 256 * j, c = idx >> 3, qq = idx & 7;
+      rq[j] = *reinterpret_cast<const f32x4*>(Q + (size_t)c * T + q0 + 4 * qq);
+      ra[j] = *reinterpret_cast<const f32x4*>(dA + (size_t)c * T + q0 + 4 * qq);
+    }
+    if (tid < 64) rl = lse[(bh * T + q0) * 2 + tid];            // (lse, delta) pairs of the chunk's 32 queries
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + 256 * j, c = idx >> 3, qq = idx & 7;
+      *reinterpret_cast<f32x4*>(&Qc[buf][c * 32 + 4 * qq]) = rq[j] * 0.125f;
+      *reinterpret_cast<f32x4*>(&Ac[buf][c * 32 + 4 * qq]) = ra[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { Qt[buf][(4 * qq + e) * ATP + c] = rq[j][e]; At[buf][(4 * qq + e) * ATP + c] = ra[j][e]; }
+    }
+    if (tid < 64) Ls[buf][tid] = rl;
+  };
+  const int nch = T / 32;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int n = 0; n < nch; ++n) {
+    const int buf = n & 1;
+    if (n + 1 < nch) fetch(32 * (n + 1));
+    f32x16 sc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+      sc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qc[buf][(2 * st + h) * 32 + l31], kreg[st], sc, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[buf][(2 * st + h) * 32 + l31], vreg[st], dp, 0, 0, 0);
+    }
+    float pr[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = MCEDM_KEY_OF(r, h);
+      pr[r] = expf(sc[r] - Ls[buf][2 * qi]);
+      ds[r] = pr[r] * (dp[r] - Ls[buf][2 * qi + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = MCEDM_KEY_OF(r, h);
+        ov[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(At[buf][qi * ATP + 32 * i + l31], pr[r], ov[i], 0, 0, 0);
+        ok[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qt[buf][qi * ATP + 32 * i + l31], ds[r], ok[i], 0, 0, 0);
+      }
+    if (n + 1 < nch) commit(buf ^ 1);
+    __syncthreads();
+  }
+  float* dK = dqkv + (bh * 3 + 1) * 64 * (size_t)T;
+  float* dV = dqkv + (bh * 3 + 2) * 64 * (size_t)T;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const size_t c = 32 * i + MCEDM_KEY_OF(r, h);
+      dK[c * T + key] = ok[i][r] * 0.125f;
+      dV[c * T + key] = ov[i][r];
+    }
+}
+
 int launch_attention_bwd(const float* qkv, const float* a, const float* da, float* dqkv, float* lse, int B, int heads,
                          int T, hipStream_t s) {
   MCEDM_REQUIRE(qkv && a && da && dqkv && lse, "attention_bwd: null pointer");
@@ -543,7 +719,14 @@ int launch_attention_bwd(const float* qkv, const float* a, const float* da, floa
   else hipLaunchKernelGGL(attn_bwd_stats_kernel<1>, grid, dim3(64), 0, s, qkv, a, da, lse, T);
   MCEDM_LAUNCH_CHECK("attn_bwd_stats_kernel");
   // split factor: a function of T only (never of the batch size)
-  if (T >= 128) {
+  static int lds_env = -1;                                 // MCEDM_ATTN_BWD_LDS=0: the direct-from-global kernels at every T (A/B runs)
+  if (lds_env < 0) { const char* e = getenv("MCEDM_ATTN_BWD_LDS"); lds_env = e ? atoi(e) : 1; }
+  if (lds_env && T % 128 == 0 && ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(da)) & 15) == 0) {
+    const dim3 g4(T / 128, B * heads);
+    hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, g4, dim3(256), 0, s, qkv, da, lse, dqkv, T);
+    MCEDM_LAUNCH_CHECK("attn_bwd_dq_lds_kernel");
+    hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, g4, dim3(256), 0, s, qkv, da, lse, dqkv, T);
+  } else if (T >= 128) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, dim3(256), 0, s, qkv, da, lse, dqkv, T);
     MCEDM_LAUNCH_CHECK("attn_bwd_dq_kernel");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, grid, dim3(256), 0, s, qkv, da, lse, dqkv, T);

@@ -173,7 +173,8 @@ def test_attention_backward_golden(lib, golden, T):
     close(unpacked_qkv(dqkv.cpu(), 2), g[f"attn{T}_dqkv"], what=f"dqkv T={T}")
 
 
-@pytest.mark.parametrize("B,heads,hw", [(1, 1, (6, 6)), (2, 1, (32, 32)), (1, 2, (2, 2))])
+@pytest.mark.parametrize("B,heads,hw", [(1, 1, (6, 6)), (2, 1, (32, 32)), (1, 2, (2, 2)),
+                                        (2, 2, (16, 16)), (1, 1, (8, 16)), (3, 1, (16, 24))])      # T = 256, 128 (LDS-staged kernels), 384
 def test_attention_backward_vs_oracle(lib, B, heads, hw):
     qkv = fx.randn(f"t/bwd/attn/{B}{heads}{hw}", B, heads * 192, *hw).requires_grad_(True)
     da = fx.randn(f"t/bwd/attn/da/{B}{heads}{hw}", B, heads * 64, *hw)
