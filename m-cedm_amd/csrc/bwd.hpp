@@ -21,7 +21,7 @@ size_t wgrad_scratch_floats(int Cout, int Cin, int taps);
 // by the GroupNorm backward of the same input, GnBwdArgs::xact: one pass over x less)
 int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_heads, float* act_tmp, hipStream_t s,
                  bool have_act = false);
-// wgrad_wino.hip: the un-resampled 3x3 weight gradient in Winograd F(3x3, 2x2) form (Cout, Cin multiples of 128, W % 32 == 0).
+// wgrad_wino.hip: the un-resampled 3x3 weight gradient in Winograd F(3x3, 2x2) form (Cout, Cin multiples of 128 and W % 32 == 0, or multiples of 64 and W % 16 == 0).
 // x: the materialised conv input [B][Cin][H][W]; the 16 bytes in FRONT of it must be readable (launch_wgrad passes act_tmp).
 bool wgrad_wino_applicable(const WgradArgs& a, int taps, int qkv_heads);
 size_t wgrad_wino_scratch_floats(int Cout, int Cin, int taps);     // 0 when the channel counts are not served

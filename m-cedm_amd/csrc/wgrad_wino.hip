@@ -278,37 +278,211 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgWinoArgs p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 64-channel form (the reference's own ch = 64 network, adm_edm_mcedm_res32: every 3x3 conv is 64 -> 64 or 128 -> 64).
+// With 64 x 64 channels per workgroup the whole 4 x 4 position grid fits one CU: wave w owns xi = w >> 1, 32 output channels
+// (w & 1) x 64 input channels x four nu = 8 accumulator blocks.  A stage is 8 tiles (16 output pixels of one row pair: W % 16
+// == 0); an X' task is (channel, tile) with all four rows of the 4x4 tile (16 values out), a dY task is (channel, quad, half of
+// the xi rows).  LDS [position 16][channel 64][8 tiles], the two 16-byte slots of a channel swapped by (channel >> 3) & 1:
+// the same 64 KB per stage, the same conflict-free reads and writes, one barrier per stage (32 MFMAs per wave).
+constexpr int G6_T = 8;
+constexpr int G6_CB = 64;
+constexpr int G6_PLANE = G6_CB * G6_T;         // floats per (position, operand)
+constexpr int G6_OP = 16 * G6_PLANE;           // floats per operand and stage
+constexpr int G6_STAGE = 2 * G6_OP;            // 64 KB
+
+__global__ __launch_bounds__(512, 1) void wgrad_wino64_kernel(const WgWinoArgs p) {
+  extern __shared__ float lds[];
+  const int nsib = p.cib * p.cob;
+  const int bid = blockIdx.x;
+  const int grp8 = bid / (8 * nsib), rem = bid - grp8 * 8 * nsib;
+  const int sib = rem >> 3, split = grp8 * 8 + (rem & 7);
+  if (split >= p.nact) return;
+  const int cb_i = sib % p.cib, cb_o = sib / p.cib;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xi = wave >> 1, coh = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int s_begin = split * p.per;
+  const int s_end = s_begin + p.per < p.total ? s_begin + p.per : p.total;
+  if (s_begin >= s_end) return;
+  const int G = s_end - s_begin;
+  const unsigned HW = (unsigned)p.H * p.W;
+  const unsigned W4 = 4u * (unsigned)p.W;
+  const int co0 = cb_o * G6_CB, ci0 = cb_i * G6_CB;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x - 4, 4u * (unsigned)p.B * p.Ci * HW + 16u);      // see wgw_body
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.dy, 4u * (unsigned)p.B * p.Co * HW);
+
+  // X' task: tile xt = tid & 7 of channel tid >> 3 (a wave: 8 channels, (channel >> 3) & 1 == wave & 1)
+  const int xt = tid & 7;
+  const unsigned xlb = 4u * ((unsigned)(tid >> 3) * HW + (unsigned)(2 * xt + 3));
+  const int xdst = (tid >> 3) * G6_T + 4 * ((xt >> 2) ^ (wave & 1)) + (xt & 3);
+  // dY task: quad yq = tid & 3 (tiles 2 yq, 2 yq + 1) of channel (tid & 255) >> 2; waves 0-3 write the rows xi = 0, 1, waves 4-7 xi = 3, 2
+  const int yq = tid & 3, yc = (tid & 255) >> 2;
+  const int yh = wave >> 2;
+  const unsigned ylb = 4u * ((unsigned)yc * HW + 4u * yq);
+  const int ydst = G6_OP + yc * G6_T + 4 * ((yq >> 1) ^ ((yc >> 3) & 1)) + 2 * (yq & 1);
+  const int xiP = yh ? 3 : 0, xiQ = yh ? 2 : 1;
+  // MFMA fragments: lane (l31, h) reads slot h of its channel: k-step s <-> tile 4 h + s
+  const int fo = l31 * G6_T + 4 * (h ^ ((l31 >> 3) & 1));
+
+  int lst = s_begin;
+  int lseg = lst % p.nseg, lty = (lst / p.nseg) % p.th, ln = lst / (p.nseg * p.th);
+  unsigned g_x1, g_up, g_dn, g_y; float g_mt, g_mb; bool g_l, g_r;
+  auto set_geo = [&]() {
+    g_x1 = 4u * ((unsigned)(ln * p.Ci + ci0) * HW + (unsigned)(2 * lty) * p.W + (unsigned)lseg * 16u);   // row 2 ty
+    g_up = lty == 0 ? 0u : W4;               // row 2 ty - 1 = g_x1 - g_up (the top tile row reads row 0 again and drops it)
+    g_dn = lty == p.th - 1 ? W4 : 2u * W4;   // row 2 ty + 2 = g_x1 + g_dn (the bottom tile row reads row H - 1 again)
+    g_mt = lty == 0 ? 0.f : 1.f; g_mb = lty == p.th - 1 ? 0.f : 1.f;
+    g_y = 4u * ((unsigned)(ln * p.Co + co0) * HW + (unsigned)(2 * lty) * p.W + (unsigned)lseg * 16u);
+    g_l = lseg == 0; g_r = lseg == p.nseg - 1;
+  };
+  auto advance = [&]() {
+    if (lst + 1 < s_end) {
+      ++lst;
+      if (++lseg == p.nseg) { lseg = 0; if (++lty == p.th) { lty = 0; ++ln; } }
+    }
+    set_geo();
+  };
+  set_geo();
+  float c_mt = 1.f, c_mb = 1.f;
+  unsigned ml = ~0u, mr = ~0u;
+  auto take_masks = [&]() { c_mt = g_mt; c_mb = g_mb; ml = (xt == 0 && g_l) ? 0u : ~0u; mr = (xt == G6_T - 1 && g_r) ? 0u : ~0u; };
+
+  f32x4 xr[4], yr[2];
+  auto load_x = [&]() {
+    xr[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xlb + (g_x1 - g_up), 0, 0));
+    xr[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xlb + g_x1, 0, 0));
+    xr[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xlb + (g_x1 + W4), 0, 0));
+    xr[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xlb + (g_x1 + g_dn), 0, 0));
+  };
+  auto load_y = [&]() {
+    yr[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, ylb + g_y, 0, 0));
+    yr[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, ylb + (g_y + W4), 0, 0));
+  };
+  auto x_row = [&](const f32x4 r, float* d) {                 // B^T along the columns of one transformed row -> nu = 0..3
+    const float e0 = r[0], e3 = r[3];
+    const float r0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e0) & ml);
+    const float r3 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e3) & mr);
+    d[0 * G6_PLANE] = r0 - r[2];
+    d[1 * G6_PLANE] = r[1] + r[2];
+    d[2 * G6_PLANE] = r[2] - r[1];
+    d[3 * G6_PLANE] = r[1] - r3;
+  };
+  auto commit_x = [&](float* sb) {
+    float* d = sb + xdst;
+    x_row(xr[0] * c_mt - xr[2], d);
+    x_row(xr[1] + xr[2], d + 4 * G6_PLANE);
+    x_row(xr[2] - xr[1], d + 8 * G6_PLANE);
+    x_row(xr[1] - xr[3] * c_mb, d + 12 * G6_PLANE);
+  };
+  auto y_row = [&](const f32x4 s, float* d) {                 // G' along the columns of both tiles
+    *reinterpret_cast<f32x2*>(d + 0 * G6_PLANE) = f32x2{s[0], s[2]};
+    *reinterpret_cast<f32x2*>(d + 1 * G6_PLANE) = f32x2{s[0] + s[1], s[2] + s[3]};
+    *reinterpret_cast<f32x2*>(d + 2 * G6_PLANE) = f32x2{s[0] - s[1], s[2] - s[3]};
+    *reinterpret_cast<f32x2*>(d + 3 * G6_PLANE) = f32x2{s[1], s[3]};
+  };
+  float bsum = 0.f;
+  auto commit_y = [&](float* sb, bool bias) {
+    const f32x4 a = yr[0], b = yr[1];
+    const f32x4 P = yh ? b : a;                               // rows xi = 0 / 3 of G' dY
+    const f32x4 Q = yh ? a - b : a + b;                       // rows xi = 1 / 2
+    y_row(P, sb + ydst + xiP * 4 * G6_PLANE);
+    y_row(Q, sb + ydst + xiQ * 4 * G6_PLANE);
+    if (bias) bsum += (Q[0] + Q[1]) + (Q[2] + Q[3]);
+  };
+  const bool do_bias = yh == 0 && cb_i == 0 && p.dbp != nullptr;
+
+  load_x(); load_y();
+  take_masks();
+  advance();
+  commit_x(lds); commit_y(lds, do_bias);
+  load_x(); load_y();
+  take_masks();
+  advance();
+
+  f32x16 acc[4][2];
+  {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("" : "+v"(z));
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, z, zero16, 0, 0, 0);
+      }
+  }
+  __syncthreads();
+
+  // one trip = one stage: 4 slots (nu) of [fragments of the next slot | 8 MFMAs | a slice of side work on the OTHER buffer]
+  for (int g = 0; g < G; ++g) {
+    const int cur = g & 1;
+    const float* fx = lds + cur * G6_STAGE + xi * 4 * G6_PLANE + fo;
+    const float* fy = fx + G6_OP + coh * 32 * G6_T;
+    float* nbuf = lds + (cur ^ 1) * G6_STAGE;
+    const bool cvalid = g + 1 < G;
+    f32x4 a = *reinterpret_cast<const f32x4*>(fy);
+    f32x4 b0 = *reinterpret_cast<const f32x4*>(fx);
+    f32x4 b1 = *reinterpret_cast<const f32x4*>(fx + 32 * G6_T);
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      f32x4 an = a, b0n = b0, b1n = b1;
+      if (nu < 3) {
+        an = *reinterpret_cast<const f32x4*>(fy + (nu + 1) * G6_PLANE);
+        b0n = *reinterpret_cast<const f32x4*>(fx + (nu + 1) * G6_PLANE);
+        b1n = *reinterpret_cast<const f32x4*>(fx + (nu + 1) * G6_PLANE + 32 * G6_T);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc[nu][0], 0, 0, 0);
+        acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1[s], acc[nu][1], 0, 0, 0);
+      }
+      if (nu == 0) { commit_x(nbuf); load_x(); }
+      else if (nu == 1) { commit_y(nbuf, do_bias && cvalid); load_y(); }
+      if (nu < 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (nu == 0) __builtin_amdgcn_sched_group_barrier(0x286, 9, 0);           // VALU | SALU | DS write
+        else __builtin_amdgcn_sched_group_barrier(0x286, 5, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (nu == 2) { take_masks(); advance(); }
+      __builtin_amdgcn_sched_barrier(0);
+      a = an; b0 = b0n; b1 = b1n;
+    }
+    __syncthreads();
+  }
+
+  float* out = p.part + ((size_t)split * 16 + xi * 4) * p.cop * p.cip;
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ci = ci0 + 32 * j + l31;
+        out[((size_t)nu * p.cop + co) * p.cip + ci] = acc[nu][j][r];
+      }
+  if (do_bias) {
+    float v = bsum;
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);
+    if (yq == 0) p.dbp[(size_t)split * p.cop + co0 + yc] = v;
+  }
+}
+
 // dW[co][ci][a][b] = sum_{xi, nu} A^T[a][xi] A^T[b][nu] c[xi] c[nu] sum_split part[split][xi][nu][co][ci]
 //   A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]   (the last column carries the sign of B^T's last row (0,1,0,-1))
 //   c = (1, 1/2, 1/2, 1): the halves of G = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]] that the kernel's transform leaves out.
-// One workgroup per (co, 64 input channels): thread (p, ci) sums position p over the splits in split order in fp64 (four
-// interleaved chains: a fixed order), the 16 sums meet in LDS, threads (tap, ci) apply A^T . A.  db[co] = sum_split dbp.
-__global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbp,
-                                                                 float* __restrict__ dw, float* __restrict__ db, int Cout, int Cin,
-                                                                 int cop, int cip, int nact) {
-  __shared__ double m[16][64];
-  const int tid = threadIdx.x, cl = tid & 63, pos = tid >> 6;
-  const int citiles = cip / 64;
-  const int co = blockIdx.x / citiles, ci = (blockIdx.x % citiles) * 64 + cl;
-  const size_t block = (size_t)16 * cop * cip;
-  const float* src = part + ((size_t)pos * cop + co) * cip + ci;
-  // eight interleaved chains (split s goes to chain s mod 8), combined in a fixed order: the eight loads of a trip are independent
-  // and stay in flight together (four chains: 2.7 TB/s on the 67 MB of partial blocks)
-  double ch[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  int sp = 0;
-  for (; sp + 8 <= nact; sp += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(sp + u) * block];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) ch[u] += (double)v[u];
-  }
-  for (int u = 0; sp < nact; ++sp, ++u) ch[u] += (double)src[(size_t)sp * block];
-  const double s0 = ch[0] + ch[4], s1 = ch[1] + ch[5], s2 = ch[2] + ch[6], s3 = ch[3] + ch[7];
-  const int xi = pos >> 2, nu = pos & 3;
-  const double cs = ((xi == 1 || xi == 2) ? 0.5 : 1.0) * ((nu == 1 || nu == 2) ? 0.5 : 1.0);
-  m[pos][cl] = ((s0 + s1) + (s2 + s3)) * cs;
-  __syncthreads();
+// One workgroup per (co, 64 input channels, slice of the splits): thread (p, ci) sums position p over the splits slice, slice + nsl,
+// ... in fp64 (eight interleaved chains: a fixed order).  nsl == 1 (layers with >= 256 such blocks): the 16 sums meet in LDS and
+// threads (tap, ci) apply A^T . A.  nsl > 1 (a 64 x 64 layer has only 64 blocks: 1 TB/s): the slice sums go to `mid`
+// [slice][16][co][ci] in fp64 and wgrad_wino_finish_kernel adds them in slice order.  db[co] = sum_split dbp.
+__device__ __forceinline__ void wgw_taps(const double (*m)[64], int tid, int cl, int co, int ci, int Cin, float* __restrict__ dw) {
   if (tid < 9 * 64 && ci < Cin) {
     const int tap = tid >> 6, a = tap / 3, b = tap % 3;
     // rows of A^T as (xi, sign) lists: a = 0: +0 +1 +2; a = 1: +1 -2; a = 2: +1 +2 -3
@@ -327,11 +501,68 @@ __global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float* __
     }
     dw[((size_t)co * Cin + ci) * 9 + tap] = (float)r;
   }
-  if (db && blockIdx.x % citiles == 0 && tid == 0) {
-    double s = 0.0;
-    for (int k = 0; k < nact; ++k) s += (double)dbp[(size_t)k * cop + co];
-    db[co] = (float)s;
+}
+__device__ __forceinline__ double wgw_pos_scale(int pos) {
+  const int xi = pos >> 2, nu = pos & 3;
+  return ((xi == 1 || xi == 2) ? 0.5 : 1.0) * ((nu == 1 || nu == 2) ? 0.5 : 1.0);
+}
+// one wave: lane k adds the splits k, k + 64, ... in order, then a fixed shuffle tree (a single thread walking 256 splits was the
+// critical path of the whole reduction: 0.2 us per dependent L2 read)
+__device__ __forceinline__ void wgw_bias(const float* __restrict__ dbp, float* __restrict__ db, int co, int cop, int nact, int lane) {
+  double s = 0.0;
+  for (int k = lane; k < nact; k += 64) s += (double)dbp[(size_t)k * cop + co];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) db[co] = (float)s;
+}
+
+__global__ __launch_bounds__(1024) void wgrad_wino_reduce_kernel(const float* __restrict__ part, const float* __restrict__ dbp,
+                                                                 float* __restrict__ dw, float* __restrict__ db, double* __restrict__ mid,
+                                                                 int Cout, int Cin, int cop, int cip, int nact, int nsl) {
+  __shared__ double m[16][64];
+  const int tid = threadIdx.x, cl = tid & 63, pos = tid >> 6;
+  const int citiles = cip / 64;
+  const int blk = blockIdx.x / nsl, sl = blockIdx.x - blk * nsl;
+  const int co = blk / citiles, ci = (blk % citiles) * 64 + cl;
+  const size_t block = (size_t)16 * cop * cip;
+  const float* src = part + ((size_t)pos * cop + co) * cip + ci;
+  // the eight loads of a trip are independent and stay in flight together (four chains: 2.7 TB/s on the 67 MB of partial blocks)
+  double ch[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const size_t step = (size_t)nsl * block;
+  int sp = sl;
+  for (; sp + 7 * nsl < nact; sp += 8 * nsl) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)sp * block + u * step];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ch[u] += (double)v[u];
   }
+  for (int u = 0; sp < nact; sp += nsl, ++u) ch[u] += (double)src[(size_t)sp * block];
+  const double s0 = ch[0] + ch[4], s1 = ch[1] + ch[5], s2 = ch[2] + ch[6], s3 = ch[3] + ch[7];
+  const double tot = (s0 + s1) + (s2 + s3);
+  if (nsl > 1) {
+    mid[(((size_t)sl * 16 + pos) * cop + co) * cip + ci] = tot;
+  } else {
+    m[pos][cl] = tot * wgw_pos_scale(pos);
+    __syncthreads();
+    wgw_taps(m, tid, cl, co, ci, Cin, dw);
+  }
+  if (db && blockIdx.x % (citiles * nsl) == 0 && tid < 64) wgw_bias(dbp, db, co, cop, nact, tid);
+}
+
+__global__ __launch_bounds__(1024) void wgrad_wino_finish_kernel(const double* __restrict__ mid, float* __restrict__ dw, int Cin, int cop,
+                                                                 int cip, int nsl) {
+  __shared__ double m[16][64];
+  const int tid = threadIdx.x, cl = tid & 63, pos = tid >> 6;
+  const int citiles = cip / 64;
+  const int co = blockIdx.x / citiles, ci = (blockIdx.x % citiles) * 64 + cl;
+  const size_t block = (size_t)16 * cop * cip;
+  const double* src = mid + ((size_t)pos * cop + co) * cip + ci;
+  double t = src[0];
+  for (int k = 1; k < nsl; ++k) t += src[(size_t)k * block];
+  m[pos][cl] = t * wgw_pos_scale(pos);
+  __syncthreads();
+  wgw_taps(m, tid, cl, co, ci, Cin, dw);
 }
 
 static int g_wgw = -1;       // -1: default (env MCEDM_WGRAD_WINO, else on); 0 / 1: forced by mcedm_op_set_wgrad_wino
@@ -342,46 +573,96 @@ static int wgw_env() {
   return variant_choice(KV_WGRAD_WINO, g_wgw, env);
 }
 
-// splits of the K range: one round of one workgroup per CU over the 4 * cib * cob siblings, a multiple of 8 (XCD mapping).
-// A function of the channel counts only, so that the scratch can be sized at plan time.
-static int wgw_nsplit(int Cout, int Cin) {
-  const int nsib = 4 * (Cout / GW_CB) * (Cin / GW_CB);
+static int wgw64_env() {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_WGRAD_WINO64"); env = e ? atoi(e) : 1; }
+  return env;
+}
+
+// splits of the K range: one round of one workgroup per CU over the siblings of a split (4 * cib * cob in the 128-channel form,
+// cib * cob in the 64-channel form), a multiple of 8 (XCD mapping).  A function of the channel counts only, so that the scratch
+// can be sized at plan time.
+static int wgw_nsplit(int nsib) {
   int ns = 256 / nsib;
   ns = ns / 8 * 8;
   return ns < 8 ? 8 : ns;
 }
-bool wgrad_wino_shape_ok(int Cout, int Cin, int taps) { return taps == 9 && Cout % GW_CB == 0 && Cin % GW_CB == 0 && Cout > 0 && Cin > 0; }
+// 0: not served, 1: the 128-channel form (one xi per workgroup), 2: the 64-channel form (all 16 positions per workgroup)
+static int wgw_form_of(int Cout, int Cin, int taps, int W) {
+  if (taps != 9 || Cout <= 0 || Cin <= 0) return 0;
+  if (Cout % GW_CB == 0 && Cin % GW_CB == 0 && W % 32 == 0) return 1;
+  if (Cout % G6_CB == 0 && Cin % G6_CB == 0 && W % 16 == 0 && wgw64_env()) return 2;
+  return 0;
+}
+// slices of the split range in the reduction: at least 256 workgroups of (co, 64 ci, slice); 1: no second kernel
+static int wgw_reduce_slices(int Cout, int Cin) {
+  const int blocks = Cout * (Cin / 64);
+  if (blocks >= 256 || blocks < 1) return 1;
+  const int n = (256 + blocks - 1) / blocks;
+  return n > 8 ? 8 : n;
+}
+static int wgw_form_nsplit(int form, int Cout, int Cin) {
+  return form == 1 ? wgw_nsplit(4 * (Cout / GW_CB) * (Cin / GW_CB)) : wgw_nsplit((Cout / G6_CB) * (Cin / G6_CB));
+}
+static size_t wgw_part_floats(int Cout, int Cin) {        // partial blocks + bias partials of the form with the larger split count
+  const size_t per = (size_t)16 * Cout * Cin + Cout;
+  size_t need = 0;
+  if (Cout % GW_CB == 0 && Cin % GW_CB == 0) need = (size_t)wgw_form_nsplit(1, Cout, Cin) * per;
+  if (Cout % G6_CB == 0 && Cin % G6_CB == 0 && wgw64_env()) {
+    const size_t n = (size_t)wgw_form_nsplit(2, Cout, Cin) * per;
+    if (n > need) need = n;
+  }
+  return need;
+}
 size_t wgrad_wino_scratch_floats(int Cout, int Cin, int taps) {
-  if (!wgrad_wino_shape_ok(Cout, Cin, taps)) return 0;
-  return (size_t)wgw_nsplit(Cout, Cin) * ((size_t)16 * Cout * Cin + Cout);
+  if (taps != 9 || Cout <= 0 || Cin <= 0) return 0;
+  const size_t need = wgw_part_floats(Cout, Cin);
+  if (need == 0) return 0;
+  const int nsl = wgw_reduce_slices(Cout, Cin);
+  return need + (nsl > 1 ? 2 * (size_t)nsl * 16 * Cout * Cin : 0);       // + the reduction's fp64 slice sums
 }
 
-bool wgrad_wino_applicable(const WgradArgs& a, int taps, int qkv_heads) {
+static int wgw_form(const WgradArgs& a, int taps, int qkv_heads) {
   const int Cin = a.Ca + a.Cb;
-  if (!wgw_env() || qkv_heads != 0 || !wgrad_wino_shape_ok(a.Cout, Cin, taps)) return false;
-  if (a.W % 32 != 0 || a.H % 2 != 0 || a.H < 2 || a.B < 1) return false;
-  if ((reinterpret_cast<size_t>(a.dy) & 15) != 0) return false;
+  if (!wgw_env() || qkv_heads != 0) return 0;
+  const int form = wgw_form_of(a.Cout, Cin, taps, a.W);
+  if (!form || a.H % 2 != 0 || a.H < 2 || a.B < 1) return 0;
+  if ((reinterpret_cast<size_t>(a.dy) & 15) != 0) return 0;
   const unsigned long long HW = (unsigned long long)a.H * a.W;
-  return 4ull * a.B * Cin * HW + 16 < (1ull << 32) && 4ull * a.B * a.Cout * HW < (1ull << 32);      // 32-bit buffer offsets
+  if (!(4ull * a.B * Cin * HW + 16 < (1ull << 32) && 4ull * a.B * a.Cout * HW < (1ull << 32))) return 0;      // 32-bit buffer offsets
+  // the 64-channel form pays a fixed 16 x Cout x Cin floats per split (store + reduction): with fewer than 4 stages of 8 tiles
+  // per split the direct kernel is as fast or faster (64 -> 64 at 32^2, B = 32: 4 stages, 47 against 46 us; tools/wgrad_wino_ab.py)
+  // (a switch FORCED on -- mcedm_op_set_wgrad_wino(1) or the plan's variant -- serves every legal shape: the parity tests' small cases)
+  if (form == 2 && variant_choice(KV_WGRAD_WINO, g_wgw, -1) != 1) {
+    static int min_per = -1;
+    if (min_per < 0) { const char* e = getenv("MCEDM_WGRAD_WINO64_MIN"); min_per = e ? atoi(e) : 4; }
+    const long long total = (long long)a.B * (a.H / 2) * (a.W / 16);
+    if (total < (long long)min_per * wgw_form_nsplit(2, a.Cout, Cin)) return 0;
+  }
+  return form;
 }
+bool wgrad_wino_applicable(const WgradArgs& a, int taps, int qkv_heads) { return wgw_form(a, taps, qkv_heads) != 0; }
 
 int launch_wgrad_wino(const WgradArgs& a, const float* x, float* dw, float* db, hipStream_t s) {
-  MCEDM_REQUIRE(wgrad_wino_applicable(a, 9, 0), "wgrad_wino: shape not served by the Winograd weight-gradient kernel");
+  const int form = wgw_form(a, 9, 0);
+  MCEDM_REQUIRE(form != 0, "wgrad_wino: shape not served by the Winograd weight-gradient kernels");
   MCEDM_REQUIRE(a.dy && x && a.dwp && dw, "wgrad_wino: null pointer");
   const int Cin = a.Ca + a.Cb;
   const unsigned long long HW = (unsigned long long)a.H * a.W;
+  const int cb = form == 1 ? GW_CB : G6_CB, segw = form == 1 ? 32 : 16;
   WgWinoArgs p{};
   p.dy = a.dy; p.x = x; p.Co = a.Cout; p.Ci = Cin; p.B = a.B; p.H = a.H; p.W = a.W;
-  p.cob = a.Cout / GW_CB; p.cib = Cin / GW_CB; p.cop = a.Cout; p.cip = Cin;
-  p.nseg = a.W / 32; p.th = a.H / 2;
+  p.cob = a.Cout / cb; p.cib = Cin / cb; p.cop = a.Cout; p.cip = Cin;
+  p.nseg = a.W / segw; p.th = a.H / 2;
   p.total = a.B * p.th * p.nseg;
-  int nsplit = wgw_nsplit(a.Cout, Cin);
+  const int nsplit_max = wgw_form_nsplit(form, a.Cout, Cin);
+  int nsplit = nsplit_max;
   if (nsplit > p.total) nsplit = p.total;
   p.per = ceil_div(p.total, nsplit);
   p.nact = ceil_div(p.total, p.per);
   p.part = a.dwp;
-  p.dbp = db ? a.dwp + (size_t)wgw_nsplit(a.Cout, Cin) * 16 * a.Cout * Cin : nullptr;
-  const int nsib = 4 * p.cib * p.cob;
+  p.dbp = db ? a.dwp + (size_t)nsplit_max * 16 * a.Cout * Cin : nullptr;
+  const int nsib = (form == 1 ? 4 : 1) * p.cib * p.cob;
   const int grid = ceil_div(p.nact, 8) * 8 * nsib;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
@@ -389,20 +670,35 @@ int launch_wgrad_wino(const WgradArgs& a, const float* x, float* dw, float* db, 
   MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
   if (!attr_set[dev].load(std::memory_order_acquire)) {
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad_wino64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[dev].store(true, std::memory_order_release);
   }
   {
     const double flops = 2.0 * a.B * (double)HW * a.Cout * Cin * 9;       // algorithmic (the direct form's); 4 / 9 are issued
-    ProfScope ps("wgrad_wino_kernel", flops, 4.0 * a.B * (double)HW * (a.Cout + Cin), s);
-    hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), 2 * GW_STAGE * sizeof(float), s, p);
+    ProfScope ps(form == 1 ? "wgrad_wino_kernel" : "wgrad_wino64_kernel", flops, 4.0 * a.B * (double)HW * (a.Cout + Cin), s);
+    if (form == 1) hipLaunchKernelGGL(wgrad_wino_kernel, dim3(grid), dim3(512), 2 * GW_STAGE * sizeof(float), s, p);
+    else hipLaunchKernelGGL(wgrad_wino64_kernel, dim3(grid), dim3(512), 2 * G6_STAGE * sizeof(float), s, p);
     MCEDM_LAUNCH_CHECK("wgrad_wino_kernel");
   }
   {
     const double elems = 16.0 * a.Cout * Cin;
-    ProfScope ps("wgrad_wino_reduce_kernel", p.nact * elems, 4.0 * (p.nact * elems + 9.0 * a.Cout * Cin), s);
-    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.Cout * (Cin / 64)), dim3(1024), 0, s, p.part, p.dbp, dw, db, a.Cout, Cin, p.cop,
-                       p.cip, p.nact);
-    MCEDM_LAUNCH_CHECK("wgrad_wino_reduce_kernel");
+    int nsl = wgw_reduce_slices(a.Cout, Cin);
+    if (nsl > p.nact) nsl = 1;
+    // the fp64 slice sums live behind the partial blocks and the bias partials of the LARGEST split count these channels can get
+    const size_t mid_off = wgw_part_floats(a.Cout, Cin);
+    double* mid = reinterpret_cast<double*>(a.dwp + mid_off);
+    MCEDM_REQUIRE(nsl == 1 || (reinterpret_cast<size_t>(mid) & 7) == 0, "wgrad_wino: scratch not 8-byte aligned");
+    {
+      ProfScope ps("wgrad_wino_reduce_kernel", p.nact * elems, 4.0 * (p.nact * elems + 9.0 * a.Cout * Cin), s);
+      hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3(a.Cout * (Cin / 64) * nsl), dim3(1024), 0, s, p.part, p.dbp, dw, db, mid, a.Cout, Cin,
+                         p.cop, p.cip, p.nact, nsl);
+      MCEDM_LAUNCH_CHECK("wgrad_wino_reduce_kernel");
+    }
+    if (nsl > 1) {
+      ProfScope ps("wgrad_wino_finish_kernel", nsl * elems, 8.0 * nsl * elems + 36.0 * a.Cout * Cin, s);
+      hipLaunchKernelGGL(wgrad_wino_finish_kernel, dim3(a.Cout * (Cin / 64)), dim3(1024), 0, s, mid, dw, Cin, p.cop, p.cip, nsl);
+      MCEDM_LAUNCH_CHECK("wgrad_wino_finish_kernel");
+    }
   }
   return MCEDM_OK;
 }

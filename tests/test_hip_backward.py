@@ -190,8 +190,10 @@ def make_plan(L, cfg):
                   cfg.attn_resolutions, cfg.resolution)
 
 
-def run_training_step(L, cfg, P, xc, cond_in, mc, noise, rnd_normal):
+def run_training_step(L, cfg, P, xc, cond_in, mc, noise, rnd_normal, variants=()):
     plan = make_plan(L, cfg)
+    for which, value in variants:
+        plan.set_variant(which, value)
     params = {k: dev(v) for k, v in P.items()}
     packed = plan.pack(params)
     ws = L.Workspace()
@@ -217,6 +219,26 @@ def test_training_step_golden(lib, golden):
     assert abs(sq - float(g["grad_sqnorm_total"])) <= 1e-3 * float(g["grad_sqnorm_total"])
     each = np.array([float((grads[n].double() ** 2).sum()) for n in plan.param_names])
     np.testing.assert_allclose(each, g["grad_sqnorm_each"], rtol=5e-3)
+
+
+def test_training_step_golden_winograd_weight_gradients(lib, golden):
+    """The same golden with the plan's 'wgrad_wino' variant forced on: the 64 -> 64 and 128 -> 64 convs of the 32^2 and 16^2 levels
+    take the 64-channel Winograd weight-gradient kernel (at this batch the default leaves them to the direct kernel: too few
+    tiles per split), and the reference's gradients still come out."""
+    g = golden("training_P.npz")
+    P = orc.make_params(fx.CFG_P, int(g["seed"]))
+    h, u, mask, cond_noise, noise, rnd_normal = fx.training_inputs()
+    xc, cond_in, mc = fx.training_nchw(h, u, mask, cond_noise)
+    lib.prof_enable(True)
+    try:
+        plan, loss, grads = run_training_step(lib, fx.CFG_P, P, xc, cond_in, mc, noise, rnd_normal, variants=[("wgrad_wino", 1)])
+        rows = {r["name"]: int(r["launches"]) for r in lib.prof_report()}
+    finally:
+        lib.prof_enable(False)
+    assert rows.get("wgrad_wino64_kernel", 0) >= 12 and rows.get("wgrad_wino_finish_kernel", 0) >= 12, rows
+    close(loss, torch.as_tensor(g["loss"]).reshape(1), what="loss")
+    for n in fx.TRAIN_GRAD_NAMES:
+        close(grads[n], g[f"grad::{n}"], rtol=1e-4, rel_atol=1e-5, what=f"grad {n}")
 
 
 CFG_M = orc.UNetConfig(ch=64, ch_mult=(1, 2, 4), attn_resolutions=(8,))

@@ -74,7 +74,23 @@ SHAPES = [
     (3, 128, 0, 256, 32, 64, 0),      # two output-channel blocks, rectangular image, odd batch, no activation
     (2, 256, 0, 128, 128, 128, 1),    # the S128 decoder shape at full resolution: four segments per row
     (5, 128, 0, 128, 6, 96, 1),       # stage count not divisible by the split count: ragged splits, clamped prefetch
+    # the 64-channel form (all 16 positions per workgroup, 16-pixel segments): the reference's own ch = 64 network
+    (2, 64, 0, 64, 32, 32, 1),        # two segments per row
+    (1, 64, 0, 64, 2, 16, 1),         # one stage in all: every border in the same stage
+    (2, 64, 64, 64, 64, 64, 1),       # the decoder's concat conv: two input-channel blocks
+    (3, 64, 0, 128, 16, 48, 0),       # two output-channel blocks, rectangular, odd batch, no activation
+    (2, 128, 0, 128, 16, 16, 1),      # 128 channels on a 16-pixel row: too narrow for the 128-channel form
+    (5, 64, 0, 64, 6, 80, 1),         # ragged splits
+    (2, 64, 0, 64, 128, 128, 1),      # the reference network's top level
 ]
+
+
+def served_by(names):
+    return {n for n in names if n in ("wgrad_wino_kernel", "wgrad_wino64_kernel")}
+
+
+def expected_kernel(Cin, Cout, W):
+    return "wgrad_wino_kernel" if Cin % 128 == 0 and Cout % 128 == 0 and W % 32 == 0 else "wgrad_wino64_kernel"
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -91,14 +107,14 @@ def test_wgrad_wino_vs_fp64_and_direct(lib, shape):
     kw = dict(coef=dev(coef), act=act)
     lib.set_wgrad_wino(1)
     (dw, db), names = kernels_of(lib, lambda: lib.op_conv_wgrad(*args, **kw))
-    assert "wgrad_wino_kernel" in names and not any(n.startswith("wgrad_kernel") for n in names), names
+    assert served_by(names) == {expected_kernel(Cin, Cout, W)} and not any(n.startswith("wgrad_kernel") for n in names), names
     close(dw, gw, what="dW (Winograd)")
     close(db, gb, what="db (Winograd)")
     dw2, db2 = lib.op_conv_wgrad(*args, **kw)
     assert torch.equal(dw, dw2) and torch.equal(db, db2), "the Winograd weight gradient is not bitwise reproducible"
     lib.set_wgrad_wino(0)
     (dwd, dbd), names = kernels_of(lib, lambda: lib.op_conv_wgrad(*args, **kw))
-    assert "wgrad_wino_kernel" not in names, names
+    assert not served_by(names), names
     lib.set_wgrad_wino(-1)
     close(dwd, gw, what="dW (direct)")
     # the two kernels against each other, and their errors against fp64 side by side (the Winograd form must stay within 4x)
@@ -107,12 +123,13 @@ def test_wgrad_wino_vs_fp64_and_direct(lib, shape):
     close(dw, dwd.cpu(), rtol=2e-5, rel_atol=2e-6, what="Winograd vs direct")
 
 
-def test_wgrad_wino_is_exact_on_small_integers(lib):
+@pytest.mark.parametrize("C,W", [(128, 64), (64, 48)])
+def test_wgrad_wino_is_exact_on_small_integers(lib, C, W):
     """With small-integer inputs every product and partial sum of both forms is exact in fp32 (and the halves of G are powers of
     two), so the Winograd kernel must reproduce the reference bit for bit.  The kernel's first tile of a row starts one column
     left of the image and its last one ends one column right of it -- a neighbouring row's data, or memory in front of / behind
     the tensor: anything leaking in from there (or a wrong border mask) changes an integer."""
-    B, C, H, W = 2, 128, 8, 64
+    B, H = 2, 8
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (B, C, H, W), generator=g).float()
     dy = torch.randint(-3, 4, (B, C, H, W), generator=g).float()
@@ -123,7 +140,7 @@ def test_wgrad_wino_is_exact_on_small_integers(lib):
         (dw, db), names = kernels_of(lib, lambda: lib.op_conv_wgrad(dev(dy), dev(x), None, 3))
     finally:
         lib.set_wgrad_wino(-1)
-    assert "wgrad_wino_kernel" in names, names
+    assert served_by(names) == {expected_kernel(C, C, W)}, names
     assert torch.equal(dw.cpu().double(), gw), f"max |diff| {float((dw.cpu().double() - gw).abs().max())}"
     assert torch.equal(db.cpu().double(), gb)
 
@@ -131,12 +148,12 @@ def test_wgrad_wino_is_exact_on_small_integers(lib):
 def test_wgrad_wino_not_taken_for_unserved_shapes(lib):
     lib.set_wgrad_wino(1)
     try:
-        for (B, Cin, Cout, H, W) in [(2, 128, 128, 16, 16), (2, 64, 128, 32, 32), (2, 128, 64, 32, 32), (2, 128, 128, 32, 48)]:
+        for (B, Cin, Cout, H, W) in [(2, 128, 128, 8, 8), (2, 96, 128, 32, 32), (2, 128, 32, 32, 32), (2, 128, 128, 32, 24), (2, 64, 64, 5, 16)]:
             tag = f"t/wgw/no/{Cin}_{Cout}_{H}_{W}"
             x = fx.randn(tag + "/x", B, Cin, H, W)
             dy = fx.randn(tag + "/dy", B, Cout, H, W)
             (dw, db), names = kernels_of(lib, lambda: lib.op_conv_wgrad(dev(dy), dev(x), None, 3))
-            assert "wgrad_wino_kernel" not in names, (names, Cin, Cout, H, W)
+            assert not served_by(names), (names, Cin, Cout, H, W)
             gw, gb = reference(x, None, torch.tensor([0.0, 1.0, 0.0, 0.0]).repeat(B, Cin, 1), 0, dy, Cout)
             close(dw, gw, what="dW")
     finally:

@@ -16,7 +16,7 @@ for sh in a.shapes:
     dy = torch.randn(a.B, cout, hw, hw, device="cuda")
     flops = 2.0 * a.B * hw * hw * cout * cin * 9
     res = {}
-    for mode, name in ((0, "direct"), (1, "winograd")):
+    for mode, name in ((0, "direct"), (1, "winograd")):      # (MCEDM_WGRAD_WINO64=0: the 64-channel form off)
         lib.set_wgrad_wino(mode)
         for _ in range(2):
             dw, db = lib.op_conv_wgrad(dy, x, None, 3)
