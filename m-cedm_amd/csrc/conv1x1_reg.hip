@@ -26,9 +26,10 @@
 
 namespace mcedm {
 
-constexpr int C1_MT = 128;                  // output channels per workgroup
-constexpr int C1_PX = 512;                  // pixels per workgroup tile (4 quarters of 128)
 constexpr int C1_KS = 16;                   // channels per stage
+// output channels per workgroup MT = 128 (tile of 512 pixels: 2 channel halves x 4 pixel quarters of 128) or 64 (the ch = 64
+// network's 128 -> 64 skip projections: one channel half x 8 pixel parts = 1024 pixels, every input element fetched once)
+constexpr int c1_px(int mt) { return mt == 128 ? 512 : 1024; }
 
 struct Conv1Args {
   const float* xa; const float* xb; int Ca, Cb;
@@ -42,14 +43,16 @@ struct Conv1Args {
 // NI = 32-channel blocks per wave: 2 (64 channels x 128 pixels per wave, 16-byte loads; every input element is fetched by the two
 // waves that share a pixel quarter) or 4 (all 128 channels x 64 pixels per wave, 8-byte loads: every element fetched ONCE per
 // workgroup, twice the LDS fragment reads)
-template <int NI>
+template <int NI, int MT = 128>
 __global__ __launch_bounds__(512, 1) void conv1x1_reg_kernel(const Conv1Args p) {
+  static_assert(MT == 128 || (MT == 64 && NI == 2), "conv1x1_reg: 64-channel workgroups exist in the NI = 2 form only");
+  constexpr int C1_MT = MT, C1_PX = c1_px(MT);
   constexpr int NE = 8 / NI;                                      // pixels (= 32-column blocks) per lane
   typedef float bvec __attribute__((ext_vector_type(NE)));
   extern __shared__ float wl[];                                   // [128][Cin + 16]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int coh = NI == 2 ? (wave & 1) : 0, pq = NI == 2 ? (wave >> 1) : wave, l31 = lane & 31, h = lane >> 5;
+  const int coh = (NI == 2 && MT == 128) ? (wave & 1) : 0, pq = (NI == 2 && MT == 128) ? (wave >> 1) : wave, l31 = lane & 31, h = lane >> 5;
   const int Cin = p.Ca + p.Cb, nst = Cin / C1_KS;
   const int pitch = Cin + 16;
   const int m0 = blockIdx.y * C1_MT;
@@ -176,6 +179,8 @@ int try_launch_conv1x1_reg(const ConvArgs& a, int taps, hipStream_t stream) {
   const unsigned long long HW = (unsigned long long)a.H * a.W;
   if (!c1_env() || taps != 1 || a.resample != RS_NONE || a.coef || a.act || a.sk_wpk || a.gsum || a.gn_on) return -1;
   if (a.res && a.res_mode != RS_NONE) return -1;
+  const int MT = a.Cout % 128 == 0 ? 128 : 64;
+  const int C1_MT = MT, C1_PX = c1_px(MT);
   if (!a.xa || a.Cout % C1_MT != 0 || a.Ca % C1_KS != 0 || a.Cb % C1_KS != 0 || Cin < C1_KS || Cin > 256) return -1;
   if ((a.Cb > 0) != (a.xb != nullptr)) return -1;
   if (HW % C1_PX != 0 || HW < 1024) return -1;                        // whole 512-pixel tiles; <= 16 x 16 stays on the resident kernels
@@ -189,6 +194,8 @@ int try_launch_conv1x1_reg(const ConvArgs& a, int taps, hipStream_t stream) {
   p.tiles_img = (int)(HW / C1_PX);
   p.ntiles = a.B * p.tiles_img;
   const int mblocks = a.Cout / C1_MT;
+  // (a function of the image size only -- never of the batch: a sample's bits must not depend on the batch it is computed in)
+  if (MT == 64 && HW < 4096) return -1;                               // one 1024-pixel tile per image: the resident kernels' job
   // persistent workgroups: one round on the chip's CUs (the weight image is loaded once per workgroup)
   int wgs = 256 / mblocks;
   if (wgs < 1) wgs = 1;
@@ -204,13 +211,15 @@ int try_launch_conv1x1_reg(const ConvArgs& a, int taps, hipStream_t stream) {
   if (!attr_set[dev].load(std::memory_order_acquire)) {
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv1x1_reg_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)conv1x1_reg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)(conv1x1_reg_kernel<2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[dev].store(true, std::memory_order_release);
   }
   const double px = (double)a.B * (double)HW;
   ProfScope ps("conv1x1_reg_kernel", 2.0 * px * a.Cout * Cin, 4.0 * (px * (Cin + a.Cout * (a.res ? 2 : 1)) + (double)a.Cout * Cin), stream);
   static int ni_env = -1;                                  // MCEDM_C1_NI: 2 or 4 (A/B runs; the two differ in the last bits of nothing: same sums)
   if (ni_env < 0) { const char* e = getenv("MCEDM_C1_NI"); ni_env = e ? atoi(e) : 2; }      // NI = 4 measured 20 % slower (436 vs 364 us)
-  if (ni_env == 2) hipLaunchKernelGGL(conv1x1_reg_kernel<2>, dim3(wgs, mblocks), dim3(512), lds, stream, p);
+  if (MT == 64) hipLaunchKernelGGL((conv1x1_reg_kernel<2, 64>), dim3(wgs, mblocks), dim3(512), lds, stream, p);
+  else if (ni_env == 2) hipLaunchKernelGGL(conv1x1_reg_kernel<2>, dim3(wgs, mblocks), dim3(512), lds, stream, p);
   else hipLaunchKernelGGL(conv1x1_reg_kernel<4>, dim3(wgs, mblocks), dim3(512), lds, stream, p);
   MCEDM_LAUNCH_CHECK("conv1x1_reg_kernel");
   return MCEDM_OK;

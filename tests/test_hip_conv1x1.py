@@ -40,6 +40,9 @@ def run(L, fn):
     (2, 128, 0, 256, 64, 64, False),        # the skip projection's data gradient: two output-channel blocks
     (1, 32, 32, 128, 16, 64, True),         # the smallest K (two stages of 16 channels per source), two tiles
     (5, 256, 0, 128, 32, 32, False),        # tile count not divisible by the workgroup count
+    (2, 64, 64, 64, 64, 64, False),         # the ch = 64 network's skip projection: 64-channel workgroups, 1024-pixel tiles
+    (3, 128, 0, 64, 64, 128, True),         # the same with a residual, rectangular, odd batch
+    (2, 64, 0, 192, 64, 64, False),         # three 64-channel blocks
 ])
 def test_conv1x1_reg_vs_fp64_and_tiled_kernel(lib, B, Ca, Cb, Cout, H, W, use_res):
     tag = f"c1/{B}_{Ca}_{Cb}_{Cout}_{H}_{W}"
@@ -73,7 +76,7 @@ def test_conv1x1_reg_vs_fp64_and_tiled_kernel(lib, B, Ca, Cb, Cout, H, W, use_re
 def test_conv1x1_reg_leaves_other_shapes_alone(lib):
     lib.set_conv1x1_reg(1)
     try:
-        for (Cin, Cout, H, W, coef) in [(128, 128, 16, 16, False), (128, 64, 32, 32, False), (40, 128, 32, 32, False), (128, 128, 32, 32, True)]:
+        for (Cin, Cout, H, W, coef) in [(128, 128, 16, 16, False), (128, 64, 32, 32, False), (128, 96, 64, 64, False), (40, 128, 32, 32, False), (128, 128, 32, 32, True)]:
             tag = f"c1/no/{Cin}_{Cout}_{H}_{W}_{coef}"
             x = fx.randn(tag + "/x", 2, Cin, H, W)
             w = fx.randn(tag + "/w", Cout, Cin, 1, 1) / Cin ** 0.5
