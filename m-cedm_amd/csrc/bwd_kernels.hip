@@ -557,9 +557,15 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(const float* __re
 // MFMA operands are LDS dwords.  Same sums in the same order per output element as the kernels above except that a wave now
 // walks ALL chunks in ascending order instead of every fourth (no cross-wave merge): deterministic, batch independent.
 constexpr int ATP = 65;                    // pitch of the transposed chunk images
+constexpr float ATT_LOG2E = 1.4426950408889634f;
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
-                                                              const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
+// The dq kernel also produces the softmax statistics the dk / dv kernel needs (no attn_bwd_stats_kernel launch on this path: its
+// S = K^T Q product is the one computed here anyway; 164 of 496 us at T = 1024): the scores are normalised ONLINE -- running
+// maximum m and sum l per query as in the forward kernel, dq accumulated unnormalised and rescaled when m moves, divided by l at
+// the end -- and (m + log l, delta = sum_c dA A) go to `lse` for the second kernel.
+__global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ a,
+                                                              const float* __restrict__ da, float* __restrict__ lse,
+                                                              float* __restrict__ dqkv, int T) {
   __shared__ float Kc[2][64 * 32], Vc[2][64 * 32], Kt[2][32 * ATP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const size_t bh = blockIdx.y;
@@ -569,12 +575,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(const float* __res
   const float* dA = da + bh * 64 * (size_t)T;
   const int q = blockIdx.x * 128 + 32 * wave + l31;
   float qreg[32], dareg[32];
+  float delta = 0.f;
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
-    qreg[s] = Q[(size_t)(2 * s + h) * T + q] * 0.125f;
+    qreg[s] = Q[(size_t)(2 * s + h) * T + q] * (0.125f * ATT_LOG2E);      // scores in units of log 2: v_exp_f32 is 2^x
     dareg[s] = dA[(size_t)(2 * s + h) * T + q];
+    delta += dareg[s] * a[bh * 64 * (size_t)T + (size_t)(2 * s + h) * T + q];
   }
-  const float L = lse[(bh * T + q) * 2], delta = lse[(bh * T + q) * 2 + 1];
+  delta += __shfl_xor(delta, 32);
+  float m = -INFINITY, l = 0.f;
   f32x16 o[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -615,25 +624,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(const float* __res
       sc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kc[buf][(2 * st + h) * 32 + l31], qreg[st], sc, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[buf][(2 * st + h) * 32 + l31], dareg[st], dp, 0, 0, 0);
     }
+    // a query's 32 scores of this chunk sit in the lanes l31 and l31 + 32
+    float mx = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);   // 0 on the first chunk (m = -inf)
     float ds[16];
+    float rs = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ds[r] = expf(sc[r] - L) * (dp[r] - delta);
+    for (int r = 0; r < 16; ++r) {
+      const float pr = __builtin_amdgcn_exp2f(sc[r] - mn);
+      rs += pr;
+      ds[r] = pr * (dp[r] - delta);
+    }
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = mn;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[buf][MCEDM_KEY_OF(r, h) * ATP + 32 * i + l31], ds[r], o[i], 0, 0, 0);
+    }
     if (n + 1 < nch) commit(buf ^ 1);
     __syncthreads();
   }
   float* dQ = dqkv + (bh * 3 + 0) * 64 * (size_t)T;
+  const float sc_out = 0.125f / l;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dQ[(size_t)(32 * i + MCEDM_KEY_OF(r, h)) * T + q] = o[i][r] * 0.125f;
+    for (int r = 0; r < 16; ++r) dQ[(size_t)(32 * i + MCEDM_KEY_OF(r, h)) * T + q] = o[i][r] * sc_out;
+  if (h == 0) {
+    lse[(bh * T + q) * 2] = m + __builtin_amdgcn_logf(l);      // base 2, as attn_bwd_dkv_lds_kernel expects it (v_log_f32 is log2)
+    lse[(bh * T + q) * 2 + 1] = delta;
+  }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
                                                                const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
   __shared__ float Qc[2][64 * 32], Ac[2][64 * 32], Qt[2][32 * ATP], At[2][32 * ATP], Ls[2][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -669,7 +701,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int idx = tid + 256 * j, c = idx >> 3, qq = idx & 7;
-      *reinterpret_cast<f32x4*>(&Qc[buf][c * 32 + 4 * qq]) = rq[j] * 0.125f;
+      *reinterpret_cast<f32x4*>(&Qc[buf][c * 32 + 4 * qq]) = rq[j] * (0.125f * ATT_LOG2E);
       *reinterpret_cast<f32x4*>(&Ac[buf][c * 32 + 4 * qq]) = ra[j];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { Qt[buf][(4 * qq + e) * ATP + c] = rq[j][e]; At[buf][(4 * qq + e) * ATP + c] = ra[j][e]; }
@@ -695,7 +727,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_lds_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = MCEDM_KEY_OF(r, h);
-      pr[r] = expf(sc[r] - Ls[buf][2 * qi]);
+      pr[r] = __builtin_amdgcn_exp2f(sc[r] - Ls[buf][2 * qi]);
       ds[r] = pr[r] * (dp[r] - Ls[buf][2 * qi + 1]);
     }
 #pragma unroll
@@ -727,16 +759,19 @@ int launch_attention_bwd(const float* qkv, const float* a, const float* da, floa
   MCEDM_REQUIRE(B > 0 && heads > 0 && T > 0 && (long long)B * heads <= 65535, "attention_bwd: bad shape");
   const dim3 grid(ceil_div(T, 32), B * heads);
   ProfScope ps("attention_bwd", 10.0 * B * heads * (double)T * T * 64, 4.0 * 8 * B * heads * 64.0 * T, s);
-  if (T >= 128) hipLaunchKernelGGL(attn_bwd_stats_kernel<4>, grid, dim3(256), 0, s, qkv, a, da, lse, T);
-  else if (T >= 64) hipLaunchKernelGGL(attn_bwd_stats_kernel<2>, grid, dim3(128), 0, s, qkv, a, da, lse, T);
-  else hipLaunchKernelGGL(attn_bwd_stats_kernel<1>, grid, dim3(64), 0, s, qkv, a, da, lse, T);
-  MCEDM_LAUNCH_CHECK("attn_bwd_stats_kernel");
   // split factor: a function of T only (never of the batch size)
   static int lds_env = -1;                                 // MCEDM_ATTN_BWD_LDS=0: the direct-from-global kernels at every T (A/B runs)
   if (lds_env < 0) { const char* e = getenv("MCEDM_ATTN_BWD_LDS"); lds_env = e ? atoi(e) : 1; }
-  if (lds_env && T % 128 == 0 && ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(da)) & 15) == 0) {
+  const bool lds_path = lds_env && T % 128 == 0 && ((reinterpret_cast<size_t>(qkv) | reinterpret_cast<size_t>(da)) & 15) == 0;
+  if (!lds_path) {
+    if (T >= 128) hipLaunchKernelGGL(attn_bwd_stats_kernel<4>, grid, dim3(256), 0, s, qkv, a, da, lse, T);
+    else if (T >= 64) hipLaunchKernelGGL(attn_bwd_stats_kernel<2>, grid, dim3(128), 0, s, qkv, a, da, lse, T);
+    else hipLaunchKernelGGL(attn_bwd_stats_kernel<1>, grid, dim3(64), 0, s, qkv, a, da, lse, T);
+    MCEDM_LAUNCH_CHECK("attn_bwd_stats_kernel");
+  }
+  if (lds_path) {
     const dim3 g4(T / 128, B * heads);
-    hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, g4, dim3(256), 0, s, qkv, da, lse, dqkv, T);
+    hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, g4, dim3(256), 0, s, qkv, a, da, lse, dqkv, T);
     MCEDM_LAUNCH_CHECK("attn_bwd_dq_lds_kernel");
     hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, g4, dim3(256), 0, s, qkv, da, lse, dqkv, T);
   } else if (T >= 128) {
