@@ -64,8 +64,17 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
   if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime(); p.dbg[blockIdx.x * 16 + 4] = per; }
   // A workgroup takes `per` consecutive pixel tiles of ONE sample (the launcher picks a divisor of the tiles per image) and
   // runs their stages as one stream: the pipeline below never drains between tiles, only the accumulators are written out.
-  const int gt0 = blockIdx.x * per;
-  const int n = gt0 / tiles_img, tile0 = gt0 % tiles_img;
+  // mode bit 256 (round 5, MCEDM_WINO_MAP): the tiles_img / per workgroups of a sample share an XCD (ids 8 apart: one L2) and walk the
+  // image INTERLEAVED -- workgroup j takes tiles j, j + wps, ... -- so that at any time they work on neighbouring tiles and fetch each
+  // other's halo columns out of that L2 (with consecutive tiles per workgroup a tile's 24 x 10 fetch per 16 x 8 pixels had left the
+  // 4 MB L2 long before the neighbouring tile asked for its overlap: 1.9x the input from HBM).  Same tiles, same sums: same bits.
+  int gt0 = blockIdx.x * per, tstep = 1;
+  int n = gt0 / tiles_img, tile0 = gt0 % tiles_img;
+  if (mode & 256) {
+    const int nwg = gridDim.x, wps = tiles_img / per;
+    const int lid = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    n = lid / wps; tile0 = lid % wps; tstep = wps;
+  }
   const int m0 = blockIdx.y * C::MT;
   const size_t HW = (size_t)p.H * p.W, HWs = (size_t)p.Hs * p.Ws;
   const int nst = (nch + WSC - 1) / WSC;                           // stages per tile
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
       }
     }
   };
-  auto raw_load_next = [&]() { if (++ld_st == nst) { ld_st = 0; ++ld_tile; set_geom(ld_tile < tiles_img ? ld_tile : tiles_img - 1); } };
+  auto raw_load_next = [&]() { if (++ld_st == nst) { ld_st = 0; ld_tile += tstep; set_geom(ld_tile < tiles_img ? ld_tile : tiles_img - 1); } };
   auto raw_load_done = [&]() {                                     // all chunks of the stage requested: on to the next stage
 #pragma unroll
     for (int i = 0; i < NG; ++i) rkeepC[i] = rkeepL[i];            // these registers are committed one trip from now
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(C::NT, C::MB == 4 ? 1 : 2) void conv_wino_kernel(co
     WINO_EP(4)                                            // 4: statistics
     __builtin_amdgcn_sched_barrier(0);
     init_acc();
-    ++tile;
+    tile += tstep;
     WINO_EP(5)                                            // 5: accumulator initialisation
     WINO_STAMP(3)
   }
@@ -531,8 +540,12 @@ static int wino_env() {                                        // MCEDM_WINOGRAD
   return variant_choice(KV_CONV_WINO, g_wino, env);            // the executing plan's choice, the process-wide hook, the environment
 }
 static int wino_mode_env() {                                   // MCEDM_WINO_MODE: ablation bits of the -DMCEDM_WINO_TIMELINE build (else unused)
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("MCEDM_WINO_MODE"); env = e ? atoi(e) : 0; }
+  static int env = -1;                                         // | 256: the interleaved, XCD-aware tile map (MCEDM_WINO_MAP, default on)
+  if (env < 0) {
+    const char* e = getenv("MCEDM_WINO_MODE");
+    const char* m = getenv("MCEDM_WINO_MAP");
+    env = ((e ? atoi(e) : 0) & ~256) | ((m ? atoi(m) : 1) ? 256 : 0);
+  }
   return env;
 }
 

@@ -220,3 +220,37 @@ def test_kernel_variants_are_a_property_of_the_plan(lib):
     assert any("conv_wino_kernel" in n for n in na), "-1 must restore the process default"
     with pytest.raises(KeyError):
         pa.set_variant("no_such_family", 1)
+
+
+def test_interleaved_tile_map_is_bit_identical_to_consecutive_tiles(lib, tmp_path):
+    """Round 5: the workgroups of a sample share an XCD and walk the image interleaved (MCEDM_WINO_MAP, default on) so that halo
+    columns are fetched out of one L2.  Which workgroup computes a tile must not change a bit: the same conv in a child process
+    with the consecutive-tile map (the switch is read once per process), several tiles per workgroup (B x 128 tiles > one round)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    script = r'''
+import importlib, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+L = importlib.import_module("m-cedm_amd.lib"); L.load()
+g = torch.Generator().manual_seed(11)
+out = {}
+for name, (B, Cin, Cout, H, W) in {"c4": (8, 128, 128, 128, 128), "c2": (16, 64, 64, 64, 128)}.items():
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    out[name] = L.op_conv_wino(x, None, L.op_pack_conv_wino(w), b, Cout, act=1).cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for m in ("0", "1"):
+        path = str(tmp_path / f"map{m}.npz")
+        env = dict(os.environ, MCEDM_WINO_MAP=m)
+        r = subprocess.run([sys.executable, "-c", script, root, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[m] = dict(np.load(path))
+    for k in res["0"]:
+        assert np.isfinite(res["0"][k]).all() and np.abs(res["0"][k]).max() > 0.1
+        assert np.array_equal(res["0"][k], res["1"][k]), k
