@@ -335,6 +335,16 @@ int mcedm_op_gn_bwd(const float* dact, int resample, const float* xa, const floa
                     const float* film, int film_batch, int film_stride, int act, float* dxa, float* dxb, int accumulate,
                     const float* add, int add_mode, float* ab, float* dgamma, float* dbeta, float* dfilm,
                     int dfilm_stride, void* stream);
+/* The same with `sync`: MCEDM_GN_SYNC_WORDS * B * groups 32-bit words (groups = min(32, C / 4)), ZERO on entry and left
+ * zero on exit.  With them a (sample, group) slab of 64 KB or more is cut into pieces of 4096 elements whose workgroups keep them in
+ * LDS between the two passes and exchange their partial sums through `sync` (round 5; without it such slabs take the two-pass
+ * kernel).  What the plan's backward (mcedm_denoise_backward) passes from its workspace. */
+#define MCEDM_GN_SYNC_WORDS 130
+int mcedm_op_gn_bwd_sync(const float* dact, int resample, const float* xa, const float* xb, int Ca, int Cb, int Hs, int Ws,
+                         int B, const mcedm_coef* coef, const float* stats, const float* gamma, const float* beta,
+                         const float* film, int film_batch, int film_stride, int act, float* dxa, float* dxb, int accumulate,
+                         const float* add, int add_mode, float* ab, float* dgamma, float* dbeta, float* dfilm,
+                         int dfilm_stride, unsigned int* sync, void* stream);
 /* Attention backward (models/adm_blocks.py:111-118): qkv / dqkv packed [B][heads][3][64][T]; a, da [B][heads*64][T];
  * lse_scratch holds B*heads*T*2 floats. */
 int mcedm_op_attention_bwd(const float* qkv, const float* a, const float* da, float* dqkv, float* lse_scratch, int B,

@@ -88,7 +88,7 @@ __global__ void colsum_kernel(const float* __restrict__ A, int rows, int cols, i
 
 struct BwdScratch {
   std::vector<size_t> g;     // gradient buffer per forward tensor id (NONE when not an activation)
-  size_t dact, dskip, xact, ab, wg, dfilm, lse, gF, pe, u1, u2, t1, t2, t3, emb, total;
+  size_t dact, dskip, xact, ab, wg, dfilm, lse, gF, pe, u1, u2, t1, t2, t3, emb, sync, sync_bytes, total;
 };
 
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
@@ -134,6 +134,8 @@ static BwdScratch make_scratch(const mcedm_plan& P, const Layout& L, int B, int 
   S.pe = take((size_t)B * ch * 4); S.u1 = take((size_t)B * ch * 4); S.u2 = take((size_t)B * ch * 4);
   S.t1 = take((size_t)B * ch * 4); S.t2 = take((size_t)B * ch * 4); S.t3 = take((size_t)B * ch * 4);
   S.emb = take((size_t)B * ch * 4);
+  S.sync_bytes = gn_bwd_sync_words(B, 32) * sizeof(unsigned);      // gn_bwd_lds_kernel's counters and piece sums (<= 32 groups)
+  S.sync = take(S.sync_bytes);
   S.total = cur;
   return S;
 }
@@ -141,6 +143,9 @@ static BwdScratch make_scratch(const mcedm_plan& P, const Layout& L, int B, int 
 size_t backward_scratch_bytes(const mcedm_plan& P, const Layout& L, int B, int H, int W) {
   return make_scratch(P, L, B, H, W).total;
 }
+
+struct Ctx;
+static GnBwdArgs with_sync(const Ctx& c, GnBwdArgs g);
 
 struct Ctx {
   const mcedm_plan& P;
@@ -163,6 +168,7 @@ struct Ctx {
   float* G(int id) const { return id < 0 ? nullptr : reinterpret_cast<float*>(scr + S.g[id]); }
   float* X(size_t off) const { return reinterpret_cast<float*>(scr + off); }
 };
+static GnBwdArgs with_sync(const Ctx& c, GnBwdArgs g) { g.sync = reinterpret_cast<unsigned*>(c.X(c.S.sync)); return g; }
 
 // plain data-gradient conv: out[B, c.cin, H, W] = conv(dy[B, c.cout, H, W], transposed+mirrored weights)
 static int dgrad(const Ctx& c, const ConvP& cv, const float* dy, int H, int W, float* out) {
@@ -203,7 +209,7 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
     if ((rc = dgrad(c, b.qkv, c.G(bl.qkv), H, W, dact))) return rc;
     GnBwdArgs g2{dact, RS_NONE, c.T(bl.y), nullptr, b.cout, 0, H, W, B, b.norm2.groups, c.CF(bl.coef2), c.T(bl.stats2),
                  c.pk + b.norm2.gamma, nullptr, 0, 0, 0, c.G(bl.y), nullptr, 0, dz, 1, b.cout, c.X(c.S.ab), c.X(c.S.xact)};
-    if ((rc = launch_gn_bwd(g2, c.s))) return rc;     // g[y] = dz (residual) + norm2 path
+    if ((rc = launch_gn_bwd(with_sync(c, g2), c.s))) return rc;     // g[y] = dz (residual) + norm2 path
     if ((rc = norm_param_grads(c, b.norm2, nullptr, 0, nullptr))) return rc;
     WgradArgs wq{c.G(bl.qkv), c.T(bl.y), nullptr, b.cout, 0, c.CF(bl.coef2), 1, 0, RS_NONE, H, W, H, W, 3 * b.cout, B, wg, nullptr};
     if ((rc = launch_wgrad(wq, 1, c.grads[b.qkv.w], c.grads[b.qkv.b], b.heads, c.X(c.S.xact), c.s, true))) return rc;
@@ -215,7 +221,7 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
   GnBwdArgs g1{dact, RS_NONE, c.T(bl.h), nullptr, b.cout, 0, H, W, B, b.norm1.groups, c.CF(bl.coef1), c.T(bl.stats1),
                c.pk + b.norm1.gamma, film, c.n_noise > 1 ? 1 : 0, c.P.film_rows, 1, c.G(bl.h), nullptr, 0, nullptr, 0, 0,
                c.X(c.S.ab), c.X(c.S.xact)};
-  if ((rc = launch_gn_bwd(g1, c.s))) return rc;
+  if ((rc = launch_gn_bwd(with_sync(c, g1), c.s))) return rc;
   if ((rc = norm_param_grads(c, b.norm1, film, c.P.film_rows, c.X(c.S.dfilm) + b.film_row0))) return rc;
   WgradArgs w1{dy, c.T(bl.h), nullptr, b.cout, 0, c.CF(bl.coef1), 1, 1, RS_NONE, H, W, H, W, b.cout, B, wg, nullptr};
   if ((rc = launch_wgrad(w1, 9, c.grads[b.conv1.w], c.grads[b.conv1.b], 0, c.X(c.S.xact), c.s, true))) return rc;
@@ -249,7 +255,7 @@ static int block_backward(Ctx& c, const BlockP& b, const BlockLayout& bl) {
   } else {
     g0.accumulate = ha ? 1 : 0;
   }
-  if ((rc = launch_gn_bwd(g0, c.s))) return rc;
+  if ((rc = launch_gn_bwd(with_sync(c, g0), c.s))) return rc;
   c.have[bl.xa] = 1;
   if (bl.xb >= 0) c.have[bl.xb] = 1;
   if ((rc = norm_param_grads(c, b.norm0, nullptr, 0, nullptr))) return rc;
@@ -338,6 +344,7 @@ static int denoise_backward_impl(const mcedm_plan* plan, const void* packed, con
   const float* pk = (const float*)packed;
   Ctx c{P, L, S, act, scr, pk, grads, B, n_sigma, s, std::vector<char>(L.t.size(), 0)};
   c.n_buckets = n_buckets; c.bucket_first = bucket_first; c.bucket_events = bucket_events;
+  MCEDM_HIP_TRY(hipMemsetAsync(c.X(S.sync), 0, S.sync_bytes, s));      // zero once per pass; every GroupNorm backward leaves it zero
   const int ch = P.desc.ch;
   const size_t per = (size_t)P.desc.out_channels * H * W;
 
@@ -369,7 +376,7 @@ static int denoise_backward_impl(const mcedm_plan* plan, const void* packed, con
   if ((rc = dgrad(c, P.conv_out, c.X(S.gF), H, W, c.X(S.dact)))) return rc;
   GnBwdArgs go{c.X(S.dact), RS_NONE, c.T(L.last), nullptr, last.C, 0, H, W, B, P.out_norm.groups, c.CF(L.coef_out),
                c.T(L.stats_out), pk + P.out_norm.gamma, nullptr, 0, 0, 1, c.G(L.last), nullptr, 0, nullptr, 0, 0, c.X(S.ab)};
-  if ((rc = launch_gn_bwd(go, s))) return rc;
+  if ((rc = launch_gn_bwd(with_sync(c, go), s))) return rc;
   c.have[L.last] = 1;
   if ((rc = norm_param_grads(c, P.out_norm, nullptr, 0, nullptr))) return rc;
 

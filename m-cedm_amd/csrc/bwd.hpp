@@ -49,7 +49,11 @@ struct GnBwdArgs {
   int add_C;           // channel count of `add` when add_mode == 2 (== C)
   float* ab;           // out [B][C][2]: sum(dt), sum(dt * xhat) per (sample, channel)
   float* xact;         // optional out [B, C, Hs, Ws]: act(coef(x)), the conv's (un-resampled) input for its weight gradient
+  unsigned* sync;      // optional gn_bwd_sync_words(B, groups) 32-bit words, ZERO on entry (the counters are left zero on exit): lets
+                       // the workgroups that share a (sample, group) slab keep their pieces in LDS between the passes and exchange
+                       // their sums (gn_bwd_lds_kernel); null: the two-pass kernel
 };
+size_t gn_bwd_sync_words(int B, int groups);
 int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s);
 
 // dgamma/dbeta (summed over the batch, overwritten) and the FiLM-row gradients from the ab table

@@ -1,5 +1,6 @@
 // bwd_kernels.hip -- K10b: backward of GroupNorm+FiLM+SiLU(+2x resampling), parameter-gradient reductions,
 // the tiny dense products of the embedding MLP backward, and the attention backward (flash-style recompute).
+#include <atomic>
 #include <cstdlib>
 
 #include "bwd.hpp"
@@ -187,12 +188,209 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(GnBwdArgs a) {
   }
 }
 
+// ---- the slab on chip between the two passes (round 5) ---------------------------------------------------------------------
+// gn_bwd_kernel reads x and the incoming gradient twice (six to eight tensor passes for the algorithmic three).  Here a (sample,
+// group) slab of >= 64 KB is cut into pieces of 4096 elements of one channel (32 KB of LDS for x and dact: four 256-thread
+// workgroups per CU, so that one workgroup's loads overlap another's stores -- one 128 KB workgroup per CU was 60 % SLOWER than the
+// two-pass kernel).  A workgroup keeps its piece in LDS, publishes the piece's (sum dt, sum dt xhat) in a table behind the counters,
+// and waits for the k - 1 other pieces of the slab -- for a BOUNDED time (partners are adjacent workgroup ids: dispatched together).  A workgroup whose wait runs out computes the missing pieces' sums itself from global memory (the same
+// function, the same bits), so no schedule can hang the kernel; the last workgroup to leave clears the exchange area (zero on
+// entry, zero on exit).  Piece sums are added per channel in piece order in fp64: deterministic.  Un-resampled inputs only.
+constexpr int GNL_PIECE = 4096;                 // elements per workgroup
+constexpr int GNL_KMAX = 64;                    // workgroups per slab
+constexpr int GNL_SYNC_WORDS = 2 + 2 * GNL_KMAX;   // per slab: a departure counter (+ 1 unused) and KMAX 64-bit slots
+static_assert(GNL_SYNC_WORDS == MCEDM_GN_SYNC_WORDS, "mcedm_hip.h");
+
+__global__ __launch_bounds__(256) void gn_bwd_lds_kernel(GnBwdArgs a, int ppc, unsigned spin_ticks) {
+  constexpr int NT = 256, NQ = GNL_PIECE / 4;
+  __shared__ f32x4 xs[NQ], ds[NQ];
+  __shared__ double red[2][NT / 64];
+  __shared__ float sP[GNL_KMAX][2], sM[2];
+  __shared__ int s_have;
+  const int C = a.Ca + a.Cb;
+  const int cpg = C / a.groups, k = cpg * ppc;
+  const int slab = blockIdx.x / k, j = blockIdx.x - slab * k;
+  const int n = slab / a.groups, g = slab - n * a.groups;
+  const int c0 = g * cpg;
+  const int HWs = a.Hs * a.Ws;
+  const unsigned nslabs = gridDim.x / k;
+  unsigned* const depart = a.sync + slab;                       // [nslabs] counters, [nslabs] unused, then [nslabs][KMAX] 64-bit slots
+  unsigned long long* const slots = reinterpret_cast<unsigned long long*>(a.sync + 2 * nslabs) + (size_t)slab * GNL_KMAX;
+  const float mean = a.stats[((size_t)n * a.groups + g) * 2], rstd = a.stats[((size_t)n * a.groups + g) * 2 + 1];
+  const int tid = threadIdx.x;
+
+  // piece jj = (channel c0 + jj / ppc, elements [jj % ppc * PIECE, + PIECE)): its two sums -> sP[jj]
+  auto piece_sums = [&](int jj, bool own) {
+    const int c = c0 + jj / ppc;
+    const size_t off = (size_t)(jj % ppc) * GNL_PIECE;
+    const float* x = ((c < a.Ca) ? a.xa + ((size_t)n * a.Ca + c) * HWs : a.xb + ((size_t)n * a.Cb + (c - a.Ca)) * HWs) + off;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(a.dact + ((size_t)n * C + c) * HWs + off);
+    const Coef cf = a.coef[(size_t)n * C + c];
+    f32x4 xv[NQ / NT], dv[NQ / NT];
+#pragma unroll
+    for (int u = 0; u < NQ / NT; ++u) { xv[u] = x4[tid + NT * u]; dv[u] = d4[tid + NT * u]; }
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int u = 0; u < NQ / NT; ++u) {
+      if (own) { xs[tid + NT * u] = xv[u]; ds[tid + NT * u] = dv[u]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float dt = dv[u][e];
+        if (a.act) dt *= dsilu((xv[u][e] - cf.mean) * cf.scale + cf.offset);
+        pa += dt;
+        pb += dt * ((xv[u][e] - mean) * rstd);
+      }
+    }
+    double da = pa, db = pb;
+#pragma unroll
+    for (int off2 = 32; off2 > 0; off2 >>= 1) { da += __shfl_xor(da, off2); db += __shfl_xor(db, off2); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = da; red[1][tid >> 6] = db; }
+    __syncthreads();
+    if (tid == 0) {
+      sP[jj][0] = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+      sP[jj][1] = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+    __syncthreads();
+  };
+
+  piece_sums(j, true);
+  // exchange: every piece's two sums travel as ONE 64-bit word through a slot that is zero until published (a zero first sum is sent
+  // as -0.0f), written and polled with agent-scope atomics: no fence anywhere -- a fence here is a write-back / invalidate of the
+  // XCD's whole L2 per workgroup (the first version: 5x slower than the two-pass kernel).
+  if (tid < 64) {                                               // wave 0: lane L watches slot L
+    int have = 1;
+    if (k > 1) {
+      if (tid == 0) {
+        float A = sP[j][0];
+        if (A == 0.f) A = -0.f;
+        const unsigned long long w = ((unsigned long long)__builtin_bit_cast(unsigned, sP[j][1]) << 32) | __builtin_bit_cast(unsigned, A);
+        __hip_atomic_store(slots + j, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned long long v = 0;
+      const bool mine = tid < k && tid != j;
+      for (;;) {
+        if (mine && v == 0) v = __hip_atomic_load(slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        have = __all(!mine || v != 0);
+        if (have || __builtin_amdgcn_s_memrealtime() - t0 > spin_ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (have && mine) {
+        sP[tid][0] = __builtin_bit_cast(float, (unsigned)(v & 0xffffffffull));
+        sP[tid][1] = __builtin_bit_cast(float, (unsigned)(v >> 32));
+      }
+    }
+    if (tid == 0) s_have = have;
+  }
+  __syncthreads();
+  if (!s_have) {                                               // the wait ran out: the other pieces' sums from global memory, same bits
+    for (int jj = 0; jj < k; ++jj)
+      if (jj != j) piece_sums(jj, false);
+  }
+  if (tid == 0) {
+    double m1 = 0, m2 = 0;
+    for (int cl = 0; cl < cpg; ++cl) {
+      const int c = c0 + cl;
+      double A = 0, Bs = 0;
+      for (int pi = 0; pi < ppc; ++pi) { A += (double)sP[cl * ppc + pi][0]; Bs += (double)sP[cl * ppc + pi][1]; }
+      const float Af = (float)A, Bf = (float)Bs;
+      if (j == cl * ppc) { a.ab[((size_t)n * C + c) * 2] = Af; a.ab[((size_t)n * C + c) * 2 + 1] = Bf; }      // one writer per channel
+      float gc = a.gamma[c];
+      if (a.film) gc *= 1.0f + a.film[(size_t)(a.film_batch ? n : 0) * a.film_stride + c];
+      m1 += (double)gc * Af;
+      m2 += (double)gc * Bf;
+    }
+    const double N = (double)cpg * HWs;
+    sM[0] = (float)(m1 / N); sM[1] = (float)(m2 / N);
+  }
+  __syncthreads();
+  const float m1 = sM[0], m2 = sM[1];
+  {
+    const int c = c0 + j / ppc;
+    const size_t off = (size_t)(j % ppc) * GNL_PIECE;
+    const bool in_a = c < a.Ca;
+    const size_t xo = (in_a ? ((size_t)n * a.Ca + c) * HWs : ((size_t)n * a.Cb + (c - a.Ca)) * HWs) + off;
+    f32x4* o4 = reinterpret_cast<f32x4*>((in_a ? a.dxa : a.dxb) + xo);
+    const f32x4* a4 = a.add ? reinterpret_cast<const f32x4*>(a.add + ((size_t)n * C + c) * HWs + off) : nullptr;
+    f32x4* q4 = a.xact ? reinterpret_cast<f32x4*>(a.xact + ((size_t)n * C + c) * HWs + off) : nullptr;
+    const Coef cf = a.coef[(size_t)n * C + c];
+#pragma unroll
+    for (int u = 0; u < NQ / NT; ++u) {
+      const int p = tid + NT * u;
+      const f32x4 xv = xs[p], dv = ds[p];
+      f32x4 o = {0.f, 0.f, 0.f, 0.f}, uu = {0.f, 0.f, 0.f, 0.f};
+      if (a4) o = a4[p];
+      if (a.accumulate) { const f32x4 old = o4[p]; o += old; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float dt = dv[e];
+        const float tt = (xv[e] - cf.mean) * cf.scale + cf.offset;
+        if (a.act) {
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-tt));
+          dt *= sg * (1.0f + tt * (1.0f - sg));
+          uu[e] = tt * sg;
+        } else {
+          uu[e] = tt;
+        }
+        const float xh = (xv[e] - mean) * rstd;
+        o[e] += cf.scale * dt - rstd * (m1 + xh * m2);
+      }
+      o4[p] = o;
+      if (q4) q4[p] = uu;
+    }
+  }
+  if (k > 1 && tid == 0) {                                     // the last one out clears the slab's slots and its counter
+    const unsigned old = atomicAdd(depart, 1u);
+    if (old == (unsigned)k - 1) {
+      for (int jj = 0; jj < k; ++jj) __hip_atomic_store(slots + jj, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static int gn_bwd_lds_env() {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_GN_BWD_LDS"); env = e ? atoi(e) : 1; }
+  return env;
+}
+
+// does the LDS-resident kernel serve this call (shape, switch, counters)?  -> pieces per channel
+static bool gn_bwd_lds_plan(const GnBwdArgs& a, int* ppc_out) {
+  const int C = a.Ca + a.Cb, cpg = C / a.groups;
+  const size_t HW = (size_t)a.Hs * a.Ws;
+  if (!gn_bwd_lds_env() || !a.sync || a.resample != RS_NONE || HW % GNL_PIECE != 0 || (size_t)cpg * HW < 16384) return false;
+  const size_t k = (size_t)cpg * (HW / GNL_PIECE);
+  if (k > GNL_KMAX) return false;
+  if (((reinterpret_cast<size_t>(a.xa) | reinterpret_cast<size_t>(a.xb) | reinterpret_cast<size_t>(a.dact) | reinterpret_cast<size_t>(a.dxa) |
+        reinterpret_cast<size_t>(a.dxb) | reinterpret_cast<size_t>(a.add) | reinterpret_cast<size_t>(a.xact)) & 15) != 0) return false;
+  *ppc_out = (int)(HW / GNL_PIECE);
+  return true;
+}
+
+static int launch_gn_bwd_lds(const GnBwdArgs& a, int ppc, hipStream_t s) {
+  static int spin_us = -1;                                   // MCEDM_GN_BWD_SPIN_US: how long a workgroup waits for its partners (0: never)
+  if (spin_us < 0) { const char* e = getenv("MCEDM_GN_BWD_SPIN_US"); spin_us = e ? atoi(e) : 100; }
+  const unsigned ticks = (unsigned)spin_us * 100u;           // s_memrealtime: 100 MHz
+  const int k = (a.Ca + a.Cb) / a.groups * ppc;
+  hipLaunchKernelGGL(gn_bwd_lds_kernel, dim3((unsigned)a.B * a.groups * k), dim3(256), 0, s, a, ppc, ticks);
+  MCEDM_LAUNCH_CHECK("gn_bwd_lds_kernel");
+  return MCEDM_OK;
+}
+
+size_t gn_bwd_sync_words(int B, int groups) { return (size_t)B * groups * GNL_SYNC_WORDS; }
+
 int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
   const int C = a.Ca + a.Cb;
   MCEDM_REQUIRE(a.groups > 0 && C % a.groups == 0 && C / a.groups <= GN_MAX_CPG, "gn_bwd: bad groups (C=%d groups=%d)", C, a.groups);
   MCEDM_REQUIRE(a.dact && a.xa && a.coef && a.stats && a.gamma && a.dxa && a.ab && (a.Cb == 0 || (a.xb && a.dxb)), "gn_bwd: null pointer");
   MCEDM_REQUIRE(a.resample != RS_DOWN || (a.Hs % 2 == 0 && a.Ws % 2 == 0), "gn_bwd: odd source size for a 2x2 mean");
   MCEDM_REQUIRE(!a.xact || a.resample == RS_NONE, "gn_bwd: the activated input is emitted for un-resampled convs only");
+  int ppc = 0;
+  if (gn_bwd_lds_plan(a, &ppc)) {
+    ProfScope ps("gn_bwd_lds_kernel", 20.0 * a.B * (double)C * a.Hs * a.Ws, 4.0 * 3 * a.B * (double)C * a.Hs * a.Ws, s);
+    return launch_gn_bwd_lds(a, ppc, s);
+  }
   ProfScope ps("gn_bwd_kernel", 20.0 * a.B * (double)C * a.Hs * a.Ws, 4.0 * 3 * a.B * (double)C * a.Hs * a.Ws, s);
   // slabs of >= 64 KB: 1024-thread workgroups (at most two per CU instead of eight, so that fewer slabs are between their two passes
   // at any time and more of pass 2 is served by the memory-side cache: 5.78 -> 5.43 ms per S128 step, 3.12 -> 2.77 ms on the ch = 64 network)

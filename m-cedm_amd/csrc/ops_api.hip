@@ -117,20 +117,39 @@ extern "C" int mcedm_op_conv_wgrad(const float* dy, const float* xa, const float
   return launch_wgrad(a, k * k, dw, db, qkv_heads, act_tmp, (hipStream_t)stream);
 }
 
-extern "C" int mcedm_op_gn_bwd(const float* dact, int resample, const float* xa, const float* xb, int Ca, int Cb, int Hs,
+static int op_gn_bwd_impl(const float* dact, int resample, const float* xa, const float* xb, int Ca, int Cb, int Hs,
                                int Ws, int B, const mcedm_coef* coef, const float* stats, const float* gamma,
                                const float* beta, const float* film, int film_batch, int film_stride, int act,
                                float* dxa, float* dxb, int accumulate, const float* add, int add_mode, float* ab,
-                               float* dgamma, float* dbeta, float* dfilm, int dfilm_stride, void* stream) {
+                               float* dgamma, float* dbeta, float* dfilm, int dfilm_stride, unsigned* sync, void* stream) {
   MCEDM_REQUIRE(dact && xa && coef && stats && gamma && beta && dxa && ab && dgamma && dbeta, "op_gn_bwd: null pointer");
   const int C = Ca + Cb;
   MCEDM_REQUIRE(C >= 4, "op_gn_bwd: C < 4");
   GnBwdArgs a{dact, resample, xa, xb, Ca, Cb, Hs, Ws, B, C / 4 < 32 ? C / 4 : 32, reinterpret_cast<const Coef*>(coef),
               stats, gamma, film, film_batch, film_stride, act, dxa, dxb, accumulate, add, add_mode, C, ab};
+  a.sync = sync;
   int rc = launch_gn_bwd(a, (hipStream_t)stream);
   if (rc) return rc;
   return launch_gn_param_grads(ab, gamma, beta, film, film_batch, film_stride, B, C, dgamma, dbeta, dfilm, dfilm_stride,
                                (hipStream_t)stream);
+}
+
+extern "C" int mcedm_op_gn_bwd(const float* dact, int resample, const float* xa, const float* xb, int Ca, int Cb, int Hs,
+                               int Ws, int B, const mcedm_coef* coef, const float* stats, const float* gamma,
+                               const float* beta, const float* film, int film_batch, int film_stride, int act,
+                               float* dxa, float* dxb, int accumulate, const float* add, int add_mode, float* ab,
+                               float* dgamma, float* dbeta, float* dfilm, int dfilm_stride, void* stream) {
+  return op_gn_bwd_impl(dact, resample, xa, xb, Ca, Cb, Hs, Ws, B, coef, stats, gamma, beta, film, film_batch, film_stride, act, dxa, dxb,
+                        accumulate, add, add_mode, ab, dgamma, dbeta, dfilm, dfilm_stride, nullptr, stream);
+}
+
+extern "C" int mcedm_op_gn_bwd_sync(const float* dact, int resample, const float* xa, const float* xb, int Ca, int Cb, int Hs,
+                                    int Ws, int B, const mcedm_coef* coef, const float* stats, const float* gamma,
+                                    const float* beta, const float* film, int film_batch, int film_stride, int act,
+                                    float* dxa, float* dxb, int accumulate, const float* add, int add_mode, float* ab,
+                                    float* dgamma, float* dbeta, float* dfilm, int dfilm_stride, unsigned int* sync, void* stream) {
+  return op_gn_bwd_impl(dact, resample, xa, xb, Ca, Cb, Hs, Ws, B, coef, stats, gamma, beta, film, film_batch, film_stride, act, dxa, dxb,
+                        accumulate, add, add_mode, ab, dgamma, dbeta, dfilm, dfilm_stride, sync, stream);
 }
 
 extern "C" int mcedm_op_attention_bwd(const float* qkv, const float* a, const float* da, float* dqkv, float* lse_scratch,

@@ -34,6 +34,7 @@ EXPORTS = [
     "mcedm_unet_plan_set_variant", "mcedm_ddpm_plan_set_variant", "mcedm_heun_sample_rng",
 ]
 # kernel families that exist in two forms (include/mcedm_hip.h MCEDM_VARIANT_*)
+GN_SYNC_WORDS = 130          # MCEDM_GN_SYNC_WORDS
 VARIANTS = {"conv_wino": 0, "conv_wino1": 1, "conv_resident": 2, "conv8": 3, "attn_fused": 4, "wgrad_wino": 5, "conv1x1_reg": 6}
 
 
@@ -881,13 +882,15 @@ def _bind_ops():
                                         vp, vp, vp, vp]
     lib.mcedm_op_gn_bwd.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp,
                                     i32, vp, i32, vp, vp, vp, vp, i32, vp]
+    lib.mcedm_op_gn_bwd_sync.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp,
+                                         i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.mcedm_op_attention_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.mcedm_op_conv_wino_packed_floats.argtypes = [i32, i32]
     lib.mcedm_op_conv_wino_packed_floats.restype = sz
     lib.mcedm_op_pack_conv_wino.argtypes = [vp, i32, i32, vp, vp]
     lib.mcedm_op_conv_wino.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp]
     for n in ("mcedm_op_pack_conv", "mcedm_op_gn_coef", "mcedm_op_conv", "mcedm_op_attention", "mcedm_op_embedding", "mcedm_op_conv_wgrad",
-              "mcedm_op_gn_bwd", "mcedm_op_attention_bwd", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino"):
+              "mcedm_op_gn_bwd", "mcedm_op_gn_bwd_sync", "mcedm_op_attention_bwd", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino"):
         getattr(lib, n).restype = C.c_int
     _OPS_BOUND = True
     return lib
@@ -898,7 +901,7 @@ OP_EXPORTS = ["mcedm_op_conv_packed_floats", "mcedm_op_pack_conv", "mcedm_op_gn_
               "mcedm_op_wgrad_scratch_floats", "mcedm_op_conv_wgrad", "mcedm_op_gn_bwd", "mcedm_op_attention_bwd",
               "mcedm_op_set_conv_debug", "mcedm_op_set_conv8", "mcedm_op_set_conv_resident", "mcedm_op_set_attn_fused", "mcedm_op_embedding",
               "mcedm_op_conv_wino_packed_floats", "mcedm_op_pack_conv_wino", "mcedm_op_conv_wino", "mcedm_op_set_conv_wino", "mcedm_op_set_conv_wino1",
-              "mcedm_op_set_wgrad_wino", "mcedm_op_set_conv1x1_reg"]
+              "mcedm_op_set_wgrad_wino", "mcedm_op_set_conv1x1_reg", "mcedm_op_gn_bwd_sync"]
 
 
 def prof_enable(on: bool) -> None:
@@ -1072,8 +1075,9 @@ def op_conv_wgrad(dy, xa, xb, k, coef=None, coef_batch=1, act=0, resample=RS_NON
 
 
 def op_gn_bwd(dact, xa, xb, coef, stats, gamma, beta, film=None, film_batch=0, film_stride=0, act=1,
-              resample=RS_NONE, add=None, add_mode=0, dx_init=None):
-    """-> (dxa, dxb, dgamma, dbeta, dfilm or None); dx_init (tuple) makes the call accumulate into copies of it."""
+              resample=RS_NONE, add=None, add_mode=0, dx_init=None, sync=None):
+    """-> (dxa, dxb, dgamma, dbeta, dfilm or None); dx_init (tuple) makes the call accumulate into copies of it.  sync: a zeroed
+    int32 tensor of GN_SYNC_WORDS * B * groups words (mcedm_op_gn_bwd_sync: slabs split over workgroups keep their pieces in LDS)."""
     lib = _bind_ops()
     B, Ca, Hs, Ws = xa.shape
     Cb = xb.shape[1] if xb is not None else 0
@@ -1083,10 +1087,15 @@ def op_gn_bwd(dact, xa, xb, coef, stats, gamma, beta, film=None, film_batch=0, f
     ab = torch.empty((B, Ct, 2), dtype=torch.float32, device=xa.device)
     dg, dbt = torch.empty(Ct, device=xa.device), torch.empty(Ct, device=xa.device)
     dfilm = torch.zeros((B if film_batch else 1, 2 * Ct), dtype=torch.float32, device=xa.device) if film is not None else None
-    check(lib.mcedm_op_gn_bwd(_ptr(dact), resample, _ptr(xa), _ptr(xb), Ca, Cb, Hs, Ws, B, _ptr(coef), _ptr(stats),
-                              _ptr(gamma), _ptr(beta), _ptr(film), film_batch, film_stride, act, _ptr(dxa), _ptr(dxb),
-                              int(dx_init is not None), _ptr(add), add_mode, _ptr(ab), _ptr(dg), _ptr(dbt), _ptr(dfilm),
-                              2 * Ct, _stream()), "op_gn_bwd")
+    args = (_ptr(dact), resample, _ptr(xa), _ptr(xb), Ca, Cb, Hs, Ws, B, _ptr(coef), _ptr(stats),
+            _ptr(gamma), _ptr(beta), _ptr(film), film_batch, film_stride, act, _ptr(dxa), _ptr(dxb),
+            int(dx_init is not None), _ptr(add), add_mode, _ptr(ab), _ptr(dg), _ptr(dbt), _ptr(dfilm), 2 * Ct)
+    if sync is not None:
+        if sync.dtype != torch.int32 or sync.numel() < GN_SYNC_WORDS * B * min(32, Ct // 4) or not sync.is_cuda:
+            raise ValueError("op_gn_bwd: sync must be a device int32 tensor of at least GN_SYNC_WORDS * B * groups zeros")
+        check(lib.mcedm_op_gn_bwd_sync(*args, _ptr(sync, torch.int32), _stream()), "op_gn_bwd_sync")
+    else:
+        check(lib.mcedm_op_gn_bwd(*args, _stream()), "op_gn_bwd")
     return dxa, dxb, dg, dbt, dfilm
 
 

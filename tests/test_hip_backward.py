@@ -95,9 +95,16 @@ def test_conv_wgrad_and_dgrad(lib, shape):
     # (B, Ca, Cb, Hs, Ws, resample, act, film, add_mode, accumulate)
     (2, 64, 0, 8, 8, 0, 1, True, 0, False), (2, 64, 64, 8, 12, 0, 1, False, 1, False), (2, 64, 0, 8, 8, 1, 1, False, 2, True),
     (2, 64, 0, 16, 16, 2, 1, False, 2, False), (3, 128, 0, 6, 6, 0, 0, False, 1, True), (2, 256, 0, 4, 4, 0, 1, True, 0, False),
+    # larger slabs on the two-pass kernel (no counters given) ...
+    (2, 128, 0, 32, 32, 0, 1, True, 1, False), (2, 64, 64, 64, 64, 0, 1, False, 1, True), (1, 64, 0, 32, 64, 0, 0, True, 0, False),
+    # ... and on gn_bwd_lds_kernel (round 5: pieces of 4096 elements stay in LDS between the passes; 16 / 16 / 8 / 4 workgroups per
+    # slab exchange their sums through `sync`)
+    (2, 64, 0, 128, 128, 0, 1, True, 1, False, "sync"), (3, 128, 0, 128, 128, 0, 1, False, 0, True, "sync"),
+    (2, 128, 128, 64, 64, 0, 1, True, 1, False, "sync"), (2, 64, 64, 64, 64, 0, 0, False, 1, True, "sync"),
 ])
 def test_gn_film_silu_backward(lib, case):
-    B, Ca, Cb, Hs, Ws, rs, act, use_film, add_mode, accumulate = case
+    use_sync = len(case) > 10
+    B, Ca, Cb, Hs, Ws, rs, act, use_film, add_mode, accumulate = case[:10]
     tag = "t/bwd/gn/" + "_".join(map(str, case))
     C = Ca + Cb
     Hc, Wc = (Hs * 2, Ws * 2) if rs == 1 else ((Hs // 2, Ws // 2) if rs == 2 else (Hs, Ws))
@@ -136,10 +143,20 @@ def test_gn_film_silu_backward(lib, case):
     # HIP
     coef, stats = lib.op_gn_coef(dev(xa), dev(xb) if Cb else None, dev(gamma), dev(beta), film=dev(film) if use_film else None,
                                  film_batch=1, film_stride=2 * C, want_stats=True)
+    sync = torch.zeros(lib.GN_SYNC_WORDS * B * min(32, C // 4), dtype=torch.int32, device="cuda") if use_sync else None
+    lib.prof_enable(True)
     dxa, dxb, dg, dbt, dfilm = lib.op_gn_bwd(dev(dact), dev(xa), dev(xb) if Cb else None, coef, stats, dev(gamma), dev(beta),
                                              film=dev(film) if use_film else None, film_batch=1, film_stride=2 * C, act=act,
                                              resample=rs, add=dev(add) if add is not None else None, add_mode=add_mode,
-                                             dx_init=(dev(init[0]), dev(init[1]) if Cb else None) if accumulate else None)
+                                             dx_init=(dev(init[0]), dev(init[1]) if Cb else None) if accumulate else None,
+                                             sync=sync)
+    torch.cuda.synchronize()
+    names = {r["name"] for r in lib.prof_report()}
+    lib.prof_enable(False)
+    on_chip = use_sync and rs == 0 and (Hs * Ws) % 4096 == 0 and (C // min(32, C // 4)) * Hs * Ws >= 16384
+    assert ("gn_bwd_lds_kernel" in names) == on_chip and ("gn_bwd_kernel" in names) != on_chip, (names, case)
+    if use_sync:
+        assert int(sync.abs().sum()) == 0, "the exchange area must be left zero"
     close(dxa, gxa, what="dxa")
     if Cb:
         close(dxb, gxb, what="dxb")
@@ -147,6 +164,46 @@ def test_gn_film_silu_backward(lib, case):
     close(dbt, gb, what="dbeta")
     if use_film:
         close(dfilm, gfilm, what="dfilm")
+
+
+def test_gn_backward_partner_wait_timeout_gives_the_same_bits(lib, tmp_path):
+    """gn_bwd_lds_kernel, groups split over workgroups: a workgroup whose (bounded) wait for its partners' channel sums runs out
+    computes them itself from global memory.  With MCEDM_GN_BWD_SPIN_US=0 (read once per process: a child process) most workgroups
+    take that path; the result must equal the waiting run bit for bit, and the counters must come back zero."""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import importlib, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+L = importlib.import_module("m-cedm_amd.lib"); L.load()
+g = torch.Generator().manual_seed(3)
+B, C, H, W = 4, 128, 128, 128
+x = (torch.randn(B, C, H, W, generator=g) * 1.3 + 0.4).cuda()
+dact = torch.randn(B, C, H, W, generator=g).cuda()
+gamma, beta = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+coef, stats = L.op_gn_coef(x, None, gamma, beta, want_stats=True)
+out = {}
+for rep in range(2):
+    sync = torch.zeros(L.GN_SYNC_WORDS * B * 32, dtype=torch.int32, device="cuda")
+    dxa, _, dg, dbt, _ = L.op_gn_bwd(dact, x, None, coef, stats, gamma, beta, act=1, sync=sync)
+    torch.cuda.synchronize()
+    assert int(sync.abs().sum()) == 0
+    out[f"dx{rep}"] = dxa.cpu().numpy(); out[f"dg{rep}"] = dg.cpu().numpy(); out[f"db{rep}"] = dbt.cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for us in ("100", "0"):
+        path = str(tmp_path / f"spin{us}.npz")
+        r = subprocess.run([sys.executable, "-c", script, root, path], env=dict(os.environ, MCEDM_GN_BWD_SPIN_US=us), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[us] = dict(np.load(path))
+    for k in res["100"]:
+        assert np.isfinite(res["100"][k]).all()
+        assert np.array_equal(res["100"][k], res["0"][k]), k
+    assert np.array_equal(res["100"]["dx0"], res["100"]["dx1"]) and np.array_equal(res["0"]["dx0"], res["0"]["dx1"])
 
 
 def packed_qkv(qkv, heads):
