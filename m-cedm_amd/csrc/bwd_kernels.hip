@@ -380,6 +380,125 @@ static int launch_gn_bwd_lds(const GnBwdArgs& a, int ppc, hipStream_t s) {
 
 size_t gn_bwd_sync_words(int B, int groups) { return (size_t)B * groups * GNL_SYNC_WORDS; }
 
+// ---- small slabs: everything in registers, one memory round trip (round 5) ---------------------------------------------------
+// gn_bwd_kernel walks a slab channel by channel -- load, reduce behind two barriers, next channel -- and then again for pass 2:
+// for a slab of 4 x 32^2 elements that is eight dependent memory round trips and 16 barriers for 32 KB of data (20 us per launch;
+// the largest single item of config 2's training step).  Here a thread owns R quads of the slab (<= 8192 elements per slab), ALL
+// loads (x, dact, the extra gradient, the accumulated dx) are issued up front, the per-channel sums come out of one segmented
+// shuffle reduction + one pass over <= 128 partials in a fixed order, and pass 2 runs on the registers.  Un-resampled inputs.
+template <int R>
+__global__ __launch_bounds__(256) void gn_bwd_reg_kernel(GnBwdArgs a, int segshift) {
+  const int C = a.Ca + a.Cb;
+  const int cpg = C / a.groups;
+  const int n = blockIdx.x / a.groups, g = blockIdx.x - n * a.groups;
+  const int c0 = g * cpg;
+  const int HWs = a.Hs * a.Ws, HW4 = HWs >> 2, Q = cpg * HW4;
+  const float mean = a.stats[((size_t)n * a.groups + g) * 2], rstd = a.stats[((size_t)n * a.groups + g) * 2 + 1];
+  const int tid = threadIdx.x;
+  const int seg = 1 << segshift;                               // lanes that share a channel (<= one wave)
+  __shared__ double red[R][16][2];
+  __shared__ float sM[2];
+  f32x4 xv[R], dv[R], av[R], ov[R];
+  Coef cf[R];
+  size_t xoff[R], coff[R]; int cc[R]; bool ok[R];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int q = tid + 256 * r;
+    ok[r] = q < Q;
+    const int cl = ok[r] ? q / HW4 : 0, p = ok[r] ? q - cl * HW4 : 0;
+    const int c = c0 + cl;
+    cc[r] = c;
+    const bool in_a = c < a.Ca;
+    xoff[r] = (in_a ? ((size_t)n * a.Ca + c) * HWs : ((size_t)n * a.Cb + (c - a.Ca)) * HWs) + 4 * (size_t)p;
+    coff[r] = ((size_t)n * C + c) * HWs + 4 * (size_t)p;
+    xv[r] = dv[r] = av[r] = ov[r] = zero4;
+    cf[r] = a.coef[(size_t)n * C + c];
+    if (ok[r]) {
+      xv[r] = *reinterpret_cast<const f32x4*>((in_a ? a.xa : a.xb) + xoff[r]);
+      dv[r] = *reinterpret_cast<const f32x4*>(a.dact + coff[r]);
+      if (a.add) av[r] = *reinterpret_cast<const f32x4*>(a.add + coff[r]);
+      if (a.accumulate) ov[r] = *reinterpret_cast<const f32x4*>((in_a ? a.dxa : a.dxb) + xoff[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float dt = dv[r][e];
+      if (a.act) dt *= dsilu((xv[r][e] - cf[r].mean) * cf[r].scale + cf[r].offset);
+      pa += dt;
+      pb += dt * ((xv[r][e] - mean) * rstd);
+    }
+    double da = pa, db = pb;
+    for (int off = seg >> 1; off > 0; off >>= 1) { da += __shfl_xor(da, off); db += __shfl_xor(db, off); }
+    if ((tid & (seg - 1)) == 0) { red[r][tid >> segshift][0] = da; red[r][tid >> segshift][1] = db; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double m1 = 0, m2 = 0;
+    for (int cl = 0; cl < cpg; ++cl) {                         // the partials of channel cl: quads [cl HW4, (cl + 1) HW4), in quad order
+      double A = 0, Bs = 0;
+      for (int q0 = cl * HW4; q0 < (cl + 1) * HW4; q0 += seg) {
+        const int r = q0 >> 8, sgi = (q0 & 255) >> segshift;
+        A += red[r][sgi][0]; Bs += red[r][sgi][1];
+      }
+      const int c = c0 + cl;
+      const float Af = (float)A, Bf = (float)Bs;
+      a.ab[((size_t)n * C + c) * 2] = Af; a.ab[((size_t)n * C + c) * 2 + 1] = Bf;
+      float gc = a.gamma[c];
+      if (a.film) gc *= 1.0f + a.film[(size_t)(a.film_batch ? n : 0) * a.film_stride + c];
+      m1 += (double)gc * Af;
+      m2 += (double)gc * Bf;
+    }
+    const double N = (double)cpg * HWs;
+    sM[0] = (float)(m1 / N); sM[1] = (float)(m2 / N);
+  }
+  __syncthreads();
+  const float m1 = sM[0], m2 = sM[1];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!ok[r]) continue;
+    f32x4 o = av[r] + ov[r], u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float dt = dv[r][e];
+      const float tt = (xv[r][e] - cf[r].mean) * cf[r].scale + cf[r].offset;
+      if (a.act) {
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-tt));
+        dt *= sg * (1.0f + tt * (1.0f - sg));
+        u[e] = tt * sg;
+      } else {
+        u[e] = tt;
+      }
+      const float xh = (xv[r][e] - mean) * rstd;
+      o[e] += cf[r].scale * dt - rstd * (m1 + xh * m2);
+    }
+    const bool in_a = cc[r] < a.Ca;
+    *reinterpret_cast<f32x4*>((in_a ? a.dxa : a.dxb) + xoff[r]) = o;
+    if (a.xact) *reinterpret_cast<f32x4*>(a.xact + coff[r]) = u;
+  }
+}
+
+// quads per thread (1, 2, 4, 8) when gn_bwd_reg_kernel serves the call, else 0; *segshift: log2 of the lanes that share a channel
+static int gn_bwd_reg_plan(const GnBwdArgs& a, int* segshift) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_GN_BWD_REG"); env = e ? atoi(e) : 1; }
+  const int C = a.Ca + a.Cb, cpg = C / a.groups;
+  const size_t HW = (size_t)a.Hs * a.Ws;
+  if (!env || a.resample != RS_NONE || HW % 4 != 0 || (size_t)cpg * HW > 8192) return 0;
+  const int HW4 = (int)(HW / 4);
+  int sh = 0;
+  if (HW4 >= 64) { if (HW4 % 64 != 0) return 0; sh = 6; }
+  else { if (HW4 < 16 || (HW4 & (HW4 - 1)) != 0) return 0; while ((1 << sh) < HW4) ++sh; }
+  if (((reinterpret_cast<size_t>(a.xa) | reinterpret_cast<size_t>(a.xb) | reinterpret_cast<size_t>(a.dact) | reinterpret_cast<size_t>(a.dxa) |
+        reinterpret_cast<size_t>(a.dxb) | reinterpret_cast<size_t>(a.add) | reinterpret_cast<size_t>(a.xact)) & 15) != 0) return 0;
+  *segshift = sh;
+  const int Q = cpg * HW4;
+  return Q <= 256 ? 1 : Q <= 512 ? 2 : Q <= 1024 ? 4 : 8;
+}
+
 int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
   const int C = a.Ca + a.Cb;
   MCEDM_REQUIRE(a.groups > 0 && C % a.groups == 0 && C / a.groups <= GN_MAX_CPG, "gn_bwd: bad groups (C=%d groups=%d)", C, a.groups);
@@ -390,6 +509,17 @@ int launch_gn_bwd(const GnBwdArgs& a, hipStream_t s) {
   if (gn_bwd_lds_plan(a, &ppc)) {
     ProfScope ps("gn_bwd_lds_kernel", 20.0 * a.B * (double)C * a.Hs * a.Ws, 4.0 * 3 * a.B * (double)C * a.Hs * a.Ws, s);
     return launch_gn_bwd_lds(a, ppc, s);
+  }
+  int segshift = 0;
+  if (const int R = gn_bwd_reg_plan(a, &segshift)) {
+    ProfScope ps("gn_bwd_reg_kernel", 20.0 * a.B * (double)C * a.Hs * a.Ws, 4.0 * 3 * a.B * (double)C * a.Hs * a.Ws, s);
+    const dim3 grid(a.B * a.groups);
+    if (R == 1) hipLaunchKernelGGL(gn_bwd_reg_kernel<1>, grid, dim3(256), 0, s, a, segshift);
+    else if (R == 2) hipLaunchKernelGGL(gn_bwd_reg_kernel<2>, grid, dim3(256), 0, s, a, segshift);
+    else if (R == 4) hipLaunchKernelGGL(gn_bwd_reg_kernel<4>, grid, dim3(256), 0, s, a, segshift);
+    else hipLaunchKernelGGL(gn_bwd_reg_kernel<8>, grid, dim3(256), 0, s, a, segshift);
+    MCEDM_LAUNCH_CHECK("gn_bwd_reg_kernel");
+    return MCEDM_OK;
   }
   ProfScope ps("gn_bwd_kernel", 20.0 * a.B * (double)C * a.Hs * a.Ws, 4.0 * 3 * a.B * (double)C * a.Hs * a.Ws, s);
   // slabs of >= 64 KB: 1024-thread workgroups (at most two per CU instead of eight, so that fewer slabs are between their two passes

@@ -95,8 +95,12 @@ def test_conv_wgrad_and_dgrad(lib, shape):
     # (B, Ca, Cb, Hs, Ws, resample, act, film, add_mode, accumulate)
     (2, 64, 0, 8, 8, 0, 1, True, 0, False), (2, 64, 64, 8, 12, 0, 1, False, 1, False), (2, 64, 0, 8, 8, 1, 1, False, 2, True),
     (2, 64, 0, 16, 16, 2, 1, False, 2, False), (3, 128, 0, 6, 6, 0, 0, False, 1, True), (2, 256, 0, 4, 4, 0, 1, True, 0, False),
-    # larger slabs on the two-pass kernel (no counters given) ...
-    (2, 128, 0, 32, 32, 0, 1, True, 1, False), (2, 64, 64, 64, 64, 0, 1, False, 1, True), (1, 64, 0, 32, 64, 0, 0, True, 0, False),
+    # slabs of up to 8192 elements: gn_bwd_reg_kernel (round 5: the slab in registers; 1 / 4 / 8 / 2 / 8 quads per thread; the first
+    # case of this list is one too: 16 lanes per channel) ...
+    (2, 128, 0, 32, 32, 0, 1, True, 1, False), (1, 64, 0, 32, 64, 0, 0, True, 0, False), (2, 64, 64, 16, 32, 0, 1, False, 1, True),
+    (3, 256, 0, 16, 16, 0, 1, True, 0, True), (2, 32, 0, 32, 32, 0, 1, False, 0, False),
+    # ... a larger slab on the two-pass kernel (no counters given) ...
+    (2, 64, 64, 64, 64, 0, 1, False, 1, True),
     # ... and on gn_bwd_lds_kernel (round 5: pieces of 4096 elements stay in LDS between the passes; 16 / 16 / 8 / 4 workgroups per
     # slab exchange their sums through `sync`)
     (2, 64, 0, 128, 128, 0, 1, True, 1, False, "sync"), (3, 128, 0, 128, 128, 0, 1, False, 0, True, "sync"),
@@ -154,7 +158,11 @@ def test_gn_film_silu_backward(lib, case):
     names = {r["name"] for r in lib.prof_report()}
     lib.prof_enable(False)
     on_chip = use_sync and rs == 0 and (Hs * Ws) % 4096 == 0 and (C // min(32, C // 4)) * Hs * Ws >= 16384
-    assert ("gn_bwd_lds_kernel" in names) == on_chip and ("gn_bwd_kernel" in names) != on_chip, (names, case)
+    cpg, hw = C // min(32, C // 4), Hs * Ws
+    in_regs = (not on_chip and rs == 0 and hw % 4 == 0 and cpg * hw <= 8192
+               and ((hw // 4) % 64 == 0 or (16 <= hw // 4 < 64 and (hw // 4) & (hw // 4 - 1) == 0)))
+    want = "gn_bwd_lds_kernel" if on_chip else "gn_bwd_reg_kernel" if in_regs else "gn_bwd_kernel"
+    assert {n_ for n_ in names if n_.startswith("gn_bwd")} == {want}, (names, want, case)
     if use_sync:
         assert int(sync.abs().sum()) == 0, "the exchange area must be left zero"
     close(dxa, gxa, what="dxa")
