@@ -75,7 +75,7 @@ REPAINT = dict(ch=64, ch_mult=(1, 1, 1), attn=(32,), H=128, W=128, batch=32, n_r
 ALGORITHMIC = {"s32": (1.1115, 20.3), "ref128": (18.787, 230.0), "s128l3": (70.759, 452.5), "s128": (70.843, 463.9),
                "darcy128": (70.843, 463.9), "ref_default": (18.787, 230.0)}
 # kernels bound by HBM rather than by the matrix pipe (their `gbps` against the 8 TB/s roofline is the number that matters)
-HBM_BOUND_KERNELS = ("gn_bwd_kernel", "gn_bwd_lds_kernel", "conv_small_cout_kernel", "act_materialize_kernel", "gn_coef_kernel", "wgrad_reduce_kernel",
+HBM_BOUND_KERNELS = ("gn_bwd_kernel", "gn_bwd_lds_kernel", "gn_bwd_reg_kernel", "conv_small_cout_kernel", "act_materialize_kernel", "gn_coef_kernel", "wgrad_reduce_kernel",
                      "wgrad_wino_reduce_kernel", "wgrad_thin", "adam_ema_kernel", "heun", "edm_loss_kernel", "sqnorm_kernel", "gelu", "pack_batch_kernel",
                      "pack_conv_kernel", "wino_pack_kernel")
 TRAIN_LEG_TIMEOUT_S = 300      # watchdog of the multi-rank training leg (an untimed extra of the line)
