@@ -196,6 +196,24 @@ __global__ __launch_bounds__(NT) void gn_bwd_kernel(GnBwdArgs a) {
 // and waits for the k - 1 other pieces of the slab -- for a BOUNDED time (partners are adjacent workgroup ids: dispatched together).  A workgroup whose wait runs out computes the missing pieces' sums itself from global memory (the same
 // function, the same bits), so no schedule can hang the kernel; the last workgroup to leave clears the exchange area (zero on
 // entry, zero on exit).  Piece sums are added per channel in piece order in fp64: deterministic.  Un-resampled inputs only.
+// four consecutive source pixels (one row, Ws % 4 == 0) of the gradient that arrives through the forward resampling: the vector form
+// of fetch_resampled (same additions in the same order)
+__device__ __forceinline__ f32x4 fetch_resampled_quad(const float* plane, int mode, int e0, int Ws) {
+  if (mode == RS_NONE) return *reinterpret_cast<const f32x4*>(plane + e0);
+  const int ys = e0 / Ws, xs = e0 - ys * Ws;
+  if (mode == RS_UP) {
+    const int Wc = 2 * Ws;
+    const float* q = plane + (size_t)(2 * ys) * Wc + 2 * xs;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(q), a1 = *reinterpret_cast<const f32x4*>(q + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(q + Wc), b1 = *reinterpret_cast<const f32x4*>(q + Wc + 4);
+    return f32x4{(a0[0] + a0[1]) + (b0[0] + b0[1]), (a0[2] + a0[3]) + (b0[2] + b0[3]), (a1[0] + a1[1]) + (b1[0] + b1[1]),
+                 (a1[2] + a1[3]) + (b1[2] + b1[3])};
+  }
+  const int Wc = Ws >> 1;
+  const f32x2 v = *reinterpret_cast<const f32x2*>(plane + (size_t)(ys >> 1) * Wc + (xs >> 1));
+  return f32x4{0.25f * v[0], 0.25f * v[0], 0.25f * v[1], 0.25f * v[1]};
+}
+
 constexpr int GNL_PIECE = 4096;                 // elements per workgroup
 constexpr int GNL_KMAX = 64;                    // workgroups per slab
 constexpr int GNL_SYNC_WORDS = 2 + 2 * GNL_KMAX;   // per slab: a departure counter (+ 1 unused) and KMAX 64-bit slots
@@ -213,6 +231,7 @@ __global__ __launch_bounds__(256) void gn_bwd_lds_kernel(GnBwdArgs a, int ppc, u
   const int n = slab / a.groups, g = slab - n * a.groups;
   const int c0 = g * cpg;
   const int HWs = a.Hs * a.Ws;
+  const int HWc = a.resample == RS_UP ? HWs * 4 : (a.resample == RS_DOWN ? HWs / 4 : HWs);
   const unsigned nslabs = gridDim.x / k;
   unsigned* const depart = a.sync + slab;                       // [nslabs] counters, [nslabs] unused, then [nslabs][KMAX] 64-bit slots
   unsigned long long* const slots = reinterpret_cast<unsigned long long*>(a.sync + 2 * nslabs) + (size_t)slab * GNL_KMAX;
@@ -225,11 +244,14 @@ __global__ __launch_bounds__(256) void gn_bwd_lds_kernel(GnBwdArgs a, int ppc, u
     const size_t off = (size_t)(jj % ppc) * GNL_PIECE;
     const float* x = ((c < a.Ca) ? a.xa + ((size_t)n * a.Ca + c) * HWs : a.xb + ((size_t)n * a.Cb + (c - a.Ca)) * HWs) + off;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(a.dact + ((size_t)n * C + c) * HWs + off);
+    const float* dpl = a.dact + ((size_t)n * C + c) * HWc;
     const Coef cf = a.coef[(size_t)n * C + c];
     f32x4 xv[NQ / NT], dv[NQ / NT];
 #pragma unroll
-    for (int u = 0; u < NQ / NT; ++u) { xv[u] = x4[tid + NT * u]; dv[u] = d4[tid + NT * u]; }
+    for (int u = 0; u < NQ / NT; ++u) {
+      xv[u] = x4[tid + NT * u];
+      dv[u] = fetch_resampled_quad(dpl, a.resample, (int)off + 4 * (tid + NT * u), a.Ws);
+    }
     float pa = 0.f, pb = 0.f;
 #pragma unroll
     for (int u = 0; u < NQ / NT; ++u) {
@@ -312,7 +334,8 @@ __global__ __launch_bounds__(256) void gn_bwd_lds_kernel(GnBwdArgs a, int ppc, u
     const bool in_a = c < a.Ca;
     const size_t xo = (in_a ? ((size_t)n * a.Ca + c) * HWs : ((size_t)n * a.Cb + (c - a.Ca)) * HWs) + off;
     f32x4* o4 = reinterpret_cast<f32x4*>((in_a ? a.dxa : a.dxb) + xo);
-    const f32x4* a4 = a.add ? reinterpret_cast<const f32x4*>(a.add + ((size_t)n * C + c) * HWs + off) : nullptr;
+    const float* apl = a.add ? a.add + ((size_t)n * C + c) * (a.add_mode == 2 ? HWc : HWs) : nullptr;
+    const int amode = a.add_mode == 2 ? a.resample : RS_NONE;
     f32x4* q4 = a.xact ? reinterpret_cast<f32x4*>(a.xact + ((size_t)n * C + c) * HWs + off) : nullptr;
     const Coef cf = a.coef[(size_t)n * C + c];
 #pragma unroll
@@ -320,7 +343,7 @@ __global__ __launch_bounds__(256) void gn_bwd_lds_kernel(GnBwdArgs a, int ppc, u
       const int p = tid + NT * u;
       const f32x4 xv = xs[p], dv = ds[p];
       f32x4 o = {0.f, 0.f, 0.f, 0.f}, uu = {0.f, 0.f, 0.f, 0.f};
-      if (a4) o = a4[p];
+      if (apl) o = fetch_resampled_quad(apl, amode, (int)off + 4 * p, a.Ws);
       if (a.accumulate) { const f32x4 old = o4[p]; o += old; }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -359,7 +382,8 @@ static int gn_bwd_lds_env() {
 static bool gn_bwd_lds_plan(const GnBwdArgs& a, int* ppc_out) {
   const int C = a.Ca + a.Cb, cpg = C / a.groups;
   const size_t HW = (size_t)a.Hs * a.Ws;
-  if (!gn_bwd_lds_env() || !a.sync || a.resample != RS_NONE || HW % GNL_PIECE != 0 || (size_t)cpg * HW < 16384) return false;
+  if (!gn_bwd_lds_env() || !a.sync || HW % GNL_PIECE != 0 || (size_t)cpg * HW < 16384) return false;
+  if (a.resample != RS_NONE && (a.Ws % 4 != 0 || a.Hs % 2 != 0 || (a.resample != RS_UP && a.resample != RS_DOWN))) return false;
   const size_t k = (size_t)cpg * (HW / GNL_PIECE);
   if (k > GNL_KMAX) return false;
   if (((reinterpret_cast<size_t>(a.xa) | reinterpret_cast<size_t>(a.xb) | reinterpret_cast<size_t>(a.dact) | reinterpret_cast<size_t>(a.dxa) |
