@@ -140,8 +140,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, const float*
   if (t_begin >= t_end) return;      // whole workgroup (depends on blockIdx only)
 
   const size_t HW = (size_t)p.H * p.W;
+  // xact == nullptr: the operand is the un-transformed cat(xa, xb) itself, read in place (the decoder's skip projections: no 537 MB copy)
+  auto plane_of = [&](int n, int ci) -> const float* {
+    if (xact) return xact + ((size_t)n * Cin + ci) * HW;
+    return ci < p.Ca ? p.xa + ((size_t)n * p.Ca + ci) * HW : p.xb + ((size_t)n * p.Cb + (ci - p.Ca)) * HW;
+  };
   const bool vec_ok = (p.W % 4 == 0) && ((reinterpret_cast<size_t>(p.dy) & 15) == 0) &&
-                      ((reinterpret_cast<size_t>(xact) & 15) == 0);
+                      (((xact ? reinterpret_cast<size_t>(xact) : (reinterpret_cast<size_t>(p.xa) | reinterpret_cast<size_t>(p.xb))) & 15) == 0);
   const int tiles_img = tiles_x * tiles_y;
   constexpr int XROWS = C::IT * C::ROWS;          // rows of the input tile (channel x tile row)
   constexpr int DROWS4 = C::CT * C::NPIX / 4;     // float4 groups of the dY tile
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, const float*
       const int ci = ci0 + cil;
       const int y = y0 + r - C::HALO;
       const bool row_ok = ci < Cin && (unsigned)y < (unsigned)p.H;
-      const float* src = xact + ((size_t)n * Cin + (ci < Cin ? ci : Cin - 1)) * HW +
+      const float* src = plane_of(n, ci < Cin ? ci : Cin - 1) +
                          (size_t)(y < 0 ? 0 : (y < p.H ? y : p.H - 1)) * p.W;
       unsigned bits = 0;
       if (C::HALO) {
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs p, const float*
       const int y = y0 + r - C::HALO;
       float* dst = al + cil * C::AP + r * C::PITCH;
       const bool row_ok = ci < Cin && (unsigned)y < (unsigned)p.H;
-      const float* src = xact + ((size_t)n * Cin + (row_ok ? ci : 0)) * HW + (size_t)(row_ok ? y : 0) * p.W;
+      const float* src = plane_of(n, row_ok ? ci : 0) + (size_t)(row_ok ? y : 0) * p.W;
       if (C::HALO) {
         dst[0] = (row_ok && x0 > 0) ? src[x0 - 1] : 0.f;
         dst[C::PITCH - 1] = (row_ok && x0 + C::PW < p.W) ? src[x0 + C::PW] : 0.f;
@@ -406,7 +411,8 @@ static int launch_wg(const WgradArgs& a, const float* xact, int* nact, hipStream
   if (prof_enabled()) snprintf(name, sizeof(name), "wgrad_kernel<WgCfg<%d, %d, %d>>", C::PH, C::PW, C::TAPS);
   const double flops = 2.0 * a.B * a.H * (double)a.W * a.Cout * (a.Ca + a.Cb) * C::TAPS;
   ProfScope ps(name, flops, 4.0 * a.B * ((double)a.Cout * a.H * a.W + (double)(a.Ca + a.Cb) * a.H * a.W), s);
-  const bool fast = (a.W % 4 == 0) && ((reinterpret_cast<size_t>(a.dy) & 15) == 0) && ((reinterpret_cast<size_t>(xact) & 15) == 0);
+  const size_t xbits = xact ? reinterpret_cast<size_t>(xact) : (reinterpret_cast<size_t>(a.xa) | reinterpret_cast<size_t>(a.xb));
+  const bool fast = (a.W % 4 == 0) && ((reinterpret_cast<size_t>(a.dy) & 15) == 0) && ((xbits & 15) == 0);
   if (fast)
     hipLaunchKernelGGL((wgrad_kernel<C, true>), dim3(ctiles * itiles * nsplit), dim3(256), 0, s, a, xact, tiles_x, tiles_y,
                        ctiles, itiles, nsplit, ntiles, cop, cip);
@@ -449,8 +455,8 @@ int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_hea
   // that is never the start of an allocation
   if (!have_act && wgrad_thin_applicable(a, taps, qkv_heads) && wgrad_thin_enabled()) return launch_wgrad_thin(a, dw, db, s);
   const bool wino = wgrad_wino_applicable(a, taps, qkv_heads);
-  const bool plain = !wino && !have_act && !a.coef && !a.act && a.resample == RS_NONE && a.Cb == 0 && a.xa;
-  const float* xact = plain ? a.xa : act_tmp;
+  const bool plain = !wino && !have_act && !a.coef && !a.act && a.resample == RS_NONE && a.xa && (a.Cb == 0 || a.xb);
+  const float* xact = plain ? (a.Cb == 0 ? a.xa : nullptr) : act_tmp;      // nullptr: the kernel reads cat(xa, xb) in place
   if (!have_act && !plain && (rc = launch_act_materialize(a, act_tmp, s))) return rc;
   if (wino) return launch_wgrad_wino(a, xact, dw, db, s);
   if (taps == 9) {

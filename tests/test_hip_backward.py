@@ -91,6 +91,28 @@ def test_conv_wgrad_and_dgrad(lib, shape):
     close(du, gu, what="d(conv input)")
 
 
+@pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,k", [(2, 64, 64, 128, 32, 32, 1), (3, 128, 128, 128, 16, 48, 1), (2, 32, 96, 64, 12, 24, 3)])
+def test_wgrad_reads_an_untransformed_concat_in_place(lib, B, Ca, Cb, Cout, H, W, k):
+    """The decoder's skip projections (adm_blocks.py:150-151): their weight gradient's operand is cat(x, skip) itself -- no transform,
+    no activation --, which the direct kernel now reads from the two tensors in place (round 5: the 537 MB copy at 128^2 is gone)."""
+    tag = f"t/bwd/catwg/{B}_{Ca}_{Cb}_{Cout}_{H}_{W}_{k}"
+    xa, xb = fx.randn(tag + "/xa", B, Ca, H, W), fx.randn(tag + "/xb", B, Cb, H, W)
+    dy = fx.randn(tag + "/dy", B, Cout, H, W)
+    w = torch.zeros(Cout, Ca + Cb, k, k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    gw, gb = torch.autograd.grad(F.conv2d(torch.cat([xa, xb], 1).double(), w, b, padding=k // 2), (w, b), dy.double())
+    lib.prof_enable(True)
+    try:
+        dw, db = lib.op_conv_wgrad(dev(dy), dev(xa), dev(xb), k)
+        torch.cuda.synchronize()
+        names = {r["name"] for r in lib.prof_report()}
+    finally:
+        lib.prof_enable(False)
+    assert "act_materialize_kernel" not in names and any(n.startswith("wgrad_kernel") for n in names), names
+    close(dw, gw, what="dW")
+    close(db, gb, what="db")
+
+
 @pytest.mark.parametrize("case", [
     # (B, Ca, Cb, Hs, Ws, resample, act, film, add_mode, accumulate)
     (2, 64, 0, 8, 8, 0, 1, True, 0, False), (2, 64, 64, 8, 12, 0, 1, False, 1, False), (2, 64, 0, 8, 8, 1, 1, False, 2, True),
