@@ -393,6 +393,8 @@ def test_s128_network_training_step_at_a_winograd_size_vs_oracle(lib):
     assert rows.get("wgrad_wino_kernel", 0) >= 8, rows                              # the 128-channel 3x3 weight gradients
     assert rows.get("wgrad_thin4_kernel", 0) == 2, rows                              # conv_in and out_conv
     assert rows.get("conv1x1_reg_kernel", 0) >= 4, rows                              # the decoder's skip projections and their data gradients
+    assert rows.get("gn_bwd_lds_kernel", 0) >= 8 and rows.get("gn_bwd_reg_kernel", 0) >= 8, rows      # GroupNorm backward: slabs in LDS (64^2) / in registers
+    assert rows.get("act_materialize_kernel", 0) <= 9, rows                          # the skip projections' operand is read in place
     # forward convs of the 64^2 and 32^2 levels and, in the backward, their data-gradient convs
     assert n_plain >= 20 and n_up >= 1, (n_plain, n_up, names)
     close(loss, ref_loss.detach().reshape(1), what="loss")
