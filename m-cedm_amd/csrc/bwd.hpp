@@ -26,6 +26,11 @@ int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_hea
 bool wgrad_wino_applicable(const WgradArgs& a, int taps, int qkv_heads);
 size_t wgrad_wino_scratch_floats(int Cout, int Cin, int taps);     // 0 when the channel counts are not served
 int launch_wgrad_wino(const WgradArgs& a, const float* x, float* dw, float* db, hipStream_t s);
+// the 1x1 weight gradient as a GEMM on the same stage machinery (Cout, Cin multiples of 128, H * W % 64 == 0); its slices are in the
+// direct kernel's scratch layout ([slice][co][ci], bias rows behind them at dbp): wgrad_reduce_kernel finishes both
+size_t wgrad_gemm1_scratch_floats(int Cout, int Cin, int taps);
+bool wgrad_gemm1_applicable(const WgradArgs& a, int taps, const float* x, bool in_place_concat);
+int launch_wgrad_gemm1(const WgradArgs& a, const float* x, float* dbp, int* nslices, hipStream_t s);
 void set_wgrad_wino(int enable);                                   // 1 / 0, -1: default (env MCEDM_WGRAD_WINO, else on)
 // the materialisation step alone: out[B, Ca+Cb, H, W] = resample(act(coef(cat(xa, xb)))); dy / Cout / dwp are not read
 int launch_act_materialize(const WgradArgs& a, float* out, hipStream_t s);

@@ -389,7 +389,9 @@ size_t wgrad_scratch_floats(int Cout, int Cin, int taps) {
   const size_t cop = (Cout + 63) / 64 * 64, cip = (Cin + 63) / 64 * 64;
   const size_t direct = (size_t)wgrad_nsplit_max(Cout, Cin) * (taps * cop * cip + cop);
   const size_t wino = wgrad_wino_scratch_floats(Cout, Cin, taps);          // wgrad_wino.hip: the Winograd-domain partial blocks
-  return direct > wino ? direct : wino;
+  const size_t gemm1 = wgrad_gemm1_scratch_floats(Cout, Cin, taps);        // ... and the 1x1 GEMM form's slices
+  const size_t m = direct > wino ? direct : wino;
+  return m > gemm1 ? m : gemm1;
 }
 
 template <class C>
@@ -459,6 +461,19 @@ int launch_wgrad(const WgradArgs& a, int taps, float* dw, float* db, int qkv_hea
   const float* xact = plain ? (a.Cb == 0 ? a.xa : nullptr) : act_tmp;      // nullptr: the kernel reads cat(xa, xb) in place
   if (!have_act && !plain && (rc = launch_act_materialize(a, act_tmp, s))) return rc;
   if (wino) return launch_wgrad_wino(a, xact, dw, db, s);
+  if (wgrad_gemm1_applicable(a, taps, xact, plain && a.Cb > 0)) {         // 1x1, 128-channel blocks: the GEMM on the Winograd kernel's stage machinery
+    const size_t per_slice = (size_t)a.Cout * Cin + a.Cout;
+    const size_t slices_max = wgrad_gemm1_scratch_floats(a.Cout, Cin, taps) / per_slice;
+    float* dbp = a.dwp + slices_max * (size_t)a.Cout * Cin;
+    int nslices = 0;
+    if ((rc = launch_wgrad_gemm1(a, xact, dbp, &nslices, s))) return rc;
+    const size_t total = (size_t)a.Cout * Cin + a.Cout;
+    ProfScope ps("wgrad_reduce_kernel", (double)nslices * total, 4.0 * ((double)nslices + 1.0) * total, s);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.dwp, dbp, dw, db, a.Cout, Cin, 1, a.Cout, Cin,
+                       nslices, qkv_heads);
+    MCEDM_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return MCEDM_OK;
+  }
   if (taps == 9) {
     if (a.W >= 24) rc = launch_wg<WgCfg<2, 32, 9>>(b, xact, &nact, s);
     else if (a.W >= 12) rc = launch_wg<WgCfg<4, 16, 9>>(b, xact, &nact, s);

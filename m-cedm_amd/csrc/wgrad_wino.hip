@@ -279,6 +279,188 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_kernel(const WgWinoArgs p) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The 1x1 weight gradient on the same machinery (round 5):  dW[co][ci] = sum_px dY[co][px] X[ci][px]  is a plain GEMM over the
+// pixels.  The direct kernel runs it at 0.45 of the matrix rate (a 64 x 64 block per workgroup: 32 MFMAs per wave between two
+// barriers); here a workgroup owns 128 x 128 channels and the stage loop, LDS layout and slot structure of wgw_body, with the
+// four Winograd columns nu standing for the four PIXELS of an aligned quad -- both "transforms" are the identity: an X task is
+// one aligned 16-byte load and four LDS dwords, a stage is 64 consecutive pixels of a sample's plane.  The four accumulator sets
+// are four interleaved partial sums; every (split, nu) is one slice [co][ci] of the direct kernel's scratch layout, so
+// wgrad_reduce_kernel (wgrad_mfma.hip) adds them unchanged (fp64, fixed order).  The operand is read in place, from xa or xb.
+__global__ __launch_bounds__(512, 1) void wgrad_gemm1_kernel(const WgWinoArgs p, const float* __restrict__ xb, int Ca) {
+  extern __shared__ float lds[];
+  const int nsib = p.cib * p.cob;
+  const int bid = blockIdx.x;
+  const int grp8 = bid / (8 * nsib), rem = bid - grp8 * 8 * nsib;
+  const int sib = rem >> 3, split = grp8 * 8 + (rem & 7);
+  if (split >= p.nact) return;
+  const int cb_i = sib % p.cib, cb_o = sib / p.cib;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nu = wave >> 1, coh = wave & 1, l31 = lane & 31, h = lane >> 5;
+  const int s_begin = split * p.per;
+  const int s_end = s_begin + p.per < p.total ? s_begin + p.per : p.total;
+  if (s_begin >= s_end) return;
+  const int G = s_end - s_begin;
+  const unsigned HW = (unsigned)p.H * p.W;
+  const int co0 = cb_o * GW_CB, ci0 = cb_i * GW_CB;
+  // this workgroup's 128 input channels lie in ONE source (Ca % 128 == 0)
+  const bool in_a = ci0 < Ca;
+  const int Csrc = in_a ? Ca : p.Ci - Ca, cs0 = in_a ? ci0 : ci0 - Ca;
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(in_a ? p.x : xb, 4u * (unsigned)p.B * Csrc * HW);
+  const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(p.dy, 4u * (unsigned)p.B * p.Co * HW);
+
+  const int xt = tid & 15;
+  const unsigned xlb = 4u * ((unsigned)(tid >> 4) * HW + 4u * (unsigned)xt);
+  const int xdst = (tid >> 4) * GW_T + 4 * ((xt >> 2) ^ (wave & 3)) + (xt & 3);
+  const int yq = tid & 7;
+  const unsigned ylb = 4u * ((unsigned)(tid >> 3) * HW + 8u * yq);
+  const int ydst = GW_OP + (tid >> 3) * GW_T + 4 * ((yq >> 1) ^ ((tid >> 5) & 3)) + 2 * (yq & 1);
+  int fo[2];
+#pragma unroll
+  for (int grp = 0; grp < 2; ++grp) fo[grp] = l31 * GW_T + 4 * ((2 * grp + h) ^ ((l31 >> 2) & 3));
+
+  int lst = s_begin;
+  int lseg = lst % p.nseg, ln = lst / p.nseg;
+  unsigned g_x, g_y;
+  auto set_geo = [&]() {
+    g_x = 4u * ((unsigned)(ln * Csrc + cs0) * HW + (unsigned)lseg * 64u);
+    g_y = 4u * ((unsigned)(ln * p.Co + co0) * HW + (unsigned)lseg * 64u);
+  };
+  auto advance = [&]() {
+    if (lst + 1 < s_end) {
+      ++lst;
+      if (++lseg == p.nseg) { lseg = 0; ++ln; }
+    }
+    set_geo();
+  };
+  set_geo();
+
+  f32x4 xr[4], yr[2][2];
+  auto load_x = [&](int j) { xr[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, xlb + (g_x + 4u * 32u * (unsigned)j * HW), 0, 0)); };
+  auto load_y = [&](int j) {
+    const unsigned vo = ylb + (g_y + 4u * 64u * (unsigned)j * HW);
+    yr[j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, vo, 0, 0));
+    yr[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, vo, 16, 0));
+  };
+  auto commit_x = [&](int j, float* sb) {
+    float* d = sb + xdst + j * 32 * GW_T;
+    d[0 * GW_PLANE] = xr[j][0];
+    d[1 * GW_PLANE] = xr[j][1];
+    d[2 * GW_PLANE] = xr[j][2];
+    d[3 * GW_PLANE] = xr[j][3];
+  };
+  float bsum[2] = {0.f, 0.f};
+  auto commit_y = [&](int j, float* sb, bool bias) {
+    const f32x4 a = yr[j][0], b = yr[j][1];
+    float* d = sb + ydst + j * 64 * GW_T;
+    *reinterpret_cast<f32x2*>(d + 0 * GW_PLANE) = f32x2{a[0], b[0]};
+    *reinterpret_cast<f32x2*>(d + 1 * GW_PLANE) = f32x2{a[1], b[1]};
+    *reinterpret_cast<f32x2*>(d + 2 * GW_PLANE) = f32x2{a[2], b[2]};
+    *reinterpret_cast<f32x2*>(d + 3 * GW_PLANE) = f32x2{a[3], b[3]};
+    if (bias) bsum[j] += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+  };
+  const bool do_bias = cb_i == 0 && p.dbp != nullptr;
+
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_x(j);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) load_y(j);
+  advance();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) commit_x(j, lds);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) commit_y(j, lds, do_bias);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_x(j);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) load_y(j);
+  advance();
+
+  f32x16 acc[2][4];
+  {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("" : "+v"(z));
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, z, zero16, 0, 0, 0);
+      }
+  }
+  __syncthreads();
+
+  for (int g = 0; g < G; ++g) {
+    const int cur = g & 1;
+    const float* fbuf = lds + cur * GW_STAGE;
+    float* nbuf = lds + (cur ^ 1) * GW_STAGE;
+    const bool cvalid = g + 1 < G;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      const float* xf = fbuf + nu * GW_PLANE + fo[grp];
+      const float* yf = fbuf + GW_OP + nu * GW_PLANE + coh * 64 * GW_T + fo[grp];
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(yf);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(yf + 32 * GW_T);
+      f32x4 bc = *reinterpret_cast<const f32x4*>(xf);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 bn = bc;
+        if (j < 3) bn = *reinterpret_cast<const f32x4*>(xf + (j + 1) * 32 * GW_T);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], bc[s], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], bc[s], acc[1][j], 0, 0, 0);
+        }
+        const int slot = grp * 4 + j;
+        if (slot < 4) { commit_x(slot, nbuf); load_x(slot); }
+        else if (slot < 6) { commit_y(slot - 4, nbuf, do_bias && cvalid); load_y(slot - 4); }
+        if (j < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x286, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (slot == 6) advance();
+        __builtin_amdgcn_sched_barrier(0);
+        bc = bn;
+      }
+    }
+    __syncthreads();
+  }
+
+  // slice (split, nu) of the direct kernel's scratch: [split * 4 + nu][co][ci]
+  float* out = p.part + ((size_t)split * 4 + nu) * p.cop * p.cip;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (2 * coh + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ci = ci0 + 32 * j + l31;
+        out[(size_t)co * p.cip + ci] = acc[i][j][r];
+      }
+  if (do_bias) {                                              // slice split * 4 carries the bias partial, the other three zeros
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float v = bsum[j];
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+      if (yq == 0) {
+        const int co = co0 + (tid >> 3) + 64 * j;
+        p.dbp[((size_t)split * 4 + 0) * p.cop + co] = v;
+        p.dbp[((size_t)split * 4 + 1) * p.cop + co] = 0.f;
+        p.dbp[((size_t)split * 4 + 2) * p.cop + co] = 0.f;
+        p.dbp[((size_t)split * 4 + 3) * p.cop + co] = 0.f;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The 64-channel form (the reference's own ch = 64 network, adm_edm_mcedm_res32: every 3x3 conv is 64 -> 64 or 128 -> 64).
 // With 64 x 64 channels per workgroup the whole 4 x 4 position grid fits one CU: wave w owns xi = w >> 1, 32 output channels
 // (w & 1) x 64 input channels x four nu = 8 accumulator blocks.  A stage is 8 tiles (16 output pixels of one row pair: W % 16
@@ -700,6 +882,67 @@ int launch_wgrad_wino(const WgradArgs& a, const float* x, float* dw, float* db, 
       MCEDM_LAUNCH_CHECK("wgrad_wino_finish_kernel");
     }
   }
+  return MCEDM_OK;
+}
+
+// ---- the 1x1 GEMM form
+static int wgg_env() {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("MCEDM_WGRAD_GEMM1"); env = e ? atoi(e) : 1; }
+  return env;
+}
+static bool wgg_shape_ok(int Cout, int Cin, int taps) { return taps == 1 && Cout > 0 && Cin > 0 && Cout % GW_CB == 0 && Cin % GW_CB == 0; }
+// slices ([co][ci] blocks + bias rows) of the LARGEST split count these channel counts can get
+size_t wgrad_gemm1_scratch_floats(int Cout, int Cin, int taps) {
+  if (!wgg_shape_ok(Cout, Cin, taps) || !wgg_env()) return 0;
+  return (size_t)4 * wgw_nsplit((Cout / GW_CB) * (Cin / GW_CB)) * ((size_t)Cout * Cin + Cout);
+}
+// the operand must be readable in place: one tensor, or cat(xa, xb) with Ca a multiple of 128
+bool wgrad_gemm1_applicable(const WgradArgs& a, int taps, const float* x, bool in_place_concat) {
+  const int Cin = a.Ca + a.Cb;
+  if (!wgg_env() || !wgw_env() || !wgg_shape_ok(a.Cout, Cin, taps)) return false;
+  const unsigned long long HW = (unsigned long long)a.H * a.W;
+  if (HW % 64 != 0 || a.B < 1) return false;
+  if (in_place_concat && (a.Ca % GW_CB != 0 || !a.xa || !a.xb)) return false;
+  if (!in_place_concat && !x) return false;
+  const size_t bits = reinterpret_cast<size_t>(a.dy) | (in_place_concat ? (reinterpret_cast<size_t>(a.xa) | reinterpret_cast<size_t>(a.xb)) : reinterpret_cast<size_t>(x));
+  if (bits & 15) return false;
+  if (4ull * a.B * Cin * HW >= (1ull << 32) || 4ull * a.B * a.Cout * HW >= (1ull << 32)) return false;
+  // enough stages per split to pay for the slices (as for the 64-channel Winograd form)
+  const long long total = (long long)a.B * (long long)(HW / 64);
+  return total >= 4ll * wgw_nsplit((a.Cout / GW_CB) * (Cin / GW_CB));
+}
+
+// x: the single-tensor operand, or nullptr for cat(a.xa, a.xb) in place.  *nslices: slices written (for wgrad_reduce_kernel)
+int launch_wgrad_gemm1(const WgradArgs& a, const float* x, float* dbp, int* nslices, hipStream_t s) {
+  const int Cin = a.Ca + a.Cb;
+  const unsigned long long HW = (unsigned long long)a.H * a.W;
+  WgWinoArgs p{};
+  p.dy = a.dy; p.x = x ? x : a.xa; p.Co = a.Cout; p.Ci = Cin; p.B = a.B; p.H = a.H; p.W = a.W;
+  p.cob = a.Cout / GW_CB; p.cib = Cin / GW_CB; p.cop = a.Cout; p.cip = Cin;
+  p.nseg = (int)(HW / 64); p.th = 0;
+  p.total = a.B * p.nseg;
+  int nsplit = wgw_nsplit(p.cib * p.cob);
+  if (nsplit > p.total) nsplit = p.total;
+  p.per = ceil_div(p.total, nsplit);
+  p.nact = ceil_div(p.total, p.per);
+  p.part = a.dwp;
+  p.dbp = dbp;
+  const int nsib = p.cib * p.cob;
+  const int grid = ceil_div(p.nact, 8) * 8 * nsib;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  MCEDM_HIP_TRY(hipGetDevice(&dev));
+  MCEDM_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  if (!attr_set[dev].load(std::memory_order_acquire)) {
+    MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)wgrad_gemm1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[dev].store(true, std::memory_order_release);
+  }
+  ProfScope ps("wgrad_gemm1_kernel", 2.0 * a.B * (double)HW * a.Cout * Cin, 4.0 * a.B * (double)HW * (a.Cout + Cin), s);
+  // a single-tensor operand is "all in xa": Ca = Cin
+  hipLaunchKernelGGL(wgrad_gemm1_kernel, dim3(grid), dim3(512), 2 * GW_STAGE * sizeof(float), s, p, x ? nullptr : a.xb, x ? Cin : a.Ca);
+  MCEDM_LAUNCH_CHECK("wgrad_gemm1_kernel");
+  *nslices = 4 * p.nact;
   return MCEDM_OK;
 }
 

@@ -91,6 +91,44 @@ def test_conv_wgrad_and_dgrad(lib, shape):
     close(du, gu, what="d(conv input)")
 
 
+@pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,use_coef", [
+    (4, 128, 0, 128, 128, 128, False),      # one tensor read in place; 1024 stages = 4 per split
+    (2, 128, 128, 128, 128, 128, False),    # the decoder's skip projection: cat(x, skip) read in place from two tensors
+    (5, 128, 0, 256, 64, 128, True),        # a transformed (materialised) operand, two output-channel blocks, ragged splits
+])
+def test_wgrad_1x1_gemm_form(lib, B, Ca, Cb, Cout, H, W, use_coef):
+    """wgrad_gemm1_kernel (round 5): the 1x1 weight gradient of 128-channel blocks as a GEMM on the Winograd weight-gradient kernel's
+    stage machinery, its slices finished by the direct kernel's reduction.  Against fp64 autograd, bit-reproducible."""
+    tag = f"t/bwd/gemm1/{B}_{Ca}_{Cb}_{Cout}_{H}_{W}"
+    Cin = Ca + Cb
+    xa = fx.randn(tag + "/xa", B, Ca, H, W)
+    xb = fx.randn(tag + "/xb", B, Cb, H, W) if Cb else None
+    dy = fx.randn(tag + "/dy", B, Cout, H, W)
+    coef = torch.stack([fx.randn(tag + "/m", B, Cin) * 0.3, 1 + 0.3 * fx.randn(tag + "/s", B, Cin), 0.2 * fx.randn(tag + "/o", B, Cin),
+                        torch.zeros(B, Cin)], dim=-1) if use_coef else None
+    x = (torch.cat([xa, xb], 1) if Cb else xa).double()
+    if use_coef:
+        c = coef.double()
+        x = F.silu((x - c[:, :, 0, None, None]) * c[:, :, 1, None, None] + c[:, :, 2, None, None])
+    w = torch.zeros(Cout, Cin, 1, 1, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    gw, gb = torch.autograd.grad(F.conv2d(x, w, b), (w, b), dy.double())
+    kw = dict(coef=dev(coef), act=1) if use_coef else {}
+    lib.prof_enable(True)
+    try:
+        dw, db = lib.op_conv_wgrad(dev(dy), dev(xa), dev(xb) if Cb else None, 1, **kw)
+        torch.cuda.synchronize()
+        names = {r["name"] for r in lib.prof_report()}
+    finally:
+        lib.prof_enable(False)
+    assert "wgrad_gemm1_kernel" in names and not any(n.startswith("wgrad_kernel") for n in names), names
+    assert ("act_materialize_kernel" in names) == use_coef, names
+    close(dw, gw, what="dW")
+    close(db, gb, what="db")
+    dw2, db2 = lib.op_conv_wgrad(dev(dy), dev(xa), dev(xb) if Cb else None, 1, **kw)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,k", [(2, 64, 64, 128, 32, 32, 1), (3, 128, 128, 128, 16, 48, 1), (2, 32, 96, 64, 12, 24, 3)])
 def test_wgrad_reads_an_untransformed_concat_in_place(lib, B, Ca, Cb, Cout, H, W, k):
     """The decoder's skip projections (adm_blocks.py:150-151): their weight gradient's operand is cat(x, skip) itself -- no transform,
