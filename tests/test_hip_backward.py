@@ -313,6 +313,24 @@ def test_attention_backward_vs_oracle(lib, B, heads, hw):
     close(unpacked_qkv(dqkv.cpu(), heads), ref, what="dqkv")
 
 
+@pytest.mark.parametrize("hw,scale", [((16, 16), 4.0), ((32, 32), 6.0), ((6, 6), 6.0)])
+def test_attention_backward_with_large_scores(lib, hw, scale):
+    """The LDS-staged dq kernel normalises the scores ONLINE (running maximum and sum, rescaled when the maximum moves) and in base 2:
+    with q, k scaled so that the scores span +-100 and more (softmax rows nearly one-hot, maxima that move many times along the key axis)
+    nothing may overflow, and the gradients must still match fp64 autograd.  T = 256 / 1024: LDS kernels; T = 36: the two-pass statistics."""
+    B, heads = 2, 1
+    qkv = fx.randn(f"t/bwd/attn/big/{hw}", B, heads * 192, *hw) * scale
+    da = fx.randn(f"t/bwd/attn/big/da/{hw}", B, heads * 64, *hw)
+    q64 = qkv.double().requires_grad_(True)
+    a = orc.attention(q64, heads)
+    (ref,) = torch.autograd.grad(a, q64, da.double())
+    pq = dev(packed_qkv(qkv, heads))
+    dqkv = lib.op_attention_bwd(pq, lib.op_attention(pq, heads), dev(da), heads)
+    got = unpacked_qkv(dqkv.cpu(), heads)
+    assert torch.isfinite(got).all()
+    close(got, ref, what="dqkv (large scores)")
+
+
 def make_plan(L, cfg):
     return L.Plan(cfg.in_channels, cfg.cond_channels, cfg.out_ch, cfg.ch, cfg.ch_mult, cfg.num_res_blocks,
                   cfg.attn_resolutions, cfg.resolution)
