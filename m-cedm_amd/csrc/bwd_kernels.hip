@@ -917,15 +917,17 @@ constexpr float ATT_LOG2E = 1.4426950408889634f;
 // the end -- and (m + log l, delta = sum_c dA A) go to `lse` for the second kernel.
 __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ a,
                                                               const float* __restrict__ da, float* __restrict__ lse,
-                                                              float* __restrict__ dqkv, int T) {
+                                                              float* __restrict__ dqkv, int T, int xmap) {
   __shared__ float Kc[2][64 * 32], Vc[2][64 * 32], Kt[2][32 * ATP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const size_t bh = blockIdx.y;
+  int bx_, by_;
+  xcd_group_map(xmap, bx_, by_);
+  const size_t bh = by_;
   const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
   const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
   const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
   const float* dA = da + bh * 64 * (size_t)T;
-  const int q = blockIdx.x * 128 + 32 * wave + l31;
+  const int q = bx_ * 128 + 32 * wave + l31;
   float qreg[32], dareg[32];
   float delta = 0.f;
 #pragma unroll
@@ -1018,15 +1020,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_lds_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ da,
-                                                               const float* __restrict__ lse, float* __restrict__ dqkv, int T) {
+                                                               const float* __restrict__ lse, float* __restrict__ dqkv, int T, int xmap) {
   __shared__ float Qc[2][64 * 32], Ac[2][64 * 32], Qt[2][32 * ATP], At[2][32 * ATP], Ls[2][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const size_t bh = blockIdx.y;
+  int bx_, by_;
+  xcd_group_map(xmap, bx_, by_);
+  const size_t bh = by_;
   const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
   const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
   const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
   const float* dA = da + bh * 64 * (size_t)T;
-  const int key = blockIdx.x * 128 + 32 * wave + l31;
+  const int key = bx_ * 128 + 32 * wave + l31;
   float kreg[32], vreg[32];
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
@@ -1123,9 +1127,11 @@ int launch_attention_bwd(const float* qkv, const float* a, const float* da, floa
   }
   if (lds_path) {
     const dim3 g4(T / 128, B * heads);
-    hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, g4, dim3(256), 0, s, qkv, a, da, lse, dqkv, T);
+    static int xmap = -1;
+    if (xmap < 0) { const char* e = getenv("MCEDM_ATTN_XCD"); xmap = e ? atoi(e) : 1; }
+    hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, g4, dim3(256), 0, s, qkv, a, da, lse, dqkv, T, xmap);
     MCEDM_LAUNCH_CHECK("attn_bwd_dq_lds_kernel");
-    hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, g4, dim3(256), 0, s, qkv, da, lse, dqkv, T);
+    hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, g4, dim3(256), 0, s, qkv, da, lse, dqkv, T, xmap);
   } else if (T >= 128) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, grid, dim3(256), 0, s, qkv, da, lse, dqkv, T);
     MCEDM_LAUNCH_CHECK("attn_bwd_dq_kernel");

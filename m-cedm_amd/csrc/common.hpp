@@ -61,6 +61,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+#ifdef __HIPCC__
+// 2-D grid (nx tiles of one (sample, head) along x, ny = B * heads along y): the nx workgroups that stream the SAME keys / values land on
+// ONE XCD (workgroup ids go round-robin over the 8 XCDs in dispatch order, x fastest), so that after the first of them the others
+// find the streamed tiles in that XCD's L2.  A bijection of the grid; ny % 8 != 0 (or map == 0): the identity.
+__device__ __forceinline__ void xcd_group_map(int map, int& bx, int& by) {
+  const int nx = gridDim.x, ny = gridDim.y;
+  bx = blockIdx.x; by = blockIdx.y;
+  if (!map || (ny & 7) != 0) return;
+  const int lin = bx + by * nx;
+  const int c = lin & 7, i = lin >> 3;
+  by = (i / nx) * 8 + c;
+  bx = i - (i / nx) * nx;
+}
+#endif
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------

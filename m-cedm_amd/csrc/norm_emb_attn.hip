@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64 * KW) __attribute__((amdgpu_waves_per_eu(3, 3)))
 // other's MFMAs) and the halves are merged in LDS at the end, half 0 first (a fixed order: bitwise reproducible).
 // K tile [64 ch][32 KH keys]; V tile transposed to [32 KH keys][64 ch] with pitch 65: both MFMA operand reads lane-linear.
 template <int KH>
-__global__ __launch_bounds__(256 * KH) void attention_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T) {
+__global__ __launch_bounds__(256 * KH) void attention_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int xmap) {
   constexpr int VP = 65, NK = 32 * KH;                     // pitch of the transposed V tile; keys per staged tile
   constexpr int KS_F = 64 * NK, VS_F = NK * VP;
   extern __shared__ float lds[];                           // ks[2][KS_F] | vs[2][VS_F]; reused for the merge
@@ -522,8 +522,10 @@ __global__ __launch_bounds__(256 * KH) void attention_lds_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = wave & 3, hf = wave >> 2;
   const int l31 = lane & 31, h = lane >> 5;
-  const int q0 = (blockIdx.x * 4 + qt) * 32;
-  const size_t bh = blockIdx.y;
+  int bx_, by_;
+  xcd_group_map(xmap, bx_, by_);
+  const int q0 = (bx_ * 4 + qt) * 32;
+  const size_t bh = by_;
   const float* Q = qkv + (bh * 3 + 0) * 64 * (size_t)T;
   const float* K = qkv + (bh * 3 + 1) * 64 * (size_t)T;
   const float* V = qkv + (bh * 3 + 2) * 64 * (size_t)T;
@@ -654,7 +656,9 @@ static int launch_attention_lds(const float* qkv, float* out, int B, int heads, 
     MCEDM_HIP_TRY(hipFuncSetAttribute((const void*)attention_lds_kernel<KH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set[dev].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(attention_lds_kernel<KH>, dim3(ceil_div(T, 128), B * heads), dim3(256 * KH), lds_bytes, stream, qkv, out, T);
+  static int xmap = -1;                                    // MCEDM_ATTN_XCD=0: workgroups in dispatch order (A/B runs)
+  if (xmap < 0) { const char* e = getenv("MCEDM_ATTN_XCD"); xmap = e ? atoi(e) : 1; }
+  hipLaunchKernelGGL(attention_lds_kernel<KH>, dim3(ceil_div(T, 128), B * heads), dim3(256 * KH), lds_bytes, stream, qkv, out, T, xmap);
   return MCEDM_OK;
 }
 
