@@ -129,6 +129,36 @@ def test_wgrad_1x1_gemm_form(lib, B, Ca, Cb, Cout, H, W, use_coef):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("B,H,W,gemm", [(8, 64, 64, True), (2, 16, 16, False)])
+def test_qkv_weight_gradient_rows_in_packed_order(lib, B, H, W, gemm):
+    """The attention projection's weight gradient (adm_blocks.py:176): dy arrives with its rows in the packed (head, {q,k,v}, c) order of
+    the attention kernels and the parameter wants (head, c, {q,k,v}).  Both 1x1 forms -- the direct kernel and, with enough pixels,
+    wgrad_gemm1_kernel -- leave the row permutation to wgrad_reduce_kernel."""
+    heads, Cin = 2, 128
+    Cout = heads * 192
+    tag = f"t/bwd/qkvwg/{B}_{H}_{W}"
+    x = fx.randn(tag + "/x", B, Cin, H, W)
+    dy = fx.randn(tag + "/dy", B, Cout, H, W)                 # packed row order
+    dwp = torch.einsum("bohw,bihw->oi", dy.double(), x.double())
+    dbp = dy.double().sum(dim=(0, 2, 3))
+    per, d = Cout // heads, Cout // heads // 3
+    idx = torch.empty(Cout, dtype=torch.long)                  # reference row co <- packed row cp
+    for cp in range(Cout):
+        hh, rr = divmod(cp, per)
+        which, c = divmod(rr, d)
+        idx[hh * per + c * 3 + which] = cp
+    lib.prof_enable(True)
+    try:
+        dw, db = lib.op_conv_wgrad(dev(dy), dev(x), None, 1, qkv_heads=heads)
+        torch.cuda.synchronize()
+        names = {r["name"] for r in lib.prof_report()}
+    finally:
+        lib.prof_enable(False)
+    assert ("wgrad_gemm1_kernel" in names) == gemm, names
+    close(dw.reshape(Cout, Cin), dwp[idx], what="dW")
+    close(db, dbp[idx], what="db")
+
+
 @pytest.mark.parametrize("B,Ca,Cb,Cout,H,W,k", [(2, 64, 64, 128, 32, 32, 1), (3, 128, 128, 128, 16, 48, 1), (2, 32, 96, 64, 12, 24, 3)])
 def test_wgrad_reads_an_untransformed_concat_in_place(lib, B, Ca, Cb, Cout, H, W, k):
     """The decoder's skip projections (adm_blocks.py:150-151): their weight gradient's operand is cat(x, skip) itself -- no transform,
