@@ -1,11 +1,11 @@
 """In-kernel timeline of the Winograd conv: per-workgroup stamps (start, prologue end, K loop end, end).
-    MCEDM_WINO_MODE=1 python tools/wino_timeline.py [B cin hw]"""
+    MCEDM_WINO_MODE=1 python tools/wino_timeline.py [B cin hw [cout]]      (cout 64: the 256-thread WinoCfg<2> variant)"""
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = importlib.import_module("m-cedm_amd.lib")
 B, cin, hw = (int(v) for v in (sys.argv[1:4] + ["32", "128", "128"][len(sys.argv) - 1:]))
-cout = 128
+cout = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 x = torch.randn(B, cin, hw, hw, device="cuda")
 w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
 b = torch.randn(cout, device="cuda")
