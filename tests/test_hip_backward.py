@@ -307,6 +307,34 @@ np.savez(sys.argv[2], **out)
     assert np.array_equal(res["100"]["dx0"], res["100"]["dx1"]) and np.array_equal(res["0"]["dx0"], res["0"]["dx1"])
 
 
+def test_gn_backward_on_chip_under_contention(lib):
+    """gn_bwd_lds_kernel's workgroups wait (bounded) for partners that may not be resident yet.  Run it on one stream while another
+    stream keeps the CUs busy with large convolutions, twenty times: every result must equal the quiet run bit for bit (whichever
+    mix of "partner arrived" / "recomputed" each workgroup saw), nothing may hang, and the exchange area must come back zero."""
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 8, 128, 128, 128
+    x = (torch.randn(B, C, H, W, generator=g) * 1.3 + 0.4).cuda()
+    dact = torch.randn(B, C, H, W, generator=g).cuda()
+    gamma, beta = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    coef, stats = lib.op_gn_coef(x, None, gamma, beta, want_stats=True)
+    sync = torch.zeros(lib.GN_SYNC_WORDS * B * 32, dtype=torch.int32, device="cuda")
+    quiet = lib.op_gn_bwd(dact, x, None, coef, stats, gamma, beta, act=1, sync=sync)[0].clone()
+    torch.cuda.synchronize()
+    # the contender: 3x3 convs of the same size on a second stream
+    wc = (torch.randn(128, 128, 3, 3, generator=g) / 34.0).cuda()
+    wino = lib.op_pack_conv_wino(wc)
+    side = torch.cuda.Stream()
+    ycon = torch.empty(B, 128, H, W, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            lib.op_conv_wino(x, None, wino, None, 128, out=ycon)
+    for rep in range(20):
+        got = lib.op_gn_bwd(dact, x, None, coef, stats, gamma, beta, act=1, sync=sync)[0]
+        assert torch.equal(got, quiet), rep
+    torch.cuda.synchronize()
+    assert int(sync.abs().sum()) == 0
+
+
 def packed_qkv(qkv, heads):
     B, C3, H, W = qkv.shape
     d = C3 // heads // 3
