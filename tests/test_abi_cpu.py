@@ -34,6 +34,13 @@ def test_library_exports_every_declared_symbol():
     assert exported == names, (set(exported) ^ set(names))
     assert sorted(set(L.EXPORTS + L.OP_EXPORTS)) == names, set(L.EXPORTS + L.OP_EXPORTS) ^ set(names)
     assert lib.mcedm_version() == 4
+    # the header's constants the binding mirrors
+    hdr = open(HEADER).read()
+    consts = {k: int(v) for k, v in re.findall(r"#define (MCEDM_[A-Z0-9_]+) (\d+)\b", hdr)}
+    assert consts["MCEDM_ABI_VERSION"] == L.ABI_VERSION == 4
+    assert consts["MCEDM_GN_SYNC_WORDS"] == L.GN_SYNC_WORDS
+    for name, idx in L.VARIANTS.items():
+        assert consts["MCEDM_VARIANT_" + name.upper()] == idx, name
 
 
 def test_plan_parameter_table_matches_state_dict_order():
